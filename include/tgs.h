@@ -1,0 +1,174 @@
+/* tgs.h -- C ABI of libtgs_hip.so: the MI355X (gfx950) Gaussian-splatting hot path of Touch-GS.
+ *
+ * This is the drop-in boundary of SURVEY.md section 8(b).  Nothing in the reference tree calls C
+ * (the reference shells out to `ns-train depth-gaussian-splatting`, scripts/train_bunny_real.sh:52,
+ * whose rasterizer lives in an un-vendored submodule, .gitmodules:7-9), so each entry point cites
+ * the reference-side *operator* it stands behind: the gsplat-0.1-shaped ops that nerfstudio's
+ * Splatfacto model calls and the INRIA-shaped GaussianRasterizer (App. A.1).
+ * The ctypes binding a maintainer adds is shown in INTEGRATION.md and lives in
+ * touch_gs_amd/_lib.py.
+ *
+ * Conventions
+ *  - plain pointers + sizes only; all pointers are DEVICE pointers unless marked [host];
+ *    the caller (PyTorch) owns every buffer; the library never allocates device memory.
+ *  - all work is enqueued on `stream` (a hipStream_t passed as void*); no hidden sync.
+ *  - returns 0 (TGS_OK) or a negative TgsStatus; message via tgs_last_error() (thread-local).
+ *  - fp32 / int32, contiguous row-major.  No float atomics anywhere: results are
+ *    bit-reproducible run to run.
+ */
+#ifndef TGS_H
+#define TGS_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TGS_VERSION 100         /* 0.1.0 */
+#define TGS_BLOCK 16            /* tile edge in pixels */
+#define TGS_SPLAT_FLOATS 12     /* floats per projected-splat record */
+#define TGS_PARTIAL_FLOATS 12   /* floats per (tile,Gaussian) partial-gradient record */
+#define TGS_GROUP 256           /* Gaussians per binning group */
+
+typedef enum TgsStatus {
+  TGS_OK = 0,
+  TGS_E_ARG = -1,        /* bad argument */
+  TGS_E_HIP = -2,        /* a HIP runtime call failed */
+  TGS_E_CAPACITY = -3    /* intersection capacity too small (see tgs_bin_sort) */
+} TgsStatus;
+
+/* Camera + frame constants.  viewmat: row-major world->camera, OpenCV axes
+ * (x right, y down, z forward). */
+typedef struct TgsCamera {
+  float viewmat[16];
+  float fx, fy, cx, cy;
+  int32_t W, H;
+  float near_plane;   /* 0.01 */
+  float pix_center;   /* 0.5  */
+  float bg[3];
+  float glob_scale;   /* 1.0  */
+} TgsCamera;
+
+/* Fused training loss evaluated inside the compositing backward:
+ *   L = l1_weight * sum|C - gt_rgb|  +  sum_{gt_depth>0} depth_weight * w(U) * (D/alpha - gt_depth)^2
+ *   w(U) = 1 (SIMPLE_LOSS) or 1/(uncertainty_weight*U + eps) (DEPTH_UNCERTAINTY_WEIGHTED_LOSS).
+ * The caller folds the means in: l1_weight = (1-ssim_lambda)/(3*H*W), depth_weight =
+ * depth_loss_mult / #valid.  Any pointer may be NULL to drop its term. */
+typedef struct TgsLossSpec {
+  const float* gt_rgb;      /* [H,W,3] */
+  const float* gt_depth;    /* [H,W]   (0 = no supervision) */
+  const float* uncertainty; /* [H,W]   (NULL => SIMPLE_LOSS) */
+  float l1_weight;
+  float depth_weight;
+  float uncertainty_weight;
+  float eps;                /* 1e-6 */
+} TgsLossSpec;
+
+/* Adam hyper-parameters for tgs_adam_step: the flat parameter buffer is
+ *   means[3N] | log_scales[3N] | quats[4N] | opac_logit[N] | sh[N*K*3]
+ * where every segment starts at the next multiple of 4 floats (16-byte aligned views; the total
+ * is rounded up to a multiple of 4 too), with one learning rate per group, SH split into DC (k=0)
+ * and the rest.  Pad elements must carry zero gradient. */
+typedef struct TgsAdamSpec {
+  float lr_means, lr_scales, lr_quats, lr_opac, lr_sh_dc, lr_sh_rest;
+  float beta1, beta2, eps;
+  float bias_corr1, bias_corr2;   /* 1-beta1^t, 1-beta2^t */
+} TgsAdamSpec;
+
+int tgs_version(void);
+const char* tgs_last_error(void);
+
+/* Number of binning groups / tiles for sizing the caller's buffers. */
+int tgs_num_groups(int N);                 /* ceil(N/TGS_GROUP) */
+int tgs_num_tiles(int W, int H);           /* ceil(W/16)*ceil(H/16) */
+/* Bytes of scratch tgs_bin_sort needs for a given intersection capacity. */
+size_t tgs_sort_scratch_bytes(int64_t capacity);
+
+/* K1  projection + 3D->2D covariance + SH colour  (stands behind gsplat `project_gaussians`
+ *     + `spherical_harmonics`; INRIA preprocess, App. A.1; spec App. B.1-B.5).
+ * in : means[N,3] log_scales[N,3] quats[N,4] (w,x,y,z un-normalised) opac_logit[N]
+ *      sh[N,sh_stride,3] (NULL or sh_deg<0 => colours taken from `colors_in`[N,3] or zero)
+ * out: splats[N,12] = {x, y, depth, opacity, conic a, b, c, r, g, b, radius(int32 bits), 0};
+ *      culled Gaussians have radius 0. */
+int tgs_project_fwd(const TgsCamera* cam /*[host]*/, int N, const float* means,
+                    const float* log_scales, const float* quats, const float* opac_logit,
+                    const float* sh, int sh_stride, int sh_deg, const float* colors_in,
+                    float* splats, void* stream);
+
+/* K2-K5  tile binning + per-tile depth sort  (stands behind gsplat `map_gaussian_to_intersects`,
+ *     the CUB radix sort and `get_tile_bin_edges` inside `rasterize_gaussians`; spec App. B.4, B.6).
+ * in : splats[N,12] (slot 11 is overwritten with the in-group intersection offset)
+ * out: group_base[G]    start of each 256-Gaussian group's contiguous range in the pair index
+ *                       space (G = tgs_num_groups; ranges are disjoint, their order is arbitrary)
+ *      tile_start[T+1]  [start,end) of every tile's list; tile_start[T] = #intersections
+ *      sorted_gid[cap]  Gaussian ids, per tile, front to back, ties by id
+ *      status[2]        {#intersections, overflow flag}; if #intersections > capacity nothing
+ *                       past the scans is written, overflow=1 (caller grows and retries)
+ * tmp: tile_cursor[T], scratch (tgs_sort_scratch_bytes(capacity)). */
+int tgs_bin_sort(const TgsCamera* cam /*[host]*/, int N, float* splats, int32_t* group_base,
+                 int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
+                 int64_t capacity, void* scratch, int32_t* status, void* stream);
+
+/* K6  per-tile front-to-back compositing of RGB + depth in ONE pass  (stands behind gsplat
+ *     `rasterize_gaussians` fwd, called twice by Splatfacto for rgb and depth; spec App. B.6).
+ * out: out_rgb[H,W,3] (incl. background)  out_depth[H,W] (= sum w*depth, NOT divided by alpha)
+ *      final_T[H,W]  final_idx[H,W] (list position of the last contributor, -1 if none) */
+int tgs_rasterize_fwd(const TgsCamera* cam /*[host]*/, const float* splats,
+                      const int32_t* sorted_gid, const int32_t* tile_start,
+                      float* out_rgb, float* out_depth, float* final_T, int32_t* final_idx,
+                      void* stream);
+
+/* K7  compositing backward with the tactile depth/uncertainty loss fused in  (stands behind
+ *     gsplat `rasterize_gaussians` bwd; spec App. B.7).
+ * in : v_rgb[H,W,3] v_depth[H,W] v_alpha[H,W] upstream grads (each may be NULL);
+ *      loss (may be NULL) adds dL/d(out) of the fused loss computed from out_rgb/out_depth/final_T;
+ * out: partials[#intersections,12] one record per (tile,Gaussian) pair, addressed by the pair's
+ *      pre-sort index = group_base[g/256] + splat[g].slot11 + index of the tile in g's rect:
+ *      {v_x, v_y, v_depth, v_opacity, v_a, v_b, v_c, v_r, v_g, v_b, 0, 0}
+ *      tile_loss[T,2] (may be NULL) per-tile {sum|C-gt|*l1_weight, depth-term} of the fused loss */
+int tgs_rasterize_bwd(const TgsCamera* cam /*[host]*/, const float* splats,
+                      const int32_t* group_base, const int32_t* sorted_gid,
+                      const int32_t* tile_start, const float* out_rgb, const float* out_depth,
+                      const float* final_T, const int32_t* final_idx,
+                      const float* v_rgb, const float* v_depth, const float* v_alpha,
+                      const TgsLossSpec* loss /*[host]*/, float* partials, float* tile_loss,
+                      void* stream);
+
+/* K8a segmented reduction of the partials to one gradient record per Gaussian
+ *     out: v_splats[N,12] = {v_x, v_y, v_depth, v_opacity, v_a, v_b, v_c, v_r, v_g, v_b, 0, 0}. */
+int tgs_reduce_partials(int N, const float* splats, const int32_t* group_base,
+                        const TgsCamera* cam /*[host]*/, const float* partials, float* v_splats,
+                        void* stream);
+
+/* K8  projection + SH backward  (stands behind gsplat `project_gaussians` bwd +
+ *     `spherical_harmonics` bwd; spec App. B.8).
+ * in : either partials (+group_base) -> reduced on the fly, or v_splats[N,12] (partials NULL)
+ * out: v_means[N,3] v_log_scales[N,3] v_quats[N,4] v_opac_logit[N] v_sh[N,sh_stride,3]
+ *      (all overwritten; v_sh may be NULL), v_xy[N,2] (may be NULL) = screen-space mean gradient (the
+ *      INRIA `means2D.grad`), used for densification statistics. */
+int tgs_project_bwd(const TgsCamera* cam /*[host]*/, int N, const float* means,
+                    const float* log_scales, const float* quats, const float* opac_logit,
+                    const float* sh, int sh_stride, int sh_deg, const float* splats,
+                    const int32_t* group_base, const float* partials, const float* v_splats,
+                    float* v_means, float* v_log_scales, float* v_quats, float* v_opac_logit,
+                    float* v_sh, float* v_xy, void* stream);
+
+/* K9  fused Adam over the flat parameter buffer (torch.optim.Adam semantics, no weight decay). */
+int tgs_adam_step(int N, int sh_stride, float* params, const float* grads, float* exp_avg,
+                  float* exp_avg_sq, const TgsAdamSpec* spec /*[host]*/, float grad_scale,
+                  void* stream);
+
+/* K10 SSIM (11x11 Gaussian window, sigma 1.5, zero padding) forward + gradient image; the
+ *     (1-SSIM) term of the Splatfacto-style loss.
+ * out: block_partials[3*ceil(H/16)*ceil(W/16)] per-block sums of the SSIM map (deterministic;
+ *      mean SSIM = sum / (3*H*W)),
+ *      v_img[H,W,3] = weight * d(sum of SSIM map)/d(img)   (NULL => forward only)
+ * tmp: scratch[9*H*W] floats (needed when v_img != NULL). */
+int tgs_ssim_fwd_bwd(int W, int H, const float* img, const float* gt, float weight,
+                     float* block_partials, float* v_img, float* scratch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TGS_H */

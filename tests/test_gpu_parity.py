@@ -1,0 +1,347 @@
+"""GPU parity tests: every HIP kernel against the CPU oracle on identical seeded inputs.
+
+The oracle is the build's own restatement of the published algorithm (parity UNPINNED against the
+reference rasterizer, whose source is absent -- see oracle/__init__.py).  Tolerances: 1e-4
+relative on RGB/depth (BASELINE.json north_star) for every pixel whose threshold tests are not
+decision-ambiguous under fp32 rounding; integer outputs exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_oracle as O
+from tests.util import amd_cam, rect_from, relerr, scene, splat_fields, to_dev
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _project(dev, P, cam, deg):
+    from touch_gs_amd import ops
+    D = to_dev(P, dev)
+    sp = ops.project_fwd(amd_cam(cam), D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], deg)
+    return D, sp
+
+
+@pytest.mark.parametrize("N,W,H,deg,seed", [(2000, 160, 96, 3, 1), (500, 80, 48, 0, 2), (3000, 200, 120, 2, 3),
+                                            (1000, 100, 70, 1, 4)])
+def test_project_fwd(dev, N, W, H, deg, seed):
+    P, cam = scene(N, W, H, deg, seed)
+    _, sp = _project(dev, P, cam, deg)
+    f = splat_fields(sp)
+    pr = O.project(P["means"], P["log_scales"], P["quats"], P["opac_logit"], P["sh"], cam, deg)
+    v = pr["valid"]
+    # integer decisions: radius may differ only where 3*sqrt(lam1) sits within fp32 noise of an integer
+    same = (f["radius"] == pr["radius"])
+    assert same.float().mean() > 0.995, f"radius mismatch fraction {1 - same.float().mean():.4f}"
+    both = v & same & (f["radius"] > 0)
+    assert both.sum() > 0.5 * v.sum()
+    for k in ("xy", "conic", "rgb"):
+        e = relerr(f[k][both], pr[k][both], floor=1e-3)
+        assert e.max() < TOL, (k, e.max())
+    assert relerr(f["depth"][both], pr["depth"][both]).max() < 1e-5
+    assert relerr(f["opac"], pr["opac"]).max() < 1e-5
+    assert relerr(f["rgb"], pr["rgb"], floor=1e-3).max() < TOL  # colour defined for every Gaussian
+
+
+@pytest.mark.parametrize("N,W,H,seed", [(3000, 160, 96, 5), (800, 50, 35, 6), (20000, 320, 200, 7)])
+def test_bin_sort_exact(dev, N, W, H, seed):
+    from touch_gs_amd import ops
+    P, cam = scene(N, W, H, 0, seed)
+    _, sp = _project(dev, P, cam, 0)
+    gb, ts, sg, st = ops.bin_sort(amd_cam(cam), sp)
+    f = splat_fields(sp)
+    rect = rect_from(f["xy"], f["radius"], cam)
+    gid, tstart = O.bin_and_sort(rect, f["radius"] > 0, f["depth"], cam)
+    n, ovf = st.tolist()
+    assert ovf == 0 and n == len(gid)
+    assert np.array_equal(ts.cpu().numpy().astype(np.int64), tstart)
+    assert np.array_equal(sg[:n].cpu().numpy().astype(np.int64), gid)
+
+
+def _blend_inputs(dev, N, W, H, deg, seed, **kw):
+    from touch_gs_amd import ops
+    P, cam = scene(N, W, H, deg, seed, **kw)
+    D, sp = _project(dev, P, cam, deg)
+    acam = amd_cam(cam)
+    gb, ts, sg, st = ops.bin_sort(acam, sp)
+    n = st.tolist()[0]
+    return P, cam, acam, D, sp, gb, ts, sg, n
+
+
+@pytest.mark.parametrize("N,W,H,deg,seed", [(3000, 160, 96, 3, 11), (600, 50, 35, 1, 12), (8000, 256, 144, 0, 13)])
+def test_rasterize_fwd(dev, N, W, H, deg, seed):
+    from touch_gs_amd import ops
+    P, cam, acam, D, sp, gb, ts, sg, n = _blend_inputs(dev, N, W, H, deg, seed)
+    rgb, depth, fT, fidx = ops.rasterize_fwd(acam, sp, sg, ts)
+    f = splat_fields(sp)
+    out = O.blend(f["xy"], f["conic"], f["opac"], f["rgb"], f["depth"],
+                  sg[:n].cpu().numpy().astype(np.int64), ts.cpu().numpy().astype(np.int64), cam, want_margin=True)
+    clear = (out["margin"] > 1e-3).numpy()
+    assert clear.mean() > 0.9
+    er = relerr(rgb.cpu().numpy(), out["rgb"].numpy(), floor=1e-2)
+    ed = relerr(depth.cpu().numpy(), out["depth_acc"].numpy(), floor=1e-2)
+    eT = np.abs(fT.cpu().numpy() - out["final_T"].numpy())
+    assert er[clear].max() < TOL and ed[clear].max() < TOL and eT[clear].max() < TOL
+    assert np.array_equal(fidx.cpu().numpy()[clear], out["final_idx"].numpy()[clear])
+    # ambiguous pixels may flip one threshold decision: bounded by one alpha_min-level contribution
+    assert np.abs(rgb.cpu().numpy() - out["rgb"].numpy()).max() < 0.02
+
+
+@pytest.mark.parametrize("N,W,H,deg,seed", [(2000, 128, 80, 3, 21), (500, 50, 35, 0, 22)])
+def test_rasterize_bwd(dev, N, W, H, deg, seed):
+    from touch_gs_amd import ops
+    P, cam, acam, D, sp, gb, ts, sg, n = _blend_inputs(dev, N, W, H, deg, seed)
+    rgb, depth, fT, fidx = ops.rasterize_fwd(acam, sp, sg, ts)
+    g = torch.Generator().manual_seed(seed)
+    v_rgb = torch.randn(H, W, 3, generator=g, dtype=torch.float64)
+    v_d = torch.randn(H, W, generator=g, dtype=torch.float64)
+    v_a = torch.randn(H, W, generator=g, dtype=torch.float64)
+    partials, _ = ops.rasterize_bwd(acam, sp, gb, sg, ts, rgb, depth, fT, fidx,
+                                    v_rgb.float().to(dev), v_d.float().to(dev), v_a.float().to(dev))
+    v = ops.reduce_partials(acam, sp, gb, partials).cpu().double()
+    f = splat_fields(sp)
+    leaves = {k: f[k].clone().requires_grad_(True) for k in ("xy", "conic", "opac", "rgb", "depth")}
+    out = O.blend(leaves["xy"], leaves["conic"], leaves["opac"], leaves["rgb"], leaves["depth"],
+                  sg[:n].cpu().numpy().astype(np.int64), ts.cpu().numpy().astype(np.int64), cam, want_margin=True)
+    L = (out["rgb"] * v_rgb).sum() + (out["depth_acc"] * v_d).sum() + (out["alpha"] * v_a).sum()
+    L.backward()
+    frac_clear = (out["margin"] > 1e-3).double().mean().item()
+    ref = dict(xy=leaves["xy"].grad, depth=leaves["depth"].grad, opac=leaves["opac"].grad,
+               conic=leaves["conic"].grad, rgb=leaves["rgb"].grad)
+    got = dict(xy=v[:, 0:2], depth=v[:, 2], opac=v[:, 3], conic=v[:, 4:7], rgb=v[:, 7:10])
+    for k in ref:
+        scale = ref[k].abs().max().item()
+        err = (got[k] - ref[k]).abs()
+        # a Gaussian's gradient sums many pixels: compare against the per-tensor scale; pixels with
+        # ambiguous threshold decisions (1 - frac_clear of them) perturb a few entries
+        bad = (err > 1e-3 * scale + 1e-4 * ref[k].abs()).double().mean().item()
+        assert bad < 0.02 + 5 * (1 - frac_clear), (k, bad, frac_clear)
+        assert np.median(relerr(got[k].numpy(), ref[k].numpy(), floor=1e-3 * scale)) < 1e-5, k
+
+
+@pytest.mark.parametrize("N,W,H,deg,seed", [(1500, 128, 80, 3, 31), (400, 64, 48, 2, 32), (400, 64, 48, 0, 33)])
+def test_project_bwd(dev, N, W, H, deg, seed):
+    from touch_gs_amd import ops
+    P, cam = scene(N, W, H, deg, seed)
+    D, sp = _project(dev, P, cam, deg)
+    g = torch.Generator().manual_seed(seed)
+    v_splats = torch.zeros(N, 12, dtype=torch.float64)
+    v_splats[:, :10] = torch.randn(N, 10, generator=g, dtype=torch.float64)
+    vm, vls, vq, vol, vsh, vxy = ops.project_bwd(amd_cam(cam), D["means"], D["log_scales"], D["quats"],
+                                                 D["opac_logit"], D["sh"], deg, sp,
+                                                 v_splats=v_splats.float().to(dev), want_v_xy=True)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    pr = O.project(Pg["means"], Pg["log_scales"], Pg["quats"], Pg["opac_logit"], Pg["sh"], cam, deg)
+    f = splat_fields(sp)
+    vis = (f["radius"] > 0) & pr["valid"]
+    vz = torch.where(vis[:, None], v_splats[:, :10], torch.zeros_like(v_splats[:, :10]))
+    # geometry terms only flow for visible Gaussians; colour/opacity terms for all
+    L = (pr["xy"] * vz[:, 0:2]).sum() + (pr["depth"] * vz[:, 2]).sum() + (pr["opac"] * v_splats[:, 3]).sum() \
+        + (pr["conic"] * vz[:, 4:7]).sum() + (pr["rgb"] * v_splats[:, 7:10]).sum()
+    L.backward()
+    same = (f["radius"] > 0) == pr["valid"]
+    pairs = [("means", vm), ("log_scales", vls), ("quats", vq), ("opac_logit", vol), ("sh", vsh)]
+    for name, got in pairs:
+        ref = Pg[name].grad[same]
+        got = got.cpu().double()[same]
+        scale = ref.abs().max().item()
+        e = relerr(got.numpy(), ref.numpy(), floor=1e-4 * scale)
+        assert np.quantile(e, 0.999) < 2e-3, (name, np.quantile(e, 0.999))
+        assert np.median(e) < 1e-5, (name, np.median(e))
+    assert torch.allclose(vxy.cpu().double(), v_splats[:, 0:2], atol=1e-6)
+
+
+def test_end_to_end_render_and_grads(dev):
+    """Whole pipeline against the fp64 oracle; statistical because fp32 flips a few decisions."""
+    from touch_gs_amd import ops
+    N, W, H, deg = 4000, 192, 112, 3
+    P, cam = scene(N, W, H, deg, 41)
+    D = to_dev(P, dev)
+    for t in D.values():
+        t.requires_grad_(True)
+    rgb, depth, alpha, radii = ops.render(D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"],
+                                          amd_cam(cam), deg)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    out, pr, gid, ts = O.render(Pg["means"], Pg["log_scales"], Pg["quats"], Pg["opac_logit"], Pg["sh"], cam, deg,
+                                want_margin=True)
+    er = relerr(rgb.detach().cpu().numpy(), out["rgb"].detach().numpy(), floor=1e-2)
+    ed = relerr(depth.detach().cpu().numpy(), out["depth_acc"].detach().numpy(), floor=1e-2)
+    assert np.quantile(er, 0.99) < TOL and np.quantile(ed, 0.99) < TOL, (np.quantile(er, 0.99), np.quantile(ed, 0.99))
+    g = torch.Generator().manual_seed(0)
+    gt = torch.rand(H, W, 3, generator=g, dtype=torch.float64)
+    dgt = torch.rand(H, W, generator=g, dtype=torch.float64) * 5
+    dgt[torch.rand(H, W, generator=g) < 0.3] = 0
+    unc = torch.rand(H, W, generator=g, dtype=torch.float64) * 5 + 1e-3
+    Lr = O.train_loss(out, gt, dgt, unc, ssim_lambda=0.0, depth_loss_mult=0.2, uncertainty_weight=1.0)
+    Lr.backward()
+    o = dict(rgb=rgb.double(), depth_acc=depth.double(), alpha=alpha.double())
+    Lg = O.train_loss(o, gt.to(dev), dgt.to(dev), unc.to(dev), ssim_lambda=0.0, depth_loss_mult=0.2,
+                      uncertainty_weight=1.0)
+    Lg.backward()
+    assert abs(Lg.item() - Lr.item()) < 1e-3 * abs(Lr.item())
+    for k in D:
+        ref, got = Pg[k].grad.numpy(), D[k].grad.cpu().double().numpy()
+        scale = np.abs(ref).max()
+        e = relerr(got, ref, floor=1e-3 * scale)
+        assert np.quantile(e, 0.98) < 5e-3, (k, np.quantile(e, 0.98))
+        cos = (ref * got).sum() / np.sqrt((ref * ref).sum() * (got * got).sum())
+        assert cos > 0.9999, (k, cos)
+
+
+def test_fused_loss_matches_autograd_path(dev):
+    """K7's in-kernel L1 + depth/uncertainty loss == the same loss applied through autograd."""
+    from touch_gs_amd import ops
+    N, W, H, deg = 3000, 160, 96, 3
+    P, cam = scene(N, W, H, deg, 51)
+    acam = amd_cam(cam)
+    D = to_dev(P, dev)
+    g = torch.Generator().manual_seed(1)
+    gt = torch.rand(H, W, 3, generator=g).to(dev)
+    dgt = (torch.rand(H, W, generator=g) * 5)
+    dgt[torch.rand(H, W, generator=g) < 0.3] = 0
+    dgt = dgt.to(dev)
+    unc = (torch.rand(H, W, generator=g) * 5 + 1e-3).to(dev)
+    for loss_type, uw in (("DEPTH_UNCERTAINTY_WEIGHTED_LOSS", 0.01), ("SIMPLE_LOSS", 1.0)):
+        Dg = {k: v.clone().requires_grad_(True) for k, v in D.items()}
+        rgb, depth, alpha, _ = ops.render(Dg["means"], Dg["log_scales"], Dg["quats"], Dg["opac_logit"], Dg["sh"], acam, deg)
+        L = O.train_loss(dict(rgb=rgb, depth_acc=depth, alpha=alpha), gt, dgt, unc, ssim_lambda=0.0,
+                         depth_loss_mult=0.3, depth_loss_type=loss_type, uncertainty_weight=uw)
+        L.backward()
+        sp = ops.project_fwd(acam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], deg)
+        gb, ts, sg, st = ops.bin_sort(acam, sp)
+        r2, d2, fT, fidx = ops.rasterize_fwd(acam, sp, sg, ts)
+        cnt = int((dgt > 0).sum())
+        spec = dict(gt_rgb=gt, gt_depth=dgt, uncertainty=unc if loss_type != "SIMPLE_LOSS" else None,
+                    l1_weight=1.0 / (3 * H * W), depth_weight=0.3 / cnt, uncertainty_weight=uw, eps=1e-6)
+        partials, tl = ops.rasterize_bwd(acam, sp, gb, sg, ts, r2, d2, fT, fidx, loss=spec, want_tile_loss=True)
+        vm, vls, vq, vol, vsh, _ = ops.project_bwd(acam, D["means"], D["log_scales"], D["quats"], D["opac_logit"],
+                                                   D["sh"], deg, sp, gb, partials)
+        assert abs(tl.sum().item() - L.item()) < 1e-4 * abs(L.item())
+        for name, got in (("means", vm), ("log_scales", vls), ("quats", vq), ("opac_logit", vol), ("sh", vsh)):
+            ref = Dg[name].grad
+            scale = ref.abs().max().item()
+            assert (got - ref).abs().max().item() < 2e-4 * scale, (loss_type, name)
+
+
+def test_deterministic_bitwise(dev):
+    from touch_gs_amd import ops
+    P, cam = scene(5000, 200, 120, 3, 61)
+    acam = amd_cam(cam)
+    D = to_dev(P, dev)
+    res = []
+    for _ in range(2):
+        Dg = {k: v.clone().requires_grad_(True) for k, v in D.items()}
+        rgb, depth, alpha, _ = ops.render(Dg["means"], Dg["log_scales"], Dg["quats"], Dg["opac_logit"], Dg["sh"], acam, 3)
+        (rgb.sum() + depth.sum() + 0.5 * alpha.sum()).backward()
+        res.append([rgb.detach().clone(), depth.detach().clone()] + [Dg[k].grad.clone() for k in Dg])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+def test_edge_cases(dev):
+    from touch_gs_amd import ops
+    # (a) everything behind the camera -> background only, zero grads
+    P, cam = scene(300, 70, 50, 1, 71, bg=(0.2, 0.4, 0.6))
+    P["means"][:, 2] = -P["means"][:, 2] - 10
+    D = {k: v.requires_grad_(True) for k, v in to_dev(P, dev).items()}
+    rgb, depth, alpha, radii = ops.render(D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], amd_cam(cam), 1)
+    assert int((radii > 0).sum()) == 0
+    assert torch.allclose(rgb, torch.tensor([0.2, 0.4, 0.6], device=dev).expand(50, 70, 3))
+    assert float(alpha.abs().max()) == 0 and float(depth.abs().max()) == 0
+    (rgb.sum() + depth.sum()).backward()
+    assert float(D["means"].grad.abs().max()) == 0
+    # (b) one huge Gaussian covering every tile + many small ones in one tile (long list -> 2nd sort class)
+    N = 6000
+    P, cam = scene(N, 64, 48, 0, 72)
+    P["means"][:] = torch.tensor([0.0, 0.0, 4.0], dtype=torch.float64) + 0.02 * torch.randn(N, 3, dtype=torch.float64)
+    P["log_scales"][:] = -5.0
+    P["log_scales"][0] = 1.0
+    D = to_dev(P, dev)
+    acam = amd_cam(cam)
+    sp = ops.project_fwd(acam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], 0)
+    gb, ts, sg, st = ops.bin_sort(acam, sp)
+    f = splat_fields(sp)
+    gid, tstart = O.bin_and_sort(rect_from(f["xy"], f["radius"], cam), f["radius"] > 0, f["depth"], cam)
+    n = st.tolist()[0]
+    assert (np.diff(tstart).max() > 2048), "test must exercise the large-list sort class"
+    assert n == len(gid) and np.array_equal(sg[:n].cpu().numpy().astype(np.int64), gid)
+    rgb, depth, fT, fidx = ops.rasterize_fwd(acam, sp, sg, ts)
+    out = O.blend(f["xy"], f["conic"], f["opac"], f["rgb"], f["depth"], gid, tstart, cam, want_margin=True)
+    clear = (out["margin"] > 1e-3).numpy()
+    assert relerr(rgb.cpu().numpy(), out["rgb"].numpy(), floor=1e-2)[clear].max() < TOL
+
+
+def test_sort_fallback_global(dev):
+    """> 16384 Gaussians in one tile exercises the global-memory sort fallback."""
+    from touch_gs_amd import ops
+    N = 17000
+    P, cam = scene(N, 32, 32, 0, 81)
+    P["means"][:] = torch.tensor([0.0, 0.0, 4.0], dtype=torch.float64) + 0.01 * torch.randn(N, 3, dtype=torch.float64)
+    P["log_scales"][:] = -6.0
+    D = to_dev(P, dev)
+    acam = amd_cam(cam)
+    sp = ops.project_fwd(acam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], 0)
+    gb, ts, sg, st = ops.bin_sort(acam, sp)
+    f = splat_fields(sp)
+    gid, tstart = O.bin_and_sort(rect_from(f["xy"], f["radius"], cam), f["radius"] > 0, f["depth"], cam)
+    n = st.tolist()[0]
+    assert np.diff(tstart).max() > 16384
+    assert n == len(gid) and np.array_equal(sg[:n].cpu().numpy().astype(np.int64), gid)
+
+
+def test_capacity_overflow_regrows(dev):
+    from touch_gs_amd import ops
+    P, cam = scene(4000, 160, 96, 0, 91)
+    D, sp = _project(dev, P, cam, 0)
+    b = ops.IntersectBudget(capacity=100)
+    gb, ts, sg, st = ops.bin_sort(amd_cam(cam), sp, b)
+    n, ovf = st.tolist()
+    assert ovf == 0 and n > 100 and b.capacity >= n
+    b2 = ops.IntersectBudget(capacity=100, sync=False)
+    ops.bin_sort(amd_cam(cam), sp, b2)
+    with pytest.raises(RuntimeError):
+        b2.check()
+
+
+def test_adam_matches_torch(dev):
+    import ctypes as C
+    from touch_gs_amd import _lib
+    from touch_gs_amd.optim import FusedAdam, GaussianParams
+    N, K = 1000, 16
+    torch.manual_seed(0)
+    gp = GaussianParams.allocate(N, K, dev)
+    gp.flat.copy_(torch.randn_like(gp.flat))
+    lrs = dict(means=1.6e-4, log_scales=5e-3, quats=1e-3, opac_logit=5e-2, sh_dc=2.5e-3, sh_rest=1.25e-4)
+    ref_p = [gp.means.clone().requires_grad_(True), gp.log_scales.clone().requires_grad_(True),
+             gp.quats.clone().requires_grad_(True), gp.opac_logit.clone().requires_grad_(True),
+             gp.sh[:, :1].clone().requires_grad_(True), gp.sh[:, 1:].clone().requires_grad_(True)]
+    opt_ref = torch.optim.Adam([dict(params=[p], lr=lr) for p, lr in zip(ref_p, lrs.values())], eps=1e-15)
+    opt = FusedAdam(gp, lrs, eps=1e-15)
+    for step in range(3):
+        g = torch.randn_like(gp.flat)
+        gp.grad.copy_(g)
+        gv = GaussianParams.views_of(g, N, K)
+        for p, gg in zip(ref_p, [gv["means"], gv["log_scales"], gv["quats"], gv["opac_logit"], gv["sh"][:, :1], gv["sh"][:, 1:]]):
+            p.grad = gg.clone()
+        opt_ref.step()
+        opt.step()
+    got = [gp.means, gp.log_scales, gp.quats, gp.opac_logit, gp.sh[:, :1], gp.sh[:, 1:]]
+    for a, b in zip(got, ref_p):
+        assert torch.allclose(a, b.detach(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("W,H", [(64, 48), (100, 70), (33, 17)])
+def test_ssim_fwd_bwd(dev, W, H):
+    from touch_gs_amd import ops
+    g = torch.Generator().manual_seed(W)
+    a = torch.rand(H, W, 3, generator=g, dtype=torch.float64)
+    b = (a + 0.2 * torch.randn(H, W, 3, generator=g, dtype=torch.float64)).clamp(0, 1)
+    a.requires_grad_(True)
+    s = O.ssim(a, b)
+    (0.2 * (1 - s)).backward()
+    tot, v = ops.ssim_fwd_bwd(a.detach().float().to(dev), b.float().to(dev), weight=-0.2 / (3 * H * W))
+    assert abs(tot.item() / (3 * H * W) - s.item()) < 1e-5
+    scale = a.grad.abs().max().item()
+    assert (v.cpu().double() - a.grad).abs().max().item() < 1e-4 * scale

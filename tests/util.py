@@ -1,0 +1,49 @@
+"""Shared helpers for the parity tests (oracle side lives in oracle/, product in touch_gs_amd/)."""
+import numpy as np
+import torch
+
+from oracle import torch_oracle as O
+
+
+def scene(N, W, H, deg, seed, view=1, nviews=8, bg=(0.1, 0.2, 0.3)):
+    """Seeded synthetic scene -> (fp64 param dict, oracle Camera)."""
+    P, c = O.synthetic_scene(N, W, H, deg, seed)
+    cam = O.Camera(viewmat=O.orbit_viewmat(view, nviews), **c, bg=bg)
+    return P, cam
+
+
+def to_dev(P, dev):
+    return {k: v.detach().to(torch.float32).to(dev).contiguous() for k, v in P.items()}
+
+
+def amd_cam(cam):
+    from touch_gs_amd import Camera
+    return Camera(cam.viewmat.numpy(), cam.fx, cam.fy, cam.cx, cam.cy, cam.W, cam.H, cam.near,
+                  cam.pix_center, cam.bg)
+
+
+def relerr(a, b, floor=1e-6):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b) / (np.abs(b) + floor)
+
+
+def splat_fields(splats):
+    """HIP splat records [N,12] (cpu float32 tensor) -> dict of fp64 tensors + radius int."""
+    s = splats.detach().cpu()
+    return dict(xy=s[:, 0:2].double(), depth=s[:, 2].double(), opac=s[:, 3].double(),
+                conic=s[:, 4:7].double(), rgb=s[:, 7:10].double(),
+                radius=s[:, 10].contiguous().view(torch.int32).long())
+
+
+def rect_from(xy, radius, cam):
+    """App. B.4 on given (fp32-valued) xy / radius, evaluated exactly like the kernel (fp32)."""
+    TW, TH = cam.tiles
+    u = xy[:, 0].float()
+    v = xy[:, 1].float()
+    r = radius.float()
+    x0 = torch.clamp(((u - r) / 16).to(torch.int64), 0, TW)
+    x1 = torch.clamp(((u + r) / 16).to(torch.int64) + 1, 0, TW)
+    y0 = torch.clamp(((v - r) / 16).to(torch.int64), 0, TH)
+    y1 = torch.clamp(((v + r) / 16).to(torch.int64) + 1, 0, TH)
+    return torch.stack([x0, y0, x1, y1], 1)

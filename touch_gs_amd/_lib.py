@@ -1,0 +1,90 @@
+"""ctypes binding of libtgs_hip.so (C ABI: include/tgs.h).  Fails loudly if the library is absent."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtgs_hip.so")
+
+SPLAT_FLOATS = 12
+PARTIAL_FLOATS = 12
+GROUP = 256
+BLOCK = 16
+
+
+class TgsCamera(C.Structure):
+    _fields_ = [("viewmat", C.c_float * 16), ("fx", C.c_float), ("fy", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float), ("W", C.c_int32), ("H", C.c_int32),
+                ("near_plane", C.c_float), ("pix_center", C.c_float), ("bg", C.c_float * 3),
+                ("glob_scale", C.c_float)]
+
+
+class TgsLossSpec(C.Structure):
+    _fields_ = [("gt_rgb", C.c_void_p), ("gt_depth", C.c_void_p), ("uncertainty", C.c_void_p),
+                ("l1_weight", C.c_float), ("depth_weight", C.c_float),
+                ("uncertainty_weight", C.c_float), ("eps", C.c_float)]
+
+
+class TgsAdamSpec(C.Structure):
+    _fields_ = [("lr_means", C.c_float), ("lr_scales", C.c_float), ("lr_quats", C.c_float),
+                ("lr_opac", C.c_float), ("lr_sh_dc", C.c_float), ("lr_sh_rest", C.c_float),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("bias_corr1", C.c_float), ("bias_corr2", C.c_float)]
+
+
+_P = C.c_void_p
+_I = C.c_int
+# name -> (restype, argtypes); must list every symbol declared in include/tgs.h
+SIGNATURES = {
+    "tgs_version": (C.c_int, []),
+    "tgs_last_error": (C.c_char_p, []),
+    "tgs_num_groups": (C.c_int, [_I]),
+    "tgs_num_tiles": (C.c_int, [_I, _I]),
+    "tgs_sort_scratch_bytes": (C.c_size_t, [C.c_int64]),
+    "tgs_project_fwd": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "tgs_bin_sort": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P]),
+    "tgs_rasterize_fwd": (C.c_int, [C.POINTER(TgsCamera), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "tgs_rasterize_bwd": (C.c_int, [C.POINTER(TgsCamera)] + [_P] * 11 + [C.POINTER(TgsLossSpec), _P, _P, _P]),
+    "tgs_reduce_partials": (C.c_int, [_I, _P, _P, C.POINTER(TgsCamera), _P, _P, _P]),
+    "tgs_project_bwd": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I] + [_P] * 11),
+    "tgs_adam_step": (C.c_int, [_I, _I, _P, _P, _P, _P, C.POINTER(TgsAdamSpec), C.c_float, _P]),
+    "tgs_ssim_fwd_bwd": (C.c_int, [_I, _I, _P, _P, C.c_float, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  No fallback: a missing library is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or touch_gs_amd/csrc/build.sh (hipcc --offload-arch=gfx950). touch_gs_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().tgs_last_error().decode(errors="replace")
+        raise RuntimeError(f"libtgs_hip {what} failed ({rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA/HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("touch_gs_amd ops need device (HIP) tensors; there is no CPU path")
+    if not t.is_contiguous():
+        raise RuntimeError("touch_gs_amd ops need contiguous tensors")
+    return t.data_ptr()

@@ -1,0 +1,299 @@
+// binning.hip -- K2-K5: tile intersection counting, tile-offset scan, bin fill and per-tile
+// depth sort.  gfx950, wave64.
+//
+// Spec: SURVEY.md App. B.4 (tile rect) and B.6 (order = tile, then depth bits, ties by Gaussian id).
+// The CUDA implementations behind the reference's `rasterize_gaussians` (gsplat
+// map_gaussian_to_intersects + cub::DeviceRadixSort + get_tile_bin_edges, App. A.2) globally
+// radix-sort 64-bit (tile|depth) keys: ~6 passes x 24 B per intersection.  Here the tile part of
+// the key is resolved by a counting sort (one integer atomic per intersection, which also yields
+// the tile bin edges for free) and the depth part by a per-tile bitonic sort held entirely in the
+// 160 KB LDS of one CU, so an intersection costs 4 B (rank) + 8 B (pair) written once, read once,
+// + 4 B sorted id.  Integer atomics only: the output is bit-reproducible.
+//
+// Work decomposition: a "group" is 256 consecutive Gaussians.  Its intersections occupy one
+// contiguous range [group_base, group_base+total) of the pair index space, so every pass is
+// balanced (one thread per intersection, found by binary search in the group's LDS-resident scan)
+// no matter how many tiles a single Gaussian covers.
+#include "tgs_common.h"
+
+namespace {
+
+struct GroupScan {
+  int off[TGS_GROUP + 1];  // exclusive scan of tiles_hit inside the group
+  int x0[TGS_GROUP], y0[TGS_GROUP], w[TGS_GROUP];
+  unsigned depth_bits[TGS_GROUP];
+  int wave_tot[TGS_GROUP / TGS_WAVE];
+  int base;
+};
+
+// Loads the group's rects, builds the in-group exclusive scan.  Returns the group total.
+__device__ __forceinline__ int group_load_scan(const CamK& cam, int N,
+                                               const float* __restrict__ splats, GroupScan& S,
+                                               int& my_off) {
+  const int tid = threadIdx.x;
+  const int g = blockIdx.x * TGS_GROUP + tid;
+  int hits = 0, x0 = 0, y0 = 0, w = 0;
+  unsigned dbits = 0;
+  if (g < N) {
+    const float* rec = splats + (size_t)g * TGS_SPLAT_FLOATS;
+    const float4 r0 = ld4(rec);
+    const int radius = __float_as_int(rec[10]);
+    if (radius > 0) {
+      int x1, y1;
+      tile_rect(r0.x, r0.y, radius, cam.TW, cam.TH, x0, y0, x1, y1);
+      w = x1 - x0;
+      hits = w * (y1 - y0);
+      dbits = __float_as_uint(r0.z);
+    }
+  }
+  // wave-level inclusive scan, then across the 4 waves
+  int incl = hits;
+#pragma unroll
+  for (int o = 1; o < TGS_WAVE; o <<= 1) {
+    const int t = __shfl_up(incl, o);
+    if ((tid & (TGS_WAVE - 1)) >= o) incl += t;
+  }
+  if ((tid & (TGS_WAVE - 1)) == TGS_WAVE - 1) S.wave_tot[tid / TGS_WAVE] = incl;
+  __syncthreads();
+  int wbase = 0, total = 0;
+#pragma unroll
+  for (int i = 0; i < TGS_GROUP / TGS_WAVE; i++) {
+    if (i < tid / TGS_WAVE) wbase += S.wave_tot[i];
+    total += S.wave_tot[i];
+  }
+  my_off = wbase + incl - hits;
+  S.off[tid] = my_off;
+  S.x0[tid] = x0; S.y0[tid] = y0; S.w[tid] = max(w, 1);
+  S.depth_bits[tid] = dbits;
+  if (tid == 0) S.off[TGS_GROUP] = total;
+  return total;
+}
+
+// pair i of the group -> (local Gaussian j, tile id)
+__device__ __forceinline__ void group_pair(const GroupScan& S, int TW, int i, int& j, int& tile) {
+  int lo = 0, hi = TGS_GROUP;
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    const int mid = (lo + hi) >> 1;
+    if (S.off[mid] <= i) lo = mid; else hi = mid;
+  }
+  j = lo;
+  const int k = i - S.off[lo];
+  const int w = S.w[lo];
+  const int ky = k / w;
+  tile = (S.y0[lo] + ky) * TW + S.x0[lo] + (k - ky * w);
+}
+
+// K3a: count intersections per tile; allocate the group's pair range; remember every pair's
+// arrival rank inside its tile.
+__global__ __launch_bounds__(TGS_GROUP) void k_tile_count(
+    CamK cam, int N, float* __restrict__ splats, int32_t* __restrict__ group_base,
+    int32_t* __restrict__ tile_count, int32_t* __restrict__ rank, int32_t* __restrict__ status,
+    long long capacity) {
+  __shared__ GroupScan S;
+  int my_off;
+  const int total = group_load_scan(cam, N, splats, S, my_off);
+  const int tid = threadIdx.x;
+  const int g = blockIdx.x * TGS_GROUP + tid;
+  if (g < N) splats[(size_t)g * TGS_SPLAT_FLOATS + 11] = __int_as_float(my_off);
+  if (tid == 0) {
+    const int base = total ? atomicAdd(&status[0], total) : 0;
+    S.base = base;
+    group_base[blockIdx.x] = base;
+    if ((long long)base + total > capacity) status[1] = 1;
+  }
+  __syncthreads();
+  const long long base = S.base;
+  const bool fits = base + total <= capacity;
+  for (int i = tid; i < total; i += TGS_GROUP) {
+    int j, tile;
+    group_pair(S, cam.TW, i, j, tile);
+    const int r = atomicAdd(&tile_count[tile], 1);
+    if (fits) rank[base + i] = r;
+  }
+}
+
+// K4: exclusive scan of tile counts -> tile_start[T+1] (single workgroup; T is a few 10^4).
+// On capacity overflow every list is made empty so that downstream kernels touch nothing.
+__global__ __launch_bounds__(1024) void k_scan_tiles(int T, const int32_t* __restrict__ tile_count,
+                                                     int32_t* __restrict__ tile_start,
+                                                     const int32_t* __restrict__ status) {
+  __shared__ int wave_tot[16];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x;
+  const bool overflow = status[1] != 0;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < T; base += 1024) {
+    const int i = base + tid;
+    const int v = (i < T && !overflow) ? tile_count[i] : 0;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < TGS_WAVE; o <<= 1) {
+      const int t = __shfl_up(incl, o);
+      if ((tid & 63) >= o) incl += t;
+    }
+    if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+    __syncthreads();
+    int wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+      if (w < (tid >> 6)) wbase += wave_tot[w];
+      tot += wave_tot[w];
+    }
+    const int carry = carry_s;
+    if (i < T) tile_start[i] = carry + wbase + incl - v;
+    __syncthreads();
+    if (tid == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+  if (tid == 0) tile_start[T] = carry_s;
+}
+
+// K3b: scatter (gid, depth bits) into the tile bins.  slot = tile_start + arrival rank.
+__global__ __launch_bounds__(TGS_GROUP) void k_fill_bins(
+    CamK cam, int N, const float* __restrict__ splats, const int32_t* __restrict__ group_base,
+    const int32_t* __restrict__ tile_start, const int32_t* __restrict__ rank,
+    uint2* __restrict__ pairs, const int32_t* __restrict__ status) {
+  if (status[1]) return;
+  __shared__ GroupScan S;
+  int my_off;
+  const int total = group_load_scan(cam, N, splats, S, my_off);
+  __syncthreads();
+  const long long base = group_base[blockIdx.x];
+  const int g0 = blockIdx.x * TGS_GROUP;
+  for (int i = threadIdx.x; i < total; i += TGS_GROUP) {
+    int j, tile;
+    group_pair(S, cam.TW, i, j, tile);
+    const int slot = tile_start[tile] + rank[base + i];
+    pairs[slot] = make_uint2((unsigned)(g0 + j), S.depth_bits[j]);  // u64 = depth<<32 | gid
+  }
+}
+
+__device__ __forceinline__ int next_pow2(int n) {
+  int p = 2;
+  while (p < n) p <<= 1;
+  return p;
+}
+
+// K5: per-tile bitonic sort of (depth bits, gid) in LDS; writes the sorted Gaussian ids.
+// One workgroup per tile; tiles whose list length is outside (LO, CAP] belong to another class.
+template <int CAP, int THREADS, int LO>
+__global__ __launch_bounds__(THREADS) void k_sort_tiles_lds(
+    const int32_t* __restrict__ tile_start, const unsigned long long* __restrict__ pairs,
+    int32_t* __restrict__ sorted_gid) {
+  __shared__ unsigned long long keys[CAP];
+  const int tile = blockIdx.x;
+  const int s = tile_start[tile];
+  const int n = tile_start[tile + 1] - s;
+  if (n <= LO || n > CAP) return;
+  const int tid = threadIdx.x;
+  if (n == 1) {
+    if (tid == 0) sorted_gid[s] = (int)(pairs[s] & 0xffffffffull);
+    return;
+  }
+  const int np2 = next_pow2(n);
+  for (int i = tid; i < np2; i += THREADS) keys[i] = (i < n) ? pairs[s + i] : ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= np2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < (np2 >> 1); i += THREADS) {
+        const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+        const int hi = lo | j;
+        const bool up = (lo & k) == 0;
+        const unsigned long long a = keys[lo], b = keys[hi];
+        if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < n; i += THREADS) sorted_gid[s + i] = (int)(keys[i] & 0xffffffffull);
+}
+
+// Fallback for lists longer than the largest LDS class: the same network in global memory, on a
+// power-of-two padded copy at fb[2*s ...) (next_pow2(n) < 2n, so per-tile regions never overlap).
+template <int LO>
+__global__ __launch_bounds__(1024) void k_sort_tiles_global(
+    const int32_t* __restrict__ tile_start, const unsigned long long* __restrict__ pairs,
+    unsigned long long* __restrict__ fb, int32_t* __restrict__ sorted_gid) {
+  const int tile = blockIdx.x;
+  const int s = tile_start[tile];
+  const int n = tile_start[tile + 1] - s;
+  if (n <= LO) return;
+  const int tid = threadIdx.x;
+  const int np2 = next_pow2(n);
+  unsigned long long* keys = fb + 2 * (size_t)s;
+  for (int i = tid; i < np2; i += 1024) keys[i] = (i < n) ? pairs[s + i] : ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= np2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < (np2 >> 1); i += 1024) {
+        const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+        const int hi = lo | j;
+        const bool up = (lo & k) == 0;
+        const unsigned long long a = keys[lo], b = keys[hi];
+        if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < n; i += 1024) sorted_gid[s + i] = (int)(keys[i] & 0xffffffffull);
+}
+
+constexpr int SORT_CAP_A = 2048;   // 16 KB LDS, 256 threads
+constexpr int SORT_CAP_B = 16384;  // 128 KB LDS, 1024 threads
+
+}  // namespace
+
+extern "C" int tgs_num_groups(int N) { return (N + TGS_GROUP - 1) / TGS_GROUP; }
+extern "C" int tgs_num_tiles(int W, int H) {
+  return ((W + TGS_BLOCK - 1) / TGS_BLOCK) * ((H + TGS_BLOCK - 1) / TGS_BLOCK);
+}
+// scratch layout: pairs u64[cap] | fallback u64[2*cap] | rank i32[cap]
+extern "C" size_t tgs_sort_scratch_bytes(int64_t capacity) {
+  if (capacity < 0) capacity = 0;
+  return (size_t)capacity * (8 + 16 + 4) + 64;
+}
+
+extern "C" int tgs_bin_sort(const TgsCamera* cam, int N, float* splats, int32_t* group_base,
+                            int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
+                            int64_t capacity, void* scratch, int32_t* status, void* stream) {
+  TGS_CHECK_ARG(camera_ok(cam), "bad camera");
+  TGS_CHECK_ARG(N >= 0 && capacity >= 0, "negative size");
+  TGS_CHECK_ARG(capacity < (1ll << 31), "capacity must be < 2^31");
+  TGS_CHECK_ARG(group_base && tile_start && tile_cursor && sorted_gid && scratch && status,
+                "null pointer");
+  TGS_CHECK_ARG(N == 0 || splats, "null splats");
+  const CamK k = make_camk(cam);
+  const int T = k.TW * k.TH;
+  const int G = tgs_num_groups(N);
+  hipStream_t s = (hipStream_t)stream;
+  unsigned long long* pairs = (unsigned long long*)scratch;
+  unsigned long long* fb = pairs + capacity;
+  int32_t* rank = (int32_t*)(fb + 2 * capacity);
+  TGS_HIP(hipMemsetAsync(tile_cursor, 0, sizeof(int32_t) * (size_t)T, s));
+  TGS_HIP(hipMemsetAsync(status, 0, sizeof(int32_t) * 2, s));
+  if (G > 0) {
+    hipLaunchKernelGGL(k_tile_count, dim3(G), dim3(TGS_GROUP), 0, s, k, N, splats, group_base,
+                       tile_cursor, rank, status, (long long)capacity);
+    TGS_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, T, tile_cursor, tile_start, status);
+  TGS_CHECK_LAUNCH();
+  if (G > 0) {
+    hipLaunchKernelGGL(k_fill_bins, dim3(G), dim3(TGS_GROUP), 0, s, k, N, splats, group_base,
+                       tile_start, rank, (uint2*)pairs, status);
+    TGS_CHECK_LAUNCH();
+    hipLaunchKernelGGL((k_sort_tiles_lds<SORT_CAP_A, 256, 0>), dim3(T), dim3(256), 0, s,
+                       tile_start, pairs, sorted_gid);
+    TGS_CHECK_LAUNCH();
+    hipLaunchKernelGGL((k_sort_tiles_lds<SORT_CAP_B, 1024, SORT_CAP_A>), dim3(T), dim3(1024), 0, s,
+                       tile_start, pairs, sorted_gid);
+    TGS_CHECK_LAUNCH();
+    hipLaunchKernelGGL((k_sort_tiles_global<SORT_CAP_B>), dim3(T), dim3(1024), 0, s, tile_start,
+                       pairs, fb, sorted_gid);
+    TGS_CHECK_LAUNCH();
+  }
+  return TGS_OK;
+}

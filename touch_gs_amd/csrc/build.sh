@@ -1,0 +1,22 @@
+#!/bin/bash
+# Builds libtgs_hip.so for gfx950 in-tree (touch_gs_amd/lib/).  hipcc cross-compiles without a GPU.
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="$HERE/../lib"
+mkdir -p "$OUT"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wall -Wno-unused-function"
+SRCS="api project binning raster optim imgloss"
+pids=()
+for s in $SRCS; do
+  [ -f "$HERE/$s.hip" ] || continue
+  if [ ! -f "$OUT/$s.o" ] || [ "$HERE/$s.hip" -nt "$OUT/$s.o" ] || [ "$HERE/tgs_common.h" -nt "$OUT/$s.o" ] || [ "$HERE/../../include/tgs.h" -nt "$OUT/$s.o" ]; then
+    $HIPCC $FLAGS -c "$HERE/$s.hip" -o "$OUT/$s.o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+OBJS=""
+for s in $SRCS; do [ -f "$OUT/$s.o" ] && OBJS="$OBJS $OUT/$s.o"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC $OBJS -o "$OUT/libtgs_hip.so"
+echo "built $OUT/libtgs_hip.so"

@@ -1,0 +1,485 @@
+// project.hip -- K1 projection + EWA covariance + SH colour (forward), K8 its backward,
+// K8a segmented reduction of per-(tile,Gaussian) partial gradients.   gfx950, wave64.
+//
+// Algorithm: SURVEY.md Appendix B.1-B.5 (forward) and B.8 (backward).  The reference tree has no
+// source for this path (scripts/train_bunny_real.sh:52 shells out to an absent submodule); the
+// op surface mirrored is gsplat-0.1 `project_gaussians` / `spherical_harmonics` (App. A.2).
+//
+// Roofline: pure streaming, HBM bound.  Forward reads 44+12K B and writes 48 B per Gaussian;
+// backward reads 44+12K+48 (+48*tiles_hit of partials) and writes 44+12K (+8) B per Gaussian.
+#include "tgs_common.h"
+
+namespace {
+
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+constexpr float SH_C2_0 = 1.0925484305920792f, SH_C2_1 = -1.0925484305920792f,
+                SH_C2_2 = 0.31539156525252005f, SH_C2_3 = -1.0925484305920792f,
+                SH_C2_4 = 0.5462742152960396f;
+constexpr float SH_C3_0 = -0.5900435899266435f, SH_C3_1 = 2.890611442640554f,
+                SH_C3_2 = -0.4570457994644658f, SH_C3_3 = 0.3731763325901154f,
+                SH_C3_4 = -0.4570457994644658f, SH_C3_5 = 1.445305721320277f,
+                SH_C3_6 = -0.5900435899266435f;
+constexpr float BLUR = 0.3f;
+
+template <int DEG>
+__device__ __forceinline__ void sh_basis(float x, float y, float z, float* Y) {
+  Y[0] = SH_C0;
+  if constexpr (DEG >= 1) { Y[1] = -SH_C1 * y; Y[2] = SH_C1 * z; Y[3] = -SH_C1 * x; }
+  if constexpr (DEG >= 2) {
+    const float xx = x * x, yy = y * y, zz = z * z;
+    Y[4] = SH_C2_0 * x * y; Y[5] = SH_C2_1 * y * z; Y[6] = SH_C2_2 * (2.f * zz - xx - yy);
+    Y[7] = SH_C2_3 * x * z; Y[8] = SH_C2_4 * (xx - yy);
+    if constexpr (DEG >= 3) {
+      Y[9] = SH_C3_0 * y * (3.f * xx - yy); Y[10] = SH_C3_1 * x * y * z;
+      Y[11] = SH_C3_2 * y * (4.f * zz - xx - yy);
+      Y[12] = SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy);
+      Y[13] = SH_C3_4 * x * (4.f * zz - xx - yy);
+      Y[14] = SH_C3_5 * z * (xx - yy); Y[15] = SH_C3_6 * x * (xx - 3.f * yy);
+    }
+  }
+}
+
+// dY_k/d(x,y,z), k >= 1 (the DC term has zero derivative)
+template <int DEG>
+__device__ __forceinline__ void sh_basis_grad(float x, float y, float z, float (*dY)[3]) {
+  constexpr int K = (DEG + 1) * (DEG + 1);
+#pragma unroll
+  for (int k = 0; k < K; k++) { dY[k][0] = 0.f; dY[k][1] = 0.f; dY[k][2] = 0.f; }
+  if constexpr (DEG >= 1) { dY[1][1] = -SH_C1; dY[2][2] = SH_C1; dY[3][0] = -SH_C1; }
+  if constexpr (DEG >= 2) {
+    dY[4][0] = SH_C2_0 * y; dY[4][1] = SH_C2_0 * x;
+    dY[5][1] = SH_C2_1 * z; dY[5][2] = SH_C2_1 * y;
+    dY[6][0] = -2.f * SH_C2_2 * x; dY[6][1] = -2.f * SH_C2_2 * y; dY[6][2] = 4.f * SH_C2_2 * z;
+    dY[7][0] = SH_C2_3 * z; dY[7][2] = SH_C2_3 * x;
+    dY[8][0] = 2.f * SH_C2_4 * x; dY[8][1] = -2.f * SH_C2_4 * y;
+  }
+  if constexpr (DEG >= 3) {
+    const float xx = x * x, yy = y * y, zz = z * z;
+    dY[9][0] = 6.f * SH_C3_0 * x * y; dY[9][1] = 3.f * SH_C3_0 * (xx - yy);
+    dY[10][0] = SH_C3_1 * y * z; dY[10][1] = SH_C3_1 * x * z; dY[10][2] = SH_C3_1 * x * y;
+    dY[11][0] = -2.f * SH_C3_2 * x * y; dY[11][1] = SH_C3_2 * (4.f * zz - xx - 3.f * yy);
+    dY[11][2] = 8.f * SH_C3_2 * y * z;
+    dY[12][0] = -6.f * SH_C3_3 * x * z; dY[12][1] = -6.f * SH_C3_3 * y * z;
+    dY[12][2] = SH_C3_3 * (6.f * zz - 3.f * xx - 3.f * yy);
+    dY[13][0] = SH_C3_4 * (4.f * zz - 3.f * xx - yy); dY[13][1] = -2.f * SH_C3_4 * x * y;
+    dY[13][2] = 8.f * SH_C3_4 * x * z;
+    dY[14][0] = 2.f * SH_C3_5 * x * z; dY[14][1] = -2.f * SH_C3_5 * y * z;
+    dY[14][2] = SH_C3_5 * (xx - yy);
+    dY[15][0] = 3.f * SH_C3_6 * (xx - yy); dY[15][1] = -6.f * SH_C3_6 * x * y;
+  }
+}
+
+struct Geom {  // everything the forward and backward share for one Gaussian
+  float tx, ty, tz;
+  float Rq[9];      // rotation of the normalised quaternion
+  float qn[4];      // normalised quaternion
+  float qnorm;
+  float s[3];       // exp(log_scale) * glob_scale
+  float Sig[6];     // 3-D covariance, upper triangle: 00 01 02 11 12 22
+  float ucx, ucy;   // clamped tx/tz, ty/tz
+  bool inx, iny;
+  float Tm[6];      // J * R_world (2x3)
+  float c00, c01, c11, det;
+};
+
+__device__ __forceinline__ void geom_eval(const CamK& cam, const float* m, const float* ls,
+                                          const float* q, Geom& G) {
+  const float* R = cam.R;
+  G.tx = R[0] * m[0] + R[1] * m[1] + R[2] * m[2] + cam.t[0];
+  G.ty = R[3] * m[0] + R[4] * m[1] + R[5] * m[2] + cam.t[1];
+  G.tz = R[6] * m[0] + R[7] * m[1] + R[8] * m[2] + cam.t[2];
+  const float qq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  G.qnorm = sqrtf(qq);
+  const float inv = 1.0f / G.qnorm;
+  const float w = q[0] * inv, x = q[1] * inv, y = q[2] * inv, z = q[3] * inv;
+  G.qn[0] = w; G.qn[1] = x; G.qn[2] = y; G.qn[3] = z;
+  G.Rq[0] = 1.f - 2.f * (y * y + z * z); G.Rq[1] = 2.f * (x * y - w * z); G.Rq[2] = 2.f * (x * z + w * y);
+  G.Rq[3] = 2.f * (x * y + w * z); G.Rq[4] = 1.f - 2.f * (x * x + z * z); G.Rq[5] = 2.f * (y * z - w * x);
+  G.Rq[6] = 2.f * (x * z - w * y); G.Rq[7] = 2.f * (y * z + w * x); G.Rq[8] = 1.f - 2.f * (x * x + y * y);
+#pragma unroll
+  for (int j = 0; j < 3; j++) G.s[j] = expf(ls[j]) * cam.glob_scale;
+  float M[9];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) M[3 * r + c] = G.Rq[3 * r + c] * G.s[c];
+  G.Sig[0] = M[0] * M[0] + M[1] * M[1] + M[2] * M[2];
+  G.Sig[1] = M[0] * M[3] + M[1] * M[4] + M[2] * M[5];
+  G.Sig[2] = M[0] * M[6] + M[1] * M[7] + M[2] * M[8];
+  G.Sig[3] = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
+  G.Sig[4] = M[3] * M[6] + M[4] * M[7] + M[5] * M[8];
+  G.Sig[5] = M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
+  const float rz = 1.0f / G.tz;
+  const float ux = G.tx * rz, uy = G.ty * rz;
+  G.inx = (ux >= -cam.limx) && (ux <= cam.limx);
+  G.iny = (uy >= -cam.limy) && (uy <= cam.limy);
+  G.ucx = fminf(fmaxf(ux, -cam.limx), cam.limx);
+  G.ucy = fminf(fmaxf(uy, -cam.limy), cam.limy);
+  const float j00 = cam.fx * rz, j02 = -cam.fx * G.ucx * rz;
+  const float j11 = cam.fy * rz, j12 = -cam.fy * G.ucy * rz;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    G.Tm[c] = j00 * R[c] + j02 * R[6 + c];
+    G.Tm[3 + c] = j11 * R[3 + c] + j12 * R[6 + c];
+  }
+  // TS = Tm * Sigma (2x3), cov = TS * Tm^T
+  float TS[6];
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const float a = G.Tm[3 * r], b = G.Tm[3 * r + 1], c = G.Tm[3 * r + 2];
+    TS[3 * r + 0] = a * G.Sig[0] + b * G.Sig[1] + c * G.Sig[2];
+    TS[3 * r + 1] = a * G.Sig[1] + b * G.Sig[3] + c * G.Sig[4];
+    TS[3 * r + 2] = a * G.Sig[2] + b * G.Sig[4] + c * G.Sig[5];
+  }
+  G.c00 = TS[0] * G.Tm[0] + TS[1] * G.Tm[1] + TS[2] * G.Tm[2] + BLUR;
+  G.c01 = TS[0] * G.Tm[3] + TS[1] * G.Tm[4] + TS[2] * G.Tm[5];
+  G.c11 = TS[3] * G.Tm[3] + TS[4] * G.Tm[4] + TS[5] * G.Tm[5] + BLUR;
+  G.det = G.c00 * G.c11 - G.c01 * G.c01;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 forward
+// ---------------------------------------------------------------------------------------------
+template <int DEG>  // DEG = -1: no SH (colours from colors_in or zero)
+__global__ __launch_bounds__(256) void k_project_fwd(
+    CamK cam, int N, const float* __restrict__ means, const float* __restrict__ log_scales,
+    const float* __restrict__ quats, const float* __restrict__ opac_logit,
+    const float* __restrict__ sh, int sh_stride, const float* __restrict__ colors_in,
+    float* __restrict__ splats) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= N) return;
+  const float m[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
+  const float ls[3] = {log_scales[3 * g], log_scales[3 * g + 1], log_scales[3 * g + 2]};
+  const float4 q4 = ld4(quats + 4 * (size_t)g);
+  const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+  const float opac = 1.0f / (1.0f + expf(-opac_logit[g]));
+
+  float rgb[3] = {0.f, 0.f, 0.f};
+  if constexpr (DEG >= 0) {
+    constexpr int K = (DEG + 1) * (DEG + 1);
+    float dx = m[0] - cam.campos[0], dy = m[1] - cam.campos[1], dz = m[2] - cam.campos[2];
+    const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    float Y[16];
+    sh_basis<DEG>(dx * inv, dy * inv, dz * inv, Y);
+    const float* c = sh + (size_t)g * sh_stride * 3;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      rgb[0] += Y[k] * c[3 * k]; rgb[1] += Y[k] * c[3 * k + 1]; rgb[2] += Y[k] * c[3 * k + 2];
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) rgb[ch] = fmaxf(rgb[ch] + 0.5f, 0.f);
+  } else if (colors_in) {
+    rgb[0] = colors_in[3 * g]; rgb[1] = colors_in[3 * g + 1]; rgb[2] = colors_in[3 * g + 2];
+  }
+
+  Geom G;
+  geom_eval(cam, m, ls, q, G);
+  float x2 = 0.f, y2 = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
+  int radius = 0;
+  if (G.tz > cam.near_plane) {
+    const float rz = 1.0f / G.tz;
+    x2 = cam.fx * G.tx * rz + cam.cx;
+    y2 = cam.fy * G.ty * rz + cam.cy;
+    if (G.det > 0.f) {
+      const float id = 1.0f / G.det;
+      ca = G.c11 * id; cb = -G.c01 * id; cc = G.c00 * id;
+      const float mid = 0.5f * (G.c00 + G.c11);
+      const float lam1 = mid + sqrtf(fmaxf(0.1f, mid * mid - G.det));
+      const int r = (int)ceilf(3.0f * sqrtf(lam1));
+      int x0, y0, x1, y1;
+      tile_rect(x2, y2, r, cam.TW, cam.TH, x0, y0, x1, y1);
+      if ((x1 - x0) * (y1 - y0) > 0) radius = r;
+    }
+  }
+  float* o = splats + (size_t)g * TGS_SPLAT_FLOATS;
+  st4(o, make_float4(x2, y2, G.tz, opac));
+  st4(o + 4, make_float4(ca, cb, cc, rgb[0]));
+  st4(o + 8, make_float4(rgb[1], rgb[2], __int_as_float(radius), 0.f));
+}
+
+// ---------------------------------------------------------------------------------------------
+// K8a: partials -> one gradient record per Gaussian
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sum_partials(const CamK& cam, const float* __restrict__ splats,
+                                             const int32_t* __restrict__ group_base,
+                                             const float* __restrict__ partials, int g, float* v) {
+#pragma unroll
+  for (int i = 0; i < 10; i++) v[i] = 0.f;
+  const float* rec = splats + (size_t)g * TGS_SPLAT_FLOATS;
+  const float4 r0 = ld4(rec);
+  const float4 r2 = ld4(rec + 8);
+  const int radius = __float_as_int(r2.z);
+  if (radius <= 0) return;
+  int x0, y0, x1, y1;
+  tile_rect(r0.x, r0.y, radius, cam.TW, cam.TH, x0, y0, x1, y1);
+  const int hits = (x1 - x0) * (y1 - y0);
+  const size_t off = (size_t)group_base[g / TGS_GROUP] + (size_t)__float_as_int(r2.w);
+  const float* p = partials + off * TGS_PARTIAL_FLOATS;
+  for (int k = 0; k < hits; k++, p += TGS_PARTIAL_FLOATS) {
+    const float4 a = ld4(p), b = ld4(p + 4);
+    const float2 c = *reinterpret_cast<const float2*>(p + 8);
+    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+    v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    v[8] += c.x; v[9] += c.y;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_reduce_partials(
+    CamK cam, int N, const float* __restrict__ splats, const int32_t* __restrict__ group_base,
+    const float* __restrict__ partials, float* __restrict__ v_splats) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= N) return;
+  float v[10];
+  sum_partials(cam, splats, group_base, partials, g, v);
+  float* o = v_splats + (size_t)g * TGS_SPLAT_FLOATS;
+  st4(o, make_float4(v[0], v[1], v[2], v[3]));
+  st4(o + 4, make_float4(v[4], v[5], v[6], v[7]));
+  st4(o + 8, make_float4(v[8], v[9], 0.f, 0.f));
+}
+
+// ---------------------------------------------------------------------------------------------
+// K8 backward
+// ---------------------------------------------------------------------------------------------
+template <int DEG>
+__global__ __launch_bounds__(256) void k_project_bwd(
+    CamK cam, int N, const float* __restrict__ means, const float* __restrict__ log_scales,
+    const float* __restrict__ quats, const float* __restrict__ opac_logit,
+    const float* __restrict__ sh, int sh_stride, const float* __restrict__ splats,
+    const int32_t* __restrict__ group_base, const float* __restrict__ partials,
+    const float* __restrict__ v_splats, float* __restrict__ v_means,
+    float* __restrict__ v_log_scales, float* __restrict__ v_quats,
+    float* __restrict__ v_opac_logit, float* __restrict__ v_sh, float* __restrict__ v_xy) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= N) return;
+  // per-Gaussian upstream gradient: {v_x, v_y, v_depth, v_opac, v_a, v_b, v_c, v_r, v_g, v_b}
+  float v[10];
+  if (partials) {
+    sum_partials(cam, splats, group_base, partials, g, v);
+  } else {
+    const float* p = v_splats + (size_t)g * TGS_SPLAT_FLOATS;
+    const float4 a = ld4(p), b = ld4(p + 4);
+    const float2 c = *reinterpret_cast<const float2*>(p + 8);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z;
+    v[7] = b.w; v[8] = c.x; v[9] = c.y;
+  }
+  const float m[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
+  float vm[3] = {0.f, 0.f, 0.f};
+
+  const float o = 1.0f / (1.0f + expf(-opac_logit[g]));
+  v_opac_logit[g] = v[3] * o * (1.0f - o);
+
+  // ---- SH colour backward (B.5) ----
+  if constexpr (DEG >= 0) {
+    constexpr int K = (DEG + 1) * (DEG + 1);
+    float dx = m[0] - cam.campos[0], dy = m[1] - cam.campos[1], dz = m[2] - cam.campos[2];
+    const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    const float d[3] = {dx * inv, dy * inv, dz * inv};
+    float Y[16];
+    sh_basis<DEG>(d[0], d[1], d[2], Y);
+    const float* c = sh + (size_t)g * sh_stride * 3;
+    float col[3] = {0.5f, 0.5f, 0.5f};
+    float ck[K][3];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+#pragma unroll
+      for (int ch = 0; ch < 3; ch++) { ck[k][ch] = c[3 * k + ch]; col[ch] += Y[k] * ck[k][ch]; }
+    }
+    float vr[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) vr[ch] = (col[ch] > 0.f) ? v[7 + ch] : 0.f;  // clamp gate
+    if (v_sh) {
+      float* o_sh = v_sh + (size_t)g * sh_stride * 3;
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        o_sh[3 * k] = Y[k] * vr[0]; o_sh[3 * k + 1] = Y[k] * vr[1]; o_sh[3 * k + 2] = Y[k] * vr[2];
+      }
+      for (int k = K; k < sh_stride; k++) { o_sh[3 * k] = 0.f; o_sh[3 * k + 1] = 0.f; o_sh[3 * k + 2] = 0.f; }
+    }
+    if constexpr (DEG >= 1) {
+      float dY[K][3];
+      sh_basis_grad<DEG>(d[0], d[1], d[2], dY);
+      float vd[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 1; k < K; k++) {
+        const float s = ck[k][0] * vr[0] + ck[k][1] * vr[1] + ck[k][2] * vr[2];
+        vd[0] += dY[k][0] * s; vd[1] += dY[k][1] * s; vd[2] += dY[k][2] * s;
+      }
+      const float dot = d[0] * vd[0] + d[1] * vd[1] + d[2] * vd[2];
+#pragma unroll
+      for (int j = 0; j < 3; j++) vm[j] += (vd[j] - d[j] * dot) * inv;
+    }
+  } else if (v_sh) {
+    float* o_sh = v_sh + (size_t)g * sh_stride * 3;
+    for (int k = 0; k < sh_stride * 3; k++) o_sh[k] = 0.f;
+  }
+
+  // ---- geometry backward (B.8) ----
+  float vls[3] = {0.f, 0.f, 0.f};
+  float vq[4] = {0.f, 0.f, 0.f, 0.f};
+  const int radius = __float_as_int(splats[(size_t)g * TGS_SPLAT_FLOATS + 10]);
+  if (radius > 0) {
+    const float ls[3] = {log_scales[3 * g], log_scales[3 * g + 1], log_scales[3 * g + 2]};
+    const float4 q4 = ld4(quats + 4 * (size_t)g);
+    const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+    Geom G;
+    geom_eval(cam, m, ls, q, G);
+    const float id = 1.0f / G.det;
+    const float a = G.c11 * id, b = -G.c01 * id, c = G.c00 * id;
+    const float va = v[4], vb = v[5], vc = v[6];
+    // gradient w.r.t. the 2x2 covariance as a full symmetric matrix [[G00,G01],[G01,G11]]
+    const float G00 = -(a * a * va + a * b * vb + b * b * vc);
+    const float G11 = -(b * b * va + b * c * vb + c * c * vc);
+    const float G01 = -0.5f * (2.f * a * b * va + (a * c + b * b) * vb + 2.f * b * c * vc);
+    // GT = Gm * Tm (2x3)
+    float GT[6];
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) {
+      GT[cc] = G00 * G.Tm[cc] + G01 * G.Tm[3 + cc];
+      GT[3 + cc] = G01 * G.Tm[cc] + G11 * G.Tm[3 + cc];
+    }
+    // v_Sigma = Tm^T * GT (3x3 symmetric)
+    float vS[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int cc = 0; cc < 3; cc++) vS[3 * r + cc] = G.Tm[r] * GT[cc] + G.Tm[3 + r] * GT[3 + cc];
+    // v_Tm = 2 * GT * Sigma
+    const float S9[9] = {G.Sig[0], G.Sig[1], G.Sig[2], G.Sig[1], G.Sig[3], G.Sig[4],
+                         G.Sig[2], G.Sig[4], G.Sig[5]};
+    float vTm[6];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+      for (int cc = 0; cc < 3; cc++)
+        vTm[3 * r + cc] = 2.f * (GT[3 * r] * S9[cc] + GT[3 * r + 1] * S9[3 + cc] + GT[3 * r + 2] * S9[6 + cc]);
+    // v_J = v_Tm * R_world^T; only J00, J02, J11, J12 are non-constant
+    const float* R = cam.R;
+    const float vJ00 = vTm[0] * R[0] + vTm[1] * R[1] + vTm[2] * R[2];
+    const float vJ02 = vTm[0] * R[6] + vTm[1] * R[7] + vTm[2] * R[8];
+    const float vJ11 = vTm[3] * R[3] + vTm[4] * R[4] + vTm[5] * R[5];
+    const float vJ12 = vTm[3] * R[6] + vTm[4] * R[7] + vTm[5] * R[8];
+    const float rz = 1.0f / G.tz, rz2 = rz * rz;
+    float vt[3] = {0.f, 0.f, 0.f};
+    vt[2] += -(vJ00 * cam.fx + vJ11 * cam.fy) * rz2;
+    if (G.inx) { vt[0] += -vJ02 * cam.fx * rz2; vt[2] += 2.f * vJ02 * cam.fx * G.tx * rz2 * rz; }
+    else vt[2] += vJ02 * cam.fx * G.ucx * rz2;
+    if (G.iny) { vt[1] += -vJ12 * cam.fy * rz2; vt[2] += 2.f * vJ12 * cam.fy * G.ty * rz2 * rz; }
+    else vt[2] += vJ12 * cam.fy * G.ucy * rz2;
+    // mean2d and depth
+    vt[0] += v[0] * cam.fx * rz; vt[2] += -v[0] * cam.fx * G.tx * rz2;
+    vt[1] += v[1] * cam.fy * rz; vt[2] += -v[1] * cam.fy * G.ty * rz2;
+    vt[2] += v[2];
+#pragma unroll
+    for (int j = 0; j < 3; j++) vm[j] += R[j] * vt[0] + R[3 + j] * vt[1] + R[6 + j] * vt[2];
+    // Sigma = M M^T  ->  v_M = 2 v_Sigma M,  M = Rq diag(s)
+    float vR[9];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      float vMj[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+        vMj[r] = 2.f * (vS[3 * r] * G.Rq[j] + vS[3 * r + 1] * G.Rq[3 + j] + vS[3 * r + 2] * G.Rq[6 + j]) * G.s[j];
+      const float vs = G.Rq[j] * vMj[0] + G.Rq[3 + j] * vMj[1] + G.Rq[6 + j] * vMj[2];
+      vls[j] = vs * G.s[j];
+      vR[j] = vMj[0] * G.s[j]; vR[3 + j] = vMj[1] * G.s[j]; vR[6 + j] = vMj[2] * G.s[j];
+    }
+    const float w = G.qn[0], x = G.qn[1], y = G.qn[2], z = G.qn[3];
+    float vqn[4];
+    vqn[0] = 2.f * (x * (vR[7] - vR[5]) + y * (vR[2] - vR[6]) + z * (vR[3] - vR[1]));
+    vqn[1] = 2.f * (-2.f * x * (vR[4] + vR[8]) + y * (vR[1] + vR[3]) + z * (vR[2] + vR[6]) + w * (vR[7] - vR[5]));
+    vqn[2] = 2.f * (x * (vR[1] + vR[3]) - 2.f * y * (vR[0] + vR[8]) + z * (vR[5] + vR[7]) + w * (vR[2] - vR[6]));
+    vqn[3] = 2.f * (x * (vR[2] + vR[6]) + y * (vR[5] + vR[7]) - 2.f * z * (vR[0] + vR[4]) + w * (vR[3] - vR[1]));
+    const float dot = w * vqn[0] + x * vqn[1] + y * vqn[2] + z * vqn[3];
+    const float iq = 1.0f / G.qnorm;
+#pragma unroll
+    for (int j = 0; j < 4; j++) vq[j] = (vqn[j] - G.qn[j] * dot) * iq;
+  }
+  v_means[3 * g] = vm[0]; v_means[3 * g + 1] = vm[1]; v_means[3 * g + 2] = vm[2];
+  v_log_scales[3 * g] = vls[0]; v_log_scales[3 * g + 1] = vls[1]; v_log_scales[3 * g + 2] = vls[2];
+  st4(v_quats + 4 * (size_t)g, make_float4(vq[0], vq[1], vq[2], vq[3]));
+  if (v_xy) {
+    v_xy[2 * g] = v[0]; v_xy[2 * g + 1] = v[1];
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" int tgs_project_fwd(const TgsCamera* cam, int N, const float* means,
+                               const float* log_scales, const float* quats,
+                               const float* opac_logit, const float* sh, int sh_stride, int sh_deg,
+                               const float* colors_in, float* splats, void* stream) {
+  TGS_CHECK_ARG(camera_ok(cam), "bad camera");
+  TGS_CHECK_ARG(N >= 0, "N < 0");
+  if (N == 0) return TGS_OK;
+  TGS_CHECK_ARG(means && log_scales && quats && opac_logit && splats, "null pointer");
+  if (!sh) sh_deg = -1;
+  TGS_CHECK_ARG(sh_deg <= 3, "sh_deg > 3");
+  TGS_CHECK_ARG(sh_deg < 0 || sh_stride >= (sh_deg + 1) * (sh_deg + 1), "sh_stride too small");
+  const CamK k = make_camk(cam);
+  const dim3 grid((N + 255) / 256), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(D)                                                                              \
+  hipLaunchKernelGGL(k_project_fwd<D>, grid, block, 0, s, k, N, means, log_scales, quats,      \
+                     opac_logit, sh, sh_stride, colors_in, splats)
+  switch (sh_deg) {
+    case 0: LAUNCH(0); break;
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 3: LAUNCH(3); break;
+    default: LAUNCH(-1); break;
+  }
+#undef LAUNCH
+  TGS_CHECK_LAUNCH();
+  return TGS_OK;
+}
+
+extern "C" int tgs_reduce_partials(int N, const float* splats, const int32_t* group_base,
+                                   const TgsCamera* cam, const float* partials, float* v_splats,
+                                   void* stream) {
+  TGS_CHECK_ARG(camera_ok(cam), "bad camera");
+  if (N <= 0) return TGS_OK;
+  TGS_CHECK_ARG(splats && group_base && partials && v_splats, "null pointer");
+  const CamK k = make_camk(cam);
+  hipLaunchKernelGGL(k_reduce_partials, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     k, N, splats, group_base, partials, v_splats);
+  TGS_CHECK_LAUNCH();
+  return TGS_OK;
+}
+
+extern "C" int tgs_project_bwd(const TgsCamera* cam, int N, const float* means,
+                               const float* log_scales, const float* quats,
+                               const float* opac_logit, const float* sh, int sh_stride, int sh_deg,
+                               const float* splats, const int32_t* group_base,
+                               const float* partials, const float* v_splats, float* v_means,
+                               float* v_log_scales, float* v_quats, float* v_opac_logit,
+                               float* v_sh, float* v_xy, void* stream) {
+  TGS_CHECK_ARG(camera_ok(cam), "bad camera");
+  if (N <= 0) return TGS_OK;
+  TGS_CHECK_ARG(means && log_scales && quats && opac_logit && splats, "null pointer");
+  TGS_CHECK_ARG((partials && group_base) || v_splats, "need partials+group_base or v_splats");
+  TGS_CHECK_ARG(v_means && v_log_scales && v_quats && v_opac_logit, "null output pointer");
+  if (!sh) sh_deg = -1;
+  TGS_CHECK_ARG(sh_deg <= 3, "sh_deg > 3");
+  TGS_CHECK_ARG(sh_deg < 0 || sh_stride >= (sh_deg + 1) * (sh_deg + 1), "sh_stride too small");
+  const CamK k = make_camk(cam);
+  const dim3 grid((N + 255) / 256), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(D)                                                                                \
+  hipLaunchKernelGGL(k_project_bwd<D>, grid, block, 0, s, k, N, means, log_scales, quats,        \
+                     opac_logit, sh, sh_stride, splats, group_base, partials, v_splats, v_means, \
+                     v_log_scales, v_quats, v_opac_logit, v_sh, v_xy)
+  switch (sh_deg) {
+    case 0: LAUNCH(0); break;
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 3: LAUNCH(3); break;
+    default: LAUNCH(-1); break;
+  }
+#undef LAUNCH
+  TGS_CHECK_LAUNCH();
+  return TGS_OK;
+}

@@ -1,0 +1,126 @@
+// tgs_common.h -- shared host/device helpers for libtgs_hip.so (gfx950 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/tgs.h"
+
+#define TGS_WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+void tgs_set_error(const char* fmt, ...);
+
+#define TGS_CHECK_ARG(cond, msg)                       \
+  do {                                                 \
+    if (!(cond)) {                                     \
+      tgs_set_error("%s: %s", __func__, msg);          \
+      return TGS_E_ARG;                                \
+    }                                                  \
+  } while (0)
+
+#define TGS_CHECK_LAUNCH()                                                     \
+  do {                                                                         \
+    hipError_t e_ = hipGetLastError();                                         \
+    if (e_ != hipSuccess) {                                                    \
+      tgs_set_error("%s: HIP launch failed: %s", __func__, hipGetErrorString(e_)); \
+      return TGS_E_HIP;                                                        \
+    }                                                                          \
+  } while (0)
+
+#define TGS_HIP(call)                                                          \
+  do {                                                                         \
+    hipError_t e_ = (call);                                                    \
+    if (e_ != hipSuccess) {                                                    \
+      tgs_set_error("%s: %s failed: %s", __func__, #call, hipGetErrorString(e_)); \
+      return TGS_E_HIP;                                                        \
+    }                                                                          \
+  } while (0)
+
+// Kernel-side camera block (passed by value in kernarg -> lives in SGPRs).
+struct CamK {
+  float R[9];      // world->cam rotation, row-major
+  float t[3];      // world->cam translation
+  float campos[3]; // -R^T t
+  float fx, fy, cx, cy;
+  float limx, limy; // 1.3 * tan(fov/2)
+  float near_plane, pix_center, glob_scale;
+  float bg[3];
+  int W, H, TW, TH;
+};
+
+static inline CamK make_camk(const TgsCamera* c) {
+  CamK k;
+  const float* V = c->viewmat;
+  for (int r = 0; r < 3; r++) {
+    for (int j = 0; j < 3; j++) k.R[3 * r + j] = V[4 * r + j];
+    k.t[r] = V[4 * r + 3];
+  }
+  for (int j = 0; j < 3; j++)
+    k.campos[j] = -(V[0 + j] * V[3] + V[4 + j] * V[7] + V[8 + j] * V[11]);
+  k.fx = c->fx; k.fy = c->fy; k.cx = c->cx; k.cy = c->cy;
+  k.limx = 1.3f * (0.5f * (float)c->W) / c->fx;
+  k.limy = 1.3f * (0.5f * (float)c->H) / c->fy;
+  k.near_plane = c->near_plane; k.pix_center = c->pix_center; k.glob_scale = c->glob_scale;
+  for (int j = 0; j < 3; j++) k.bg[j] = c->bg[j];
+  k.W = c->W; k.H = c->H;
+  k.TW = (c->W + TGS_BLOCK - 1) / TGS_BLOCK;
+  k.TH = (c->H + TGS_BLOCK - 1) / TGS_BLOCK;
+  return k;
+}
+
+static inline bool camera_ok(const TgsCamera* c) {
+  return c && c->W > 0 && c->H > 0 && c->fx > 0.f && c->fy > 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device side
+// ---------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+// App. B.4 tile rectangle.  ONE definition shared by every kernel so that the pair index of a
+// (tile, Gaussian) intersection is computed identically everywhere.
+__device__ __forceinline__ void tile_rect(float u, float v, int radius, int TW, int TH,
+                                          int& x0, int& y0, int& x1, int& y1) {
+  const float r = (float)radius;
+  const float inv = 1.0f / (float)TGS_BLOCK;  // exact (power of two)
+  x0 = min(max((int)((u - r) * inv), 0), TW);
+  x1 = min(max((int)((u + r) * inv) + 1, 0), TW);
+  y0 = min(max((int)((v - r) * inv), 0), TH);
+  y1 = min(max((int)((v + r) * inv) + 1, 0), TH);
+}
+
+// wave64 sum via DPP (no LDS, no ds_bpermute).  Total lands in lane 63; the helper returns it
+// wave-uniformly (SGPR) through v_readlane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  int s = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+  return v + __builtin_bit_cast(float, s);
+}
+
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v = dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xf>(v);  // row_half_mirror
+  v = dpp_add<0x140, 0xf>(v);  // row_mirror      -> every lane holds its row's sum
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1,3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3 -> lane 63 = total
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+  v = wave_sum_to_lane63(v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+#endif  // __HIPCC__

@@ -1,0 +1,430 @@
+"""Operator layer: thin wrappers over the C ABI (include/tgs.h) + the autograd Functions.
+
+Mirrors the operator surface the reference's training loop reaches through
+``ns-train depth-gaussian-splatting`` (reference ``scripts/train_bunny_real.sh:52``):
+
+* fused fast path  -- :func:`render` -> (rgb, depth_acc, alpha) in ONE compositing pass;
+* gsplat-0.1 shaped -- :func:`project_gaussians`, :func:`rasterize_gaussians`,
+  :func:`spherical_harmonics` (these are what nerfstudio's Splatfacto calls);
+* INRIA shaped      -- ``touch_gs_amd.rasterizer.GaussianRasterizer`` (App. A.1).
+
+Every op runs the HIP kernels; there is no eager/CPU fallback (tensors must be on the device).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import PARTIAL_FLOATS, SPLAT_FLOATS, check, ptr
+from .camera import Camera
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# capacity management for the (tile, Gaussian) intersection buffers
+# ------------------------------------------------------------------------------------------------
+class IntersectBudget:
+    """Remembers how many (tile, Gaussian) intersections recent frames needed.
+
+    ``sync=True`` (default): after binning, the 8-byte status word is read back (one D2H sync per
+    frame) and the frame is re-binned with a larger buffer if it overflowed -- always correct.
+    ``sync=False``: no read-back; the caller must size ``capacity`` itself and call
+    :meth:`check` at a convenient sync point (bench.py does this once after the timed region).
+    """
+
+    def __init__(self, capacity: int = 0, sync: bool = True, growth: float = 1.25):
+        self.capacity = int(capacity)
+        self.sync = sync
+        self.growth = growth
+        self.last_status = None  # device int32[2] of the most recent frame
+        self.last_n = None
+
+    def initial(self, N: int):
+        if self.capacity <= 0:
+            self.capacity = max(8 * N, 1 << 16)
+        return self.capacity
+
+    def check(self):
+        """Read the last frame's status; raises if it overflowed.  Returns #intersections."""
+        if self.last_status is None:
+            return None
+        n, ovf = self.last_status.tolist()
+        self.last_n = n
+        if ovf:
+            raise RuntimeError(f"intersection capacity {self.capacity} too small: frame needed {n}")
+        return n
+
+
+_default_budget = IntersectBudget()
+
+
+# ------------------------------------------------------------------------------------------------
+# thin wrappers (one per C entry point)
+# ------------------------------------------------------------------------------------------------
+def project_fwd(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_deg: int, colors=None):
+    """K1 -> splats [N,12].  (tgs_project_fwd)"""
+    lib = _lib.load()
+    N = means.shape[0]
+    splats = torch.empty(N, SPLAT_FLOATS, dtype=torch.float32, device=means.device)
+    cs = cam.c_struct()
+    sh_stride = sh.shape[1] if sh is not None else 0
+    check(lib.tgs_project_fwd(C.byref(cs), N, ptr(means), ptr(log_scales), ptr(quats), ptr(opac_logit),
+                              ptr(sh), sh_stride, sh_deg if sh is not None else -1, ptr(colors),
+                              ptr(splats), _stream()), "tgs_project_fwd")
+    return splats
+
+
+def bin_sort(cam: Camera, splats, budget: Optional[IntersectBudget] = None):
+    """K2-K5 -> (group_base, tile_start, sorted_gid, status).  (tgs_bin_sort)"""
+    lib = _lib.load()
+    budget = budget or _default_budget
+    N = splats.shape[0]
+    dev = splats.device
+    T = cam.num_tiles
+    G = lib.tgs_num_groups(N)
+    cs = cam.c_struct()
+    group_base = torch.empty(max(G, 1), dtype=torch.int32, device=dev)
+    tile_start = torch.empty(T + 1, dtype=torch.int32, device=dev)
+    tile_cursor = torch.empty(max(T, 1), dtype=torch.int32, device=dev)
+    status = torch.empty(2, dtype=torch.int32, device=dev)
+    cap = budget.initial(N)
+    while True:
+        sorted_gid = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+        scratch = torch.empty(lib.tgs_sort_scratch_bytes(cap), dtype=torch.uint8, device=dev)
+        check(lib.tgs_bin_sort(C.byref(cs), N, ptr(splats), ptr(group_base), ptr(tile_start),
+                               ptr(tile_cursor), ptr(sorted_gid), cap, ptr(scratch), ptr(status),
+                               _stream()), "tgs_bin_sort")
+        budget.last_status = status
+        if not budget.sync:
+            break
+        n, ovf = status.tolist()
+        budget.last_n = n
+        if not ovf:
+            break
+        cap = int(n * budget.growth) + 1024
+        budget.capacity = cap
+    return group_base, tile_start, sorted_gid, status
+
+
+def rasterize_fwd(cam: Camera, splats, sorted_gid, tile_start):
+    """K6 -> (rgb [H,W,3], depth_acc [H,W], final_T [H,W], final_idx [H,W]).  (tgs_rasterize_fwd)"""
+    lib = _lib.load()
+    dev = splats.device
+    H, W = cam.H, cam.W
+    rgb = torch.empty(H, W, 3, dtype=torch.float32, device=dev)
+    depth = torch.empty(H, W, dtype=torch.float32, device=dev)
+    fT = torch.empty(H, W, dtype=torch.float32, device=dev)
+    fidx = torch.empty(H, W, dtype=torch.int32, device=dev)
+    cs = cam.c_struct()
+    check(lib.tgs_rasterize_fwd(C.byref(cs), ptr(splats), ptr(sorted_gid), ptr(tile_start), ptr(rgb),
+                                ptr(depth), ptr(fT), ptr(fidx), _stream()), "tgs_rasterize_fwd")
+    return rgb, depth, fT, fidx
+
+
+def rasterize_bwd(cam: Camera, splats, group_base, sorted_gid, tile_start, rgb, depth, fT, fidx,
+                  v_rgb=None, v_depth=None, v_alpha=None, loss: Optional[dict] = None,
+                  want_tile_loss: bool = False):
+    """K7 -> (partials [cap,12], tile_loss [T,2] or None).  (tgs_rasterize_bwd)
+
+    ``loss`` = dict(gt_rgb, gt_depth, uncertainty, l1_weight, depth_weight, uncertainty_weight, eps).
+    """
+    lib = _lib.load()
+    dev = splats.device
+    partials = torch.empty(sorted_gid.shape[0], PARTIAL_FLOATS, dtype=torch.float32, device=dev)
+    tile_loss = torch.empty(cam.num_tiles, 2, dtype=torch.float32, device=dev) if want_tile_loss else None
+    cs = cam.c_struct()
+    ls = None
+    keep = []
+    if loss is not None:
+        ls = _lib.TgsLossSpec()
+        for k in ("gt_rgb", "gt_depth", "uncertainty"):
+            t = _f32c(loss.get(k))
+            keep.append(t)
+            setattr(ls, k, ptr(t))
+        ls.l1_weight = float(loss.get("l1_weight", 0.0))
+        ls.depth_weight = float(loss.get("depth_weight", 0.0))
+        ls.uncertainty_weight = float(loss.get("uncertainty_weight", 1.0))
+        ls.eps = float(loss.get("eps", 1e-6))
+    v_rgb, v_depth, v_alpha = _f32c(v_rgb), _f32c(v_depth), _f32c(v_alpha)
+    check(lib.tgs_rasterize_bwd(C.byref(cs), ptr(splats), ptr(group_base), ptr(sorted_gid),
+                                ptr(tile_start), ptr(rgb), ptr(depth), ptr(fT), ptr(fidx),
+                                ptr(v_rgb), ptr(v_depth), ptr(v_alpha),
+                                C.byref(ls) if ls is not None else None, ptr(partials),
+                                ptr(tile_loss), _stream()), "tgs_rasterize_bwd")
+    return partials, tile_loss
+
+
+def reduce_partials(cam: Camera, splats, group_base, partials):
+    """K8a -> v_splats [N,12].  (tgs_reduce_partials)"""
+    lib = _lib.load()
+    N = splats.shape[0]
+    v_splats = torch.empty(N, SPLAT_FLOATS, dtype=torch.float32, device=splats.device)
+    cs = cam.c_struct()
+    check(lib.tgs_reduce_partials(N, ptr(splats), ptr(group_base), C.byref(cs), ptr(partials),
+                                  ptr(v_splats), _stream()), "tgs_reduce_partials")
+    return v_splats
+
+
+def project_bwd(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_deg, splats,
+                group_base=None, partials=None, v_splats=None, out=None, want_v_xy=False):
+    """K8 -> (v_means, v_log_scales, v_quats, v_opac_logit, v_sh, v_xy).  (tgs_project_bwd)
+
+    ``out`` may supply pre-allocated gradient tensors (e.g. views into a flat gradient buffer).
+    """
+    lib = _lib.load()
+    N = means.shape[0]
+    dev = means.device
+    e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    if out is None:
+        out = (e(N, 3), e(N, 3), e(N, 4), e(N), torch.empty_like(sh) if sh is not None else None)
+    v_means, v_ls, v_q, v_ol, v_sh = out
+    v_xy = e(N, 2) if want_v_xy else None
+    cs = cam.c_struct()
+    sh_stride = sh.shape[1] if sh is not None else 0
+    check(lib.tgs_project_bwd(C.byref(cs), N, ptr(means), ptr(log_scales), ptr(quats), ptr(opac_logit),
+                              ptr(sh), sh_stride, sh_deg if sh is not None else -1, ptr(splats),
+                              ptr(group_base), ptr(partials), ptr(v_splats), ptr(v_means), ptr(v_ls),
+                              ptr(v_q), ptr(v_ol), ptr(v_sh), ptr(v_xy), _stream()), "tgs_project_bwd")
+    return v_means, v_ls, v_q, v_ol, v_sh, v_xy
+
+
+# ------------------------------------------------------------------------------------------------
+# fused differentiable render
+# ------------------------------------------------------------------------------------------------
+class _Render(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, log_scales, quats, opac_logit, sh, means2d, cam, sh_deg, budget):
+        means, log_scales, quats, opac_logit, sh = map(_f32c, (means, log_scales, quats, opac_logit, sh))
+        splats = project_fwd(cam, means, log_scales, quats, opac_logit, sh, sh_deg)
+        group_base, tile_start, sorted_gid, _ = bin_sort(cam, splats, budget)
+        rgb, depth, fT, fidx = rasterize_fwd(cam, splats, sorted_gid, tile_start)
+        ctx.cam, ctx.sh_deg = cam, sh_deg
+        ctx.want_xy = means2d is not None
+        ctx.save_for_backward(means, log_scales, quats, opac_logit, sh, splats, group_base,
+                              tile_start, sorted_gid, rgb, depth, fT, fidx)
+        alpha = 1.0 - fT
+        radii = splats[:, 10].view(torch.int32)
+        ctx.mark_non_differentiable(radii)
+        return rgb, depth, alpha, radii
+
+    @staticmethod
+    def backward(ctx, v_rgb, v_depth, v_alpha, _v_radii):
+        (means, log_scales, quats, opac_logit, sh, splats, group_base, tile_start, sorted_gid,
+         rgb, depth, fT, fidx) = ctx.saved_tensors
+        cam = ctx.cam
+        partials, _ = rasterize_bwd(cam, splats, group_base, sorted_gid, tile_start, rgb, depth, fT,
+                                    fidx, v_rgb, v_depth, v_alpha)
+        v_means, v_ls, v_q, v_ol, v_sh, v_xy = project_bwd(
+            cam, means, log_scales, quats, opac_logit, sh, ctx.sh_deg, splats, group_base, partials,
+            want_v_xy=ctx.want_xy)
+        return v_means, v_ls, v_q, v_ol, v_sh, v_xy, None, None, None
+
+
+def render(means, log_scales, quats, opac_logit, sh, cam: Camera, sh_deg: int,
+           means2d: Optional[torch.Tensor] = None, budget: Optional[IntersectBudget] = None):
+    """Fused differentiable render of RGB + depth + alpha in one compositing pass.
+
+    Parameters are the raw (pre-activation) Gaussian parameters of SURVEY App. B.0.
+    ``means2d`` ([N,2], requires_grad) optionally receives the screen-space mean gradient
+    (INRIA ``means2D.grad`` convention) for densification statistics.
+    Returns (rgb [H,W,3] incl. background, depth_acc [H,W] = sum w*z, alpha [H,W], radii [N]).
+    Expected depth is ``depth_acc / alpha`` (consumer side, as Splatfacto does).
+    """
+    return _Render.apply(means, log_scales, quats, opac_logit, sh, means2d, cam, sh_deg, budget)
+
+
+# ------------------------------------------------------------------------------------------------
+# gsplat-0.1 shaped operator surface
+# ------------------------------------------------------------------------------------------------
+def _sh_basis_torch(deg: int, d: torch.Tensor) -> torch.Tensor:
+    x, y, z = d[..., 0], d[..., 1], d[..., 2]
+    out = [torch.full_like(x, 0.28209479177387814)]
+    if deg >= 1:
+        c1 = 0.4886025119029199
+        out += [-c1 * y, c1 * z, -c1 * x]
+    if deg >= 2:
+        xx, yy, zz = x * x, y * y, z * z
+        out += [1.0925484305920792 * x * y, -1.0925484305920792 * y * z,
+                0.31539156525252005 * (2 * zz - xx - yy), -1.0925484305920792 * x * z,
+                0.5462742152960396 * (xx - yy)]
+    if deg >= 3:
+        out += [-0.5900435899266435 * y * (3 * xx - yy), 2.890611442640554 * x * y * z,
+                -0.4570457994644658 * y * (4 * zz - xx - yy),
+                0.3731763325901154 * z * (2 * zz - 3 * xx - 3 * yy),
+                -0.4570457994644658 * x * (4 * zz - xx - yy), 1.445305721320277 * z * (xx - yy),
+                -0.5900435899266435 * x * (xx - 3 * yy)]
+    return torch.stack(out, dim=-1)
+
+
+def spherical_harmonics(degrees_to_use: int, viewdirs: torch.Tensor, coeffs: torch.Tensor):
+    """gsplat-shaped SH evaluation: coeffs [N,K,3], viewdirs [N,3] (normalised here) -> [N,3].
+
+    Stand-alone compatibility op built from device torch ops (differentiable); the training hot
+    path does not use it -- K1/K8 evaluate SH inside the projection kernels.
+    """
+    if not coeffs.is_cuda:
+        raise RuntimeError("touch_gs_amd ops need device (HIP) tensors; there is no CPU path")
+    d = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
+    K = (degrees_to_use + 1) ** 2
+    Y = _sh_basis_torch(degrees_to_use, d)
+    return (Y[..., :, None] * coeffs[..., :K, :]).sum(-2)
+
+
+class _ProjectGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3d, scales, glob_scale, quats, cam):
+        means3d, quats = _f32c(means3d), _f32c(quats)
+        log_scales = torch.log(_f32c(scales))
+        N = means3d.shape[0]
+        zero = torch.zeros(N, dtype=torch.float32, device=means3d.device)
+        cam = Camera(cam.viewmat, cam.fx, cam.fy, cam.cx, cam.cy, cam.W, cam.H, cam.near,
+                     cam.pix_center, cam.bg, float(glob_scale))
+        splats = project_fwd(cam, means3d, log_scales, quats, zero, None, -1)
+        ctx.cam = cam
+        ctx.save_for_backward(means3d, log_scales, quats, zero, splats)
+        xys = splats[:, 0:2].contiguous()
+        depths = splats[:, 2].contiguous()
+        conics = splats[:, 4:7].contiguous()
+        radii = splats[:, 10].contiguous().view(torch.int32)
+        ctx.mark_non_differentiable(radii)
+        return xys, depths, radii, conics
+
+    @staticmethod
+    def backward(ctx, v_xys, v_depths, _v_radii, v_conics):
+        means3d, log_scales, quats, zero, splats = ctx.saved_tensors
+        N = means3d.shape[0]
+        v_splats = torch.zeros(N, SPLAT_FLOATS, dtype=torch.float32, device=means3d.device)
+        if v_xys is not None:
+            v_splats[:, 0:2] = v_xys
+        if v_depths is not None:
+            v_splats[:, 2] = v_depths
+        if v_conics is not None:
+            v_splats[:, 4:7] = v_conics
+        v_means, v_ls, v_q, _, _, _ = project_bwd(ctx.cam, means3d, log_scales, quats, zero, None, -1,
+                                                  splats, v_splats=v_splats)
+        v_scales = v_ls / torch.exp(log_scales)
+        return v_means, v_scales, None, v_q, None
+
+
+def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height,
+                      img_width, block_width: int = 16, clip_thresh: float = 0.01):
+    """gsplat-0.1 ``project_gaussians``: -> (xys, depths, radii, conics, comp, num_tiles_hit, cov3d).
+
+    ``scales`` are post-exp, ``quats`` un-normalised (w,x,y,z), ``viewmat`` world->camera.
+    ``comp`` is all ones (no anti-aliasing compensation in App. B); ``cov3d`` is the upper triangle
+    of R S S^T R^T computed with device torch ops (not differentiated, as in gsplat 0.1).
+    """
+    if block_width != 16:
+        raise ValueError("only 16x16 tiles are supported (SURVEY App. B.0)")
+    cam = Camera(viewmat, fx, fy, cx, cy, img_width, img_height, near=clip_thresh)
+    xys, depths, radii, conics = _ProjectGaussians.apply(means3d, scales, glob_scale, quats, cam)
+    with torch.no_grad():
+        tw, th = cam.tiles
+        r = radii.to(torch.float32)
+        x0 = torch.clamp(((xys[:, 0] - r) / 16).to(torch.int32), 0, tw)
+        x1 = torch.clamp(((xys[:, 0] + r) / 16).to(torch.int32) + 1, 0, tw)
+        y0 = torch.clamp(((xys[:, 1] - r) / 16).to(torch.int32), 0, th)
+        y1 = torch.clamp(((xys[:, 1] + r) / 16).to(torch.int32) + 1, 0, th)
+        num_tiles_hit = torch.where(radii > 0, (x1 - x0) * (y1 - y0), torch.zeros_like(x0))
+        q = quats / quats.norm(dim=-1, keepdim=True)
+        w, x, y, z = q.unbind(-1)
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                         2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                         2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1).view(-1, 3, 3)
+        M = R * (scales * glob_scale)[:, None, :]
+        S = M @ M.transpose(1, 2)
+        cov3d = torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], -1)
+        comp = torch.ones_like(depths)
+    return xys, depths, radii, conics, comp, num_tiles_hit, cov3d
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xys, depths, radii, conics, colors, opacity, cam, budget):
+        N = xys.shape[0]
+        dev = xys.device
+        op = opacity.reshape(N, 1).to(torch.float32)
+        splats = torch.cat([xys.to(torch.float32), depths.reshape(N, 1).to(torch.float32), op,
+                            conics.to(torch.float32), colors.to(torch.float32),
+                            radii.to(torch.int32).reshape(N, 1).view(torch.float32),
+                            torch.zeros(N, 1, dtype=torch.float32, device=dev)], dim=1).contiguous()
+        group_base, tile_start, sorted_gid, _ = bin_sort(cam, splats, budget)
+        rgb, depth, fT, fidx = rasterize_fwd(cam, splats, sorted_gid, tile_start)
+        ctx.cam = cam
+        ctx.opacity_shape = opacity.shape
+        ctx.save_for_backward(splats, group_base, tile_start, sorted_gid, rgb, depth, fT, fidx)
+        return rgb, 1.0 - fT, depth
+
+    @staticmethod
+    def backward(ctx, v_rgb, v_alpha, v_depth):
+        splats, group_base, tile_start, sorted_gid, rgb, depth, fT, fidx = ctx.saved_tensors
+        cam = ctx.cam
+        partials, _ = rasterize_bwd(cam, splats, group_base, sorted_gid, tile_start, rgb, depth, fT,
+                                    fidx, v_rgb, v_depth, v_alpha)
+        v = reduce_partials(cam, splats, group_base, partials)
+        v_xys, v_depths = v[:, 0:2].contiguous(), v[:, 2].contiguous()
+        v_op = v[:, 3].contiguous().reshape(ctx.opacity_shape)
+        v_conics, v_colors = v[:, 4:7].contiguous(), v[:, 7:10].contiguous()
+        return v_xys, v_depths, None, v_conics, v_colors, v_op, None, None
+
+
+def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height,
+                        img_width, block_width: int = 16, background=None, return_alpha: bool = False,
+                        return_depth: bool = False, budget: Optional[IntersectBudget] = None):
+    """gsplat-0.1 ``rasterize_gaussians``: -> out_img [H,W,3] (, out_alpha [H,W]) (, depth_acc [H,W]).
+
+    ``num_tiles_hit`` is accepted for signature compatibility and recomputed in-kernel from
+    (xys, radii) by the App. B.4 rule.  ``return_depth`` is this build's extension: the depth
+    channel composited in the same pass (Splatfacto instead calls the op a second time with
+    ``depths.repeat(1,3)`` as colours, which also works here).
+    """
+    if block_width != 16:
+        raise ValueError("only 16x16 tiles are supported (SURVEY App. B.0)")
+    if colors.shape[-1] != 3:
+        raise ValueError("colors must be [N,3]")
+    bg = (0.0, 0.0, 0.0) if background is None else tuple(float(b) for b in background.detach().cpu().tolist())
+    eye = [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]]
+    cam = Camera(eye, 1.0, 1.0, 0.0, 0.0, img_width, img_height, bg=bg)
+    rgb, alpha, depth = _RasterizeGaussians.apply(xys, depths, radii, conics, colors, opacity, cam, budget)
+    out = (rgb,)
+    if return_alpha:
+        out += (alpha,)
+    if return_depth:
+        out += (depth,)
+    return out[0] if len(out) == 1 else out
+
+
+# ------------------------------------------------------------------------------------------------
+# image-space loss kernel (K10)
+# ------------------------------------------------------------------------------------------------
+def ssim_fwd_bwd(img, gt, weight: float = 1.0, want_grad: bool = True):
+    """K10 -> (sum of the SSIM map [device scalar], v_img = weight * d(sum)/d(img) or None).
+
+    Mean SSIM = sum / (3*H*W).  For the loss term l*(1-mean SSIM) pass weight = -l/(3*H*W).
+    (tgs_ssim_fwd_bwd)
+    """
+    lib = _lib.load()
+    img, gt = _f32c(img), _f32c(gt)
+    H, W = img.shape[0], img.shape[1]
+    dev = img.device
+    nb = 3 * ((H + 15) // 16) * ((W + 15) // 16)
+    bp = torch.empty(nb, dtype=torch.float32, device=dev)
+    v_img = torch.empty_like(img) if want_grad else None
+    scratch = torch.empty(9 * H * W, dtype=torch.float32, device=dev) if want_grad else None
+    check(lib.tgs_ssim_fwd_bwd(W, H, ptr(img), ptr(gt), C.c_float(weight), ptr(bp), ptr(v_img),
+                               ptr(scratch), _stream()), "tgs_ssim_fwd_bwd")
+    return bp.sum(), v_img

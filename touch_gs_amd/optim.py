@@ -1,0 +1,113 @@
+"""Flat SoA parameter store + fused Adam (K9) for the Gaussian model.
+
+All parameters of the model live in ONE flat fp32 buffer (and the gradients / Adam moments in
+three more of the same layout) so that (a) the data-parallel gradient exchange is a single RCCL
+collective over one buffer and (b) the optimizer is a single streaming launch.  Layout
+(include/tgs.h, TgsAdamSpec):  means[3N] | log_scales[3N] | quats[4N] | opac_logit[N] | sh[N*K*3],
+each segment starting at a multiple of 4 floats.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+
+
+def _al4(x: int) -> int:
+    return (x + 3) & ~3
+
+
+def layout(N: int, K: int) -> Dict[str, tuple]:
+    """name -> (offset, numel, shape); 'total' -> padded element count."""
+    o_means = 0
+    o_scales = _al4(o_means + 3 * N)
+    o_quats = _al4(o_scales + 3 * N)
+    o_opac = o_quats + 4 * N
+    o_sh = _al4(o_opac + N)
+    total = _al4(o_sh + 3 * K * N)
+    return dict(means=(o_means, 3 * N, (N, 3)), log_scales=(o_scales, 3 * N, (N, 3)),
+                quats=(o_quats, 4 * N, (N, 4)), opac_logit=(o_opac, N, (N,)),
+                sh=(o_sh, 3 * K * N, (N, K, 3)), total=total)
+
+
+class GaussianParams:
+    """Flat parameter + gradient buffers with named views (SURVEY App. B.0 parameters)."""
+
+    NAMES = ("means", "log_scales", "quats", "opac_logit", "sh")
+
+    def __init__(self, flat: torch.Tensor, N: int, K: int):
+        self.N, self.K = N, K
+        self.flat = flat
+        self.grad = torch.zeros_like(flat)
+        for k, v in self.views_of(self.flat, N, K).items():
+            setattr(self, k, v)
+        self.g = self.views_of(self.grad, N, K)
+
+    @staticmethod
+    def views_of(flat: torch.Tensor, N: int, K: int) -> Dict[str, torch.Tensor]:
+        L = layout(N, K)
+        return {k: flat[L[k][0]:L[k][0] + L[k][1]].view(L[k][2]) for k in GaussianParams.NAMES}
+
+    @staticmethod
+    def allocate(N: int, K: int, device) -> "GaussianParams":
+        flat = torch.zeros(layout(N, K)["total"], dtype=torch.float32, device=device)
+        return GaussianParams(flat, N, K)
+
+    @staticmethod
+    def from_tensors(means, log_scales, quats, opac_logit, sh) -> "GaussianParams":
+        N, K = means.shape[0], sh.shape[1]
+        gp = GaussianParams.allocate(N, K, means.device)
+        for k, t in zip(GaussianParams.NAMES, (means, log_scales, quats, opac_logit, sh)):
+            getattr(gp, k).copy_(t)
+        return gp
+
+    def tensors(self):
+        return tuple(getattr(self, k) for k in self.NAMES)
+
+    def grad_views(self):
+        """Pre-allocated gradient outputs for ops.project_bwd(out=...)."""
+        return tuple(self.g[k] for k in self.NAMES)
+
+
+class FusedAdam:
+    """torch.optim.Adam semantics (no weight decay, no amsgrad) in one HIP launch (tgs_adam_step).
+
+    ``lrs`` keys: means, log_scales, quats, opac_logit, sh_dc, sh_rest (Splatfacto's groups,
+    SURVEY App. A.3).  ``grad_scale`` multiplies the gradient on the fly (e.g. 1/world_size after a
+    sum all-reduce).
+    """
+
+    def __init__(self, params: GaussianParams, lrs: Dict[str, float], betas=(0.9, 0.999), eps=1e-15):
+        self.p = params
+        self.lrs = dict(lrs)
+        self.betas, self.eps = betas, eps
+        self.exp_avg = torch.zeros_like(params.flat)
+        self.exp_avg_sq = torch.zeros_like(params.flat)
+        self.t = 0
+
+    def step(self, grad_scale: float = 1.0):
+        lib = _lib.load()
+        self.t += 1
+        s = _lib.TgsAdamSpec()
+        s.lr_means, s.lr_scales, s.lr_quats = self.lrs["means"], self.lrs["log_scales"], self.lrs["quats"]
+        s.lr_opac, s.lr_sh_dc, s.lr_sh_rest = self.lrs["opac_logit"], self.lrs["sh_dc"], self.lrs["sh_rest"]
+        s.beta1, s.beta2, s.eps = self.betas[0], self.betas[1], self.eps
+        s.bias_corr1 = 1.0 - self.betas[0] ** self.t
+        s.bias_corr2 = 1.0 - self.betas[1] ** self.t
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.tgs_adam_step(self.p.N, self.p.K, ptr(self.p.flat), ptr(self.p.grad), ptr(self.exp_avg),
+                                ptr(self.exp_avg_sq), C.byref(s), C.c_float(grad_scale), stream),
+              "tgs_adam_step")
+
+    def state_dict(self):
+        return dict(t=self.t, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lrs=self.lrs)
+
+    def load_state_dict(self, sd):
+        self.t = sd["t"]
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.lrs = dict(sd["lrs"])
