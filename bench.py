@@ -1,0 +1,231 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric on its config: train iters/s (+ render Mpix/s) of the full
+Touch-GS train step, 1 M synthetic Gaussians @ 1920x1080, SH degree 3, on N MI355X.
+
+One "step" per rank = project + bin/sort + RGB&depth compositing + SSIM + compositing backward with
+the fused L1 + tactile depth/uncertainty loss + projection backward + (N>1: RCCL all-reduce of the
+flat gradient buffer) + fused Adam.  Inputs are resident in HBM before the timed region.
+`value` = optimizer iterations/s x ranks = views/s of the whole job (weak scaling: one view per
+rank per iteration).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E vendor peak (MI355X_MICROARCH.md); ~6290 measured copy ceiling
+
+
+def algorithmic_bytes(N, I, P, T, K):
+    """Compulsory-traffic model of THIS build's data layout, bytes/step."""
+    A = 44 + 12 * K                      # parameter bytes per Gaussian
+    b = {}
+    b["project_fwd"] = N * (A + 48)
+    b["bin_sort"] = N * (16 + 4) + I * (4 + 4 + 8 + 8 + 4) + 12 * T   # rect read, rank w/r, pair w/r, id w
+    b["raster_fwd"] = I * (4 + 48) + P * 24 + 8 * T
+    b["ssim"] = P * (24 + 36 + 36 + 12 + 24)
+    b["raster_bwd"] = I * (4 + 48 + 48) + P * (24 + 12 + 28) + 8 * T
+    b["project_bwd"] = N * (A + 48 + A) + I * 48
+    b["adam"] = 28 * (A // 4) * N
+    return b
+
+
+def cpu_baseline(N, W, H, deg, seed, frac=16):
+    """Build's own scalar C restatement (oracle/ref_raster.c, fp32, OpenMP over tiles) timed on the
+    host cores: full projection / binning / projection-backward, compositing fwd+bwd on the first
+    1/frac of the tiles and extrapolated.  The reference's rasterizer source is unavailable."""
+    from oracle.ref_c import RefC
+    from oracle import torch_oracle as O
+    import numpy as np
+    R = RefC("f32")
+    P, c = O.synthetic_scene(N, W, H, deg, seed, dtype=torch.float32)
+    n = lambda t: t.numpy()
+    cam = R.cam_block(O.orbit_viewmat(0, 8).numpy(), c["fx"], c["fy"], c["cx"], c["cy"])
+    t0 = time.perf_counter()
+    pr = R.project_fwd(n(P["means"]), n(P["log_scales"]), n(P["quats"]), n(P["opac_logit"]), n(P["sh"]), deg, cam, W, H)
+    t1 = time.perf_counter()
+    gid, ts = R.bin_sort(pr["rect"], pr["tiles_hit"], pr["depth"], W, H)
+    t2 = time.perf_counter()
+    T = (len(ts) - 1)
+    tr = (0, max(T // frac, 1))
+    f = R.blend_fwd(pr["xy"], pr["conic"], pr["opac"], pr["rgb"], pr["depth"], gid, ts, cam, W, H, tile_range=tr)
+    t3 = time.perf_counter()
+    ones3 = np.ones((H, W, 3), np.float32)
+    ones1 = np.ones((H, W), np.float32)
+    b = R.blend_bwd(pr["xy"], pr["conic"], pr["opac"], pr["rgb"], pr["depth"], gid, ts, cam, W, H,
+                    f["final_T"], f["final_idx"], ones3, ones1, ones1, tile_range=tr)
+    t4 = time.perf_counter()
+    R.project_bwd(n(P["means"]), n(P["log_scales"]), n(P["quats"]), n(P["opac_logit"]), n(P["sh"]), deg, cam, W, H,
+                  pr["radius"], b["v_xy"], b["v_conic"], b["v_opac"], b["v_rgb"], b["v_depth"])
+    t5 = time.perf_counter()
+    scale = T / (tr[1] - tr[0])
+    est = (t1 - t0) + (t2 - t1) + (t3 - t2) * scale + (t4 - t3) * scale + (t5 - t4)
+    return dict(value=1.0 / est, unit="train iters/s (fwd+bwd, no SSIM/Adam)", cores=R.num_threads(), kind="port",
+                sample=(f"build's own C restatement of the published algorithm (oracle/ref_raster.c, fp32, OpenMP; "
+                        f"reference rasterizer source unavailable): full project/bin-sort/project-bwd + compositing "
+                        f"fwd+bwd on tiles [0,{tr[1]}) of {T}, extrapolated x{scale:.1f}; measured "
+                        f"{(t5 - t0):.1f} s CPU wall"),
+                seconds=dict(project=t1 - t0, bin_sort=t2 - t1, blend_fwd_sample=t3 - t2, blend_bwd_sample=t4 - t3,
+                             project_bwd=t5 - t4))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--seed", type=int, default=1236)  # cfg3 seed of SURVEY 8(d)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from touch_gs_amd import ops, parallel
+    from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
+    from touch_gs_amd.optim import GaussianParams
+    from touch_gs_amd.scene import make_view, synthetic_gaussians
+
+    dp = parallel.init_from_env()
+    if dp.world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={dp.world}; launch with torch.distributed.run")
+    dev = torch.device("cuda", dp.local_rank)
+    torch.cuda.set_device(dev)
+    N, W, H, deg = args.gaussians, args.width, args.height, args.sh_degree
+    K = (deg + 1) ** 2
+
+    # ---- setup (untimed): scene, replicas, views, intersection capacity ----
+    P, intr = synthetic_gaussians(N, W, H, deg, args.seed)
+    params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
+    cfg = ModelConfig(sh_degree=deg, sh_degree_interval=0, depth_loss_mult=0.2,
+                      depth_loss_type="DEPTH_UNCERTAINTY_WEIGHTED_LOSS", uncertainty_weight=1.0)
+    model = DepthGaussianSplattingModel(cfg, params)
+    views = [make_view(N, W, H, deg, args.seed, dev, view=v, n_views=args.views) for v in range(args.views)]
+    for v in views:
+        v.valid_count()
+    n_isect = []
+    for v in views:  # size the intersection buffers once; no host sync inside the timed region
+        sp = ops.project_fwd(v.cam, params.means, params.log_scales, params.quats, params.opac_logit, params.sh, deg)
+        b = ops.IntersectBudget()
+        ops.bin_sort(v.cam, sp, b)
+        n_isect.append(b.last_n)
+    model.budget = ops.IntersectBudget(capacity=int(max(n_isect) * 1.25) + 4096, sync=False)
+    del sp
+    torch.cuda.empty_cache()
+
+    def step(i):
+        model.train_step(views[dp.views_for_step(i, len(views))], dp if dp.world > 1 else None)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    dp.barrier()
+    torch.cuda.synchronize()
+    elapsed = dp.max_over_ranks(time.perf_counter() - t0)
+    model.budget.check()  # raises if any timed frame overflowed its intersection buffer
+    ms_per_step = elapsed / args.steps * 1e3
+    value = args.steps * dp.world / elapsed
+
+    # ---- per-kernel timing of the same step (HIP events on the launch stream), rank 0 ----
+    out = None
+    if dp.rank == 0:
+        view = views[0]
+        I = n_isect[0]
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+        names = ["project_fwd", "bin_sort", "raster_fwd", "ssim", "raster_bwd", "project_bwd", "adam"]
+        acc = {k: 0.0 for k in names}
+        reps = min(args.steps, 20)
+        p = params
+        for _ in range(reps):
+            e = [ev() for _ in range(8)]
+            e[0].record()
+            sp = ops.project_fwd(view.cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg)
+            e[1].record()
+            gb, ts, sg, _ = ops.bin_sort(view.cam, sp, model.budget)
+            e[2].record()
+            rgb, dacc, fT, fidx = ops.rasterize_fwd(view.cam, sp, sg, ts)
+            e[3].record()
+            ssim_sum, v_img = ops.ssim_fwd_bwd(rgb, view.rgb, weight=-cfg.ssim_lambda / (3 * H * W))
+            e[4].record()
+            partials, tl = ops.rasterize_bwd(view.cam, sp, gb, sg, ts, rgb, dacc, fT, fidx, v_rgb=v_img,
+                                             loss=model.loss_spec(view), want_tile_loss=True)
+            e[5].record()
+            ops.project_bwd(view.cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, sp, gb, partials,
+                            out=p.grad_views())
+            e[6].record()
+            p.grad.zero_()  # keep the scene fixed while profiling
+            e[7].record()
+            model.optimizer.step()
+            e7b = ev(); e7b.record()
+            torch.cuda.synchronize()
+            for j, k in enumerate(names[:6]):
+                acc[k] += e[j].elapsed_time(e[j + 1])
+            acc["adam"] += e[7].elapsed_time(e7b)
+        kern_ms = {k: v / reps for k, v in acc.items()}
+        # render-only throughput (K1..K6)
+        torch.cuda.synchronize()
+        r0 = time.perf_counter()
+        rr = 20
+        for _ in range(rr):
+            sp = ops.project_fwd(view.cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg)
+            gb, ts, sg, _ = ops.bin_sort(view.cam, sp, model.budget)
+            ops.rasterize_fwd(view.cam, sp, sg, ts)
+        torch.cuda.synchronize()
+        render_ms = (time.perf_counter() - r0) / rr * 1e3
+
+        T = view.cam.num_tiles
+        ab = algorithmic_bytes(N, I, W * H, T, K)
+        dom = max(kern_ms, key=kern_ms.get)
+        achieved = ab[dom] / (kern_ms[dom] * 1e-3) / 1e9
+        step_bytes = sum(ab.values())
+        out = {
+            "metric": "train iters/s (whole-job views/s) + render Mpix/s, 1M Gaussians @ 1080p",
+            "value": round(value, 3), "unit": "iters/s",
+            "n_gpus": dp.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "render_mpix_s": round(W * H / (render_ms * 1e-3) / 1e6, 1),
+            "config": {"workload": "configs[2]: 1M Gaussians, 1080p, full Touch-GS train loop "
+                                   "(RGB L1/SSIM + tactile depth/uncertainty loss), one view per rank per iter",
+                       "gaussians": N, "width": W, "height": H, "sh_degree": deg, "views": args.views,
+                       "intersections": I, "tiles": T, "parallelism": f"dp{dp.world}",
+                       "depth_loss_type": cfg.depth_loss_type},
+            "kernel_ms": {k: round(v, 4) for k, v in kern_ms.items()},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes": ab[dom]},
+            "step_roofline": {"algorithmic_bytes": step_bytes,
+                              "achieved_GBs": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                              "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "fwd_bwd_ms": round(sum(kern_ms[k] for k in names[:6] if k != "ssim"), 4)},
+        }
+        if dp.world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(N, W, H, deg, args.seed)
+            except Exception as ex:  # the oracle is test infrastructure; never fail the bench on it
+                out["cpu_baseline"] = {"value": None, "error": repr(ex)}
+        print(json.dumps(out), flush=True)
+    dp.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -66,20 +66,25 @@ class RefC:
                               C.c_int(TW), C.c_int(TH), self._p(gid), self._p(ts))
         return gid[:I], ts
 
-    def blend_fwd(self, xy, conic, opac, rgb, depth, gid, ts, cam, W, H):
+    def num_threads(self):
+        return int(self.lib.ref_num_threads())
+
+    def blend_fwd(self, xy, conic, opac, rgb, depth, gid, ts, cam, W, H, tile_range=None):
         xy, conic, opac, rgb, depth = map(self._r, (xy, conic, opac, rgb, depth))
         gid = np.ascontiguousarray(gid, np.int32)
         ts = np.ascontiguousarray(ts, np.int64)
         o = dict(rgb=np.zeros((H, W, 3), self.dt), depth_acc=np.zeros((H, W), self.dt),
                  final_T=np.zeros((H, W), self.dt), final_idx=np.zeros((H, W), np.int32))
-        self.lib.ref_blend_fwd(self._p(xy), self._p(conic), self._p(opac), self._p(rgb), self._p(depth),
-                               self._p(gid), self._p(ts), self._p(cam), C.c_int(W), C.c_int(H),
-                               self._p(o["rgb"]), self._p(o["depth_acc"]), self._p(o["final_T"]), self._p(o["final_idx"]))
+        t0, t1 = tile_range if tile_range is not None else (0, ((W + 15) // 16) * ((H + 15) // 16))
+        self.lib.ref_blend_fwd_range(self._p(xy), self._p(conic), self._p(opac), self._p(rgb), self._p(depth),
+                                     self._p(gid), self._p(ts), self._p(cam), C.c_int(W), C.c_int(H),
+                                     self._p(o["rgb"]), self._p(o["depth_acc"]), self._p(o["final_T"]),
+                                     self._p(o["final_idx"]), C.c_int(t0), C.c_int(t1))
         o["alpha"] = 1 - o["final_T"]
         return o
 
     def blend_bwd(self, xy, conic, opac, rgb, depth, gid, ts, cam, W, H, final_T, final_idx,
-                  v_rgb_img, v_depth_img, v_alpha_img):
+                  v_rgb_img, v_depth_img, v_alpha_img, tile_range=None):
         xy, conic, opac, rgb, depth, final_T, v_rgb_img, v_depth_img, v_alpha_img = map(
             self._r, (xy, conic, opac, rgb, depth, final_T, v_rgb_img, v_depth_img, v_alpha_img))
         gid = np.ascontiguousarray(gid, np.int32)
@@ -88,11 +93,13 @@ class RefC:
         N = xy.shape[0]
         o = dict(v_xy=np.zeros((N, 2), self.dt), v_conic=np.zeros((N, 3), self.dt), v_opac=np.zeros(N, self.dt),
                  v_rgb=np.zeros((N, 3), self.dt), v_depth=np.zeros(N, self.dt))
-        self.lib.ref_blend_bwd(self._p(xy), self._p(conic), self._p(opac), self._p(rgb), self._p(depth),
-                               self._p(gid), self._p(ts), self._p(cam), C.c_int(W), C.c_int(H),
-                               self._p(final_T), self._p(final_idx),
-                               self._p(v_rgb_img), self._p(v_depth_img), self._p(v_alpha_img),
-                               *[self._p(o[k]) for k in ("v_xy", "v_conic", "v_opac", "v_rgb", "v_depth")])
+        t0, t1 = tile_range if tile_range is not None else (0, ((W + 15) // 16) * ((H + 15) // 16))
+        self.lib.ref_blend_bwd_range(self._p(xy), self._p(conic), self._p(opac), self._p(rgb), self._p(depth),
+                                     self._p(gid), self._p(ts), self._p(cam), C.c_int(W), C.c_int(H),
+                                     self._p(final_T), self._p(final_idx),
+                                     self._p(v_rgb_img), self._p(v_depth_img), self._p(v_alpha_img),
+                                     *[self._p(o[k]) for k in ("v_xy", "v_conic", "v_opac", "v_rgb", "v_depth")],
+                                     C.c_int(t0), C.c_int(t1))
         return o
 
     def project_bwd(self, means, log_scales, quats, opac_logit, sh, sh_deg, cam, W, H, radius,

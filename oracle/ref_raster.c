@@ -214,12 +214,12 @@ void ref_bin_sort(int N, const int32_t *rect, const int32_t *tiles_hit, const fl
 }
 
 /* B.6 forward blend.  Images row-major: rgb [H,W,3] (incl. bg), depth_acc/final_T [H,W], final_idx int32 [H,W]. */
-void ref_blend_fwd(const real *xy, const real *conic, const real *opac, const real *rgb, const real *depth,
+void ref_blend_fwd_range(const real *xy, const real *conic, const real *opac, const real *rgb, const real *depth,
                    const int32_t *sorted_gid, const int64_t *tile_start, const cam_t *cam, int W, int H,
-                   real *o_rgb, real *o_depth, real *o_T, int32_t *o_idx) {
-    int TW = (W + BLK - 1) / BLK, TH = (H + BLK - 1) / BLK;
+                   real *o_rgb, real *o_depth, real *o_T, int32_t *o_idx, int t0, int t1) {
+    int TW = (W + BLK - 1) / BLK;
 #pragma omp parallel for schedule(dynamic, 4)
-    for (int t = 0; t < TW * TH; t++) {
+    for (int t = t0; t < t1; t++) {
         int ty = t / TW, tx = t % TW;
         int64_t s = tile_start[t], e = tile_start[t + 1];
         for (int py = ty * BLK; py < (ty + 1) * BLK && py < H; py++)
@@ -246,16 +246,23 @@ void ref_blend_fwd(const real *xy, const real *conic, const real *opac, const re
     }
 }
 
+void ref_blend_fwd(const real *xy, const real *conic, const real *opac, const real *rgb, const real *depth,
+                   const int32_t *sorted_gid, const int64_t *tile_start, const cam_t *cam, int W, int H,
+                   real *o_rgb, real *o_depth, real *o_T, int32_t *o_idx) {
+    int TW = (W + BLK - 1) / BLK, TH = (H + BLK - 1) / BLK;
+    ref_blend_fwd_range(xy, conic, opac, rgb, depth, sorted_gid, tile_start, cam, W, H, o_rgb, o_depth, o_T, o_idx, 0, TW * TH);
+}
+
 /* B.7 backward blend.  v_rgb_img [H,W,3], v_depth_img [H,W] (w.r.t. depth_acc), v_alpha_img [H,W].
  * Accumulates (+=) into v_xy [N,2], v_conic [N,3], v_opac [N], v_rgb [N,3], v_depth [N] (caller zeroes). */
-void ref_blend_bwd(const real *xy, const real *conic, const real *opac, const real *rgb, const real *depth,
+void ref_blend_bwd_range(const real *xy, const real *conic, const real *opac, const real *rgb, const real *depth,
                    const int32_t *sorted_gid, const int64_t *tile_start, const cam_t *cam, int W, int H,
                    const real *f_T, const int32_t *f_idx,
                    const real *v_rgb_img, const real *v_depth_img, const real *v_alpha_img,
-                   real *v_xy, real *v_conic, real *v_opac, real *v_rgb, real *v_depth) {
-    int TW = (W + BLK - 1) / BLK, TH = (H + BLK - 1) / BLK;
+                   real *v_xy, real *v_conic, real *v_opac, real *v_rgb, real *v_depth, int t0, int t1) {
+    int TW = (W + BLK - 1) / BLK;
 #pragma omp parallel for schedule(dynamic, 4)
-    for (int t = 0; t < TW * TH; t++) {
+    for (int t = t0; t < t1; t++) {
         int ty = t / TW, tx = t % TW;
         int64_t s = tile_start[t];
         for (int py = ty * BLK; py < (ty + 1) * BLK && py < H; py++)
@@ -307,6 +314,16 @@ void ref_blend_bwd(const real *xy, const real *conic, const real *opac, const re
                 }
             }
     }
+}
+
+void ref_blend_bwd(const real *xy, const real *conic, const real *opac, const real *rgb, const real *depth,
+                   const int32_t *sorted_gid, const int64_t *tile_start, const cam_t *cam, int W, int H,
+                   const real *f_T, const int32_t *f_idx,
+                   const real *v_rgb_img, const real *v_depth_img, const real *v_alpha_img,
+                   real *v_xy, real *v_conic, real *v_opac, real *v_rgb, real *v_depth) {
+    int TW = (W + BLK - 1) / BLK, TH = (H + BLK - 1) / BLK;
+    ref_blend_bwd_range(xy, conic, opac, rgb, depth, sorted_gid, tile_start, cam, W, H, f_T, f_idx,
+                        v_rgb_img, v_depth_img, v_alpha_img, v_xy, v_conic, v_opac, v_rgb, v_depth, 0, TW * TH);
 }
 
 /* B.8 projection + SH backward.  Inputs: per-Gaussian v_xy, v_conic, v_opac, v_rgb, v_depth.
@@ -450,3 +467,9 @@ void ref_project_bwd(int N, const real *means, const real *log_scales, const rea
 }
 
 int ref_real_bytes(void) { return (int)sizeof(real); }
+#ifdef _OPENMP
+#include <omp.h>
+int ref_num_threads(void) { return omp_get_max_threads(); }
+#else
+int ref_num_threads(void) { return 1; }
+#endif

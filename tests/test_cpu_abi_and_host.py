@@ -1,0 +1,162 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/tgs.h declares; argument
+validation (no GPU work is launched); host-side logic (layouts, split rule, cameras, DP)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "tgs.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(tgs_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from touch_gs_amd import _lib
+    lib = _lib.load()
+    syms = _declared_symbols()
+    assert len(syms) >= 12
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/tgs.h but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in touch_gs_amd/_lib.py"
+    assert set(_lib.SIGNATURES) == set(syms)
+    assert lib.tgs_version() == 100
+
+
+def test_struct_layouts_match_header():
+    from touch_gs_amd import _lib
+    assert C.sizeof(_lib.TgsCamera) == 16 * 4 + 4 * 4 + 2 * 4 + 2 * 4 + 3 * 4 + 4
+    assert C.sizeof(_lib.TgsAdamSpec) == 11 * 4
+    assert C.sizeof(_lib.TgsLossSpec) == 3 * 8 + 4 * 4
+
+
+def test_argument_validation_without_gpu():
+    from touch_gs_amd import _lib
+    lib = _lib.load()
+    assert lib.tgs_num_groups(1000) == 4 and lib.tgs_num_groups(0) == 0
+    assert lib.tgs_num_tiles(1920, 1080) == 120 * 68
+    assert lib.tgs_sort_scratch_bytes(1000) >= 28 * 1000
+    cam = _lib.TgsCamera()  # W = H = 0 -> invalid
+    rc = lib.tgs_project_fwd(C.byref(cam), 10, None, None, None, None, None, 0, -1, None, None, None)
+    assert rc == -1 and b"camera" in lib.tgs_last_error()
+    cam.W, cam.H, cam.fx, cam.fy = 64, 64, 50.0, 50.0
+    rc = lib.tgs_project_fwd(C.byref(cam), 10, None, None, None, None, None, 0, -1, None, None, None)
+    assert rc == -1 and b"null" in lib.tgs_last_error()
+    assert lib.tgs_project_fwd(C.byref(cam), 0, None, None, None, None, None, 0, -1, None, None, None) == 0
+    with pytest.raises(RuntimeError):
+        _lib.check(rc, "x")
+    with pytest.raises(RuntimeError):  # CPU tensors are rejected: there is no CPU path
+        _lib.ptr(torch.zeros(4))
+
+
+def test_ops_refuse_cpu_tensors():
+    from touch_gs_amd import Camera, ops
+    cam = Camera(np.eye(4), 50, 50, 32, 32, 64, 64)
+    z = torch.zeros(4, 3)
+    with pytest.raises(RuntimeError):
+        ops.project_fwd(cam, z, z, torch.zeros(4, 4), torch.zeros(4), None, -1)
+
+
+def test_param_layout_alignment():
+    from touch_gs_amd.optim import GaussianParams, layout
+    for N in (1, 2, 3, 5, 1000, 1001):
+        L = layout(N, 16)
+        for k in GaussianParams.NAMES:
+            assert L[k][0] % 4 == 0
+        assert L["total"] % 4 == 0 and L["total"] >= 59 * N
+    gp = GaussianParams.allocate(5, 4, "cpu")
+    gp.quats.fill_(2.0)
+    assert float(gp.flat.sum()) == 40.0
+    assert gp.g["sh"].shape == (5, 4, 3)
+
+
+def test_split_rule_matches_reference_goldens():
+    """Goldens captured from the reference's utils/create_point_cloud_from_touches.py:174-198
+    (SURVEY 8b): n=151,f=0.08 -> 13 idx starting [0,11,23,34,46]; n=100,f=0.13 -> 13; n=40,f=0.8 -> 32."""
+    from touch_gs_amd.parallel import split_train_indices
+    tr, ev = split_train_indices(151, 0.08)
+    assert len(tr) == 13 and tr[:5] == [0, 11, 23, 34, 46] and len(ev) == 138
+    assert len(split_train_indices(100, 0.13)[0]) == 13
+    assert len(split_train_indices(40, 0.8)[0]) == 32
+
+
+def test_camera_opengl_conversion():
+    from touch_gs_amd import Camera
+    c2w = np.eye(4)
+    c2w[:3, 3] = [1.0, 2.0, 3.0]
+    cam = Camera.from_c2w_opengl(c2w, 100, 100, 50, 50, 100, 100)
+    # a point one unit in front of an OpenGL camera (-z) has OpenCV depth +1
+    p = np.array([1.0, 2.0, 2.0, 1.0])
+    assert np.allclose(cam.viewmat @ p, [0, 0, 1, 1])
+    cs = cam.c_struct()
+    assert cs.W == 100 and abs(cs.viewmat[11] - cam.viewmat[2, 3]) < 1e-6
+
+
+def test_scene_generator_matches_oracle_recipe():
+    from oracle import torch_oracle as O
+    from touch_gs_amd.scene import orbit_viewmat, synthetic_gaussians
+    P, intr = synthetic_gaussians(500, 160, 96, 3, 1236)
+    Po, c = O.synthetic_scene(500, 160, 96, 3, 1236)
+    for k in P:
+        assert torch.allclose(P[k].double(), Po[k], atol=1e-6), k
+    assert abs(intr["fx"] - c["fx"]) < 1e-9
+    assert np.allclose(orbit_viewmat(3, 8), O.orbit_viewmat(3, 8).numpy())
+
+
+def test_intersect_budget_logic():
+    from touch_gs_amd.ops import IntersectBudget
+    b = IntersectBudget()
+    assert b.initial(1000) == max(8 * 1000, 1 << 16)
+    b = IntersectBudget(capacity=123, sync=False)
+    assert b.initial(10) == 123 and b.check() is None
+    b.last_status = torch.tensor([500, 1], dtype=torch.int32)
+    with pytest.raises(RuntimeError):
+        b.check()
+
+
+_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from touch_gs_amd import parallel
+dp = parallel.init_from_env(backend="gloo")
+assert dist.is_initialized() and dp.world == 2
+torch.manual_seed(0)
+params = torch.randn(1000)                       # identical replicas
+m = torch.zeros(1000); v = torch.zeros(1000)
+seen = []
+for step in range(4):
+    view = dp.views_for_step(step, 8)
+    seen.append(view)
+    g = torch.full((1000,), float(view + 1))      # "gradient of view"
+    scale = dp.all_reduce_(g)
+    g = g * scale
+    expect = (2 * step * 2 + 1 + 2) / 2.0         # mean of (2s+1) and (2s+2)
+    assert torch.allclose(g, torch.full((1000,), expect)), (g[0].item(), expect)
+    m = 0.9 * m + 0.1 * g; v = 0.999 * v + 0.001 * g * g
+    params = params - 1e-3 * m / (v.sqrt() + 1e-15)
+    dp.assert_replicas_identical(params)
+assert seen == [(s * 2 + dp.rank) % 8 for s in range(4)]
+assert dp.max_over_ranks(float(dp.rank)) == 1.0
+dp.barrier()
+if dp.rank == 0: print("GLOO_OK", dp.bytes_per_step)
+'''
+
+
+def test_data_parallel_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29611", str(script), ROOT],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "GLOO_OK 4000" in r.stdout

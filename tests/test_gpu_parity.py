@@ -37,9 +37,11 @@ def test_project_fwd(dev, N, W, H, deg, seed):
     assert same.float().mean() > 0.995, f"radius mismatch fraction {1 - same.float().mean():.4f}"
     both = v & same & (f["radius"] > 0)
     assert both.sum() > 0.5 * v.sum()
-    for k in ("xy", "conic", "rgb"):
+    for k in ("conic", "rgb"):
         e = relerr(f[k][both], pr[k][both], floor=1e-3)
         assert e.max() < TOL, (k, e.max())
+    # pixel coordinates: 1e-4 relative to the image scale (fp32 ulp at 2000 px is already 1.2e-4 px)
+    assert relerr(f["xy"][both], pr["xy"][both], floor=float(max(W, H))).max() < 1e-5
     assert relerr(f["depth"][both], pr["depth"][both]).max() < 1e-5
     assert relerr(f["opac"], pr["opac"]).max() < 1e-5
     assert relerr(f["rgb"], pr["rgb"], floor=1e-3).max() < TOL  # colour defined for every Gaussian
@@ -329,7 +331,7 @@ def test_adam_matches_torch(dev):
         opt.step()
     got = [gp.means, gp.log_scales, gp.quats, gp.opac_logit, gp.sh[:, :1], gp.sh[:, 1:]]
     for a, b in zip(got, ref_p):
-        assert torch.allclose(a, b.detach(), rtol=1e-5, atol=1e-7)
+        assert torch.allclose(a, b.detach(), rtol=2e-5, atol=2e-6)
 
 
 @pytest.mark.parametrize("W,H", [(64, 48), (100, 70), (33, 17)])
@@ -345,3 +347,27 @@ def test_ssim_fwd_bwd(dev, W, H):
     assert abs(tot.item() / (3 * H * W) - s.item()) < 1e-5
     scale = a.grad.abs().max().item()
     assert (v.cpu().double() - a.grad).abs().max().item() < 1e-4 * scale
+
+
+def test_selforacle_fixtures_gpu(dev):
+    """HIP pipeline against the committed known-answer fixtures (tests/golden/raster_selforacle.npz)."""
+    import os
+    from touch_gs_amd import Camera, ops
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "raster_selforacle.npz"))
+    for name in ("one", "seven", "two_hundred"):
+        N, W, H, deg, seed = [int(v) for v in z[f"{name}/meta"]]
+        fx, fy, cx, cy = z[f"{name}/intr"]
+        cam = Camera(z[f"{name}/viewmat"], fx, fy, cx, cy, W, H, bg=tuple(z[f"{name}/bg"]))
+        D = {k: torch.from_numpy(z[f"{name}/in/{k}"]).float().to(dev).requires_grad_(True)
+             for k in ("means", "log_scales", "quats", "opac_logit", "sh")}
+        rgb, depth, alpha, _ = ops.render(D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], cam, deg)
+        for got, k in ((rgb, "rgb"), (depth, "depth_acc"), (alpha, "alpha")):
+            e = relerr(got.detach().cpu().numpy(), z[f"{name}/out/{k}"], floor=1e-2)
+            assert np.quantile(e, 0.995) < TOL, (name, k, np.quantile(e, 0.995))
+        w = lambda k: torch.from_numpy(z[f"{name}/{k}"]).float().to(dev)
+        ((rgb * w("w_rgb")).sum() + (depth * w("w_depth")).sum() + (alpha * w("w_alpha")).sum()).backward()
+        for k in D:
+            ref = z[f"{name}/grad/{k}"]
+            got = D[k].grad.cpu().double().numpy()
+            cos = (ref * got).sum() / max(np.sqrt((ref * ref).sum() * (got * got).sum()), 1e-30)
+            assert cos > 0.9999, (name, k, cos)

@@ -1,0 +1,242 @@
+"""Splatfacto-style Gaussian model for the ``depth-gaussian-splatting`` method of Touch-GS.
+
+The reference trains through ``ns-train depth-gaussian-splatting --pipeline.model.depth-loss-mult ..
+--pipeline.model.depth-loss-type {DEPTH_UNCERTAINTY_WEIGHTED_LOSS,SIMPLE_LOSS}
+--pipeline.model.uncertainty_weight ..`` (reference scripts/train_bunny_real.sh:52,
+train_block_data.sh:50, train_bunny_blender.sh:50); the model class itself lives in an absent
+submodule, so the method surface mirrors the in-tree nerfstudio plugin evidence
+(legacy/model_tactile.py:68,77,103,138,192: populate_modules / get_outputs / get_metrics_dict /
+get_loss_dict / get_image_metrics_and_images) and the loss follows SURVEY section 8 row a11.
+
+Two execution paths over the same kernels:
+* ``get_outputs`` + ``get_loss_dict`` -- autograd path (ops.render is a torch.autograd.Function);
+* ``train_step``                      -- fused path: forward, SSIM, compositing backward with the
+  L1 + tactile depth/uncertainty loss evaluated in-kernel, projection backward straight into the
+  flat gradient buffer, optional RCCL all-reduce, fused Adam.  No autograd graph, no host sync.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .camera import Camera
+from .optim import FusedAdam, GaussianParams
+
+DEPTH_LOSS_TYPES = ("DEPTH_UNCERTAINTY_WEIGHTED_LOSS", "SIMPLE_LOSS")
+
+
+@dataclasses.dataclass
+class ModelConfig:
+    """Flag names follow the reference's tyro flags (scripts/train_*.sh) and Splatfacto defaults
+    (SURVEY App. A.3)."""
+    sh_degree: int = 3
+    ssim_lambda: float = 0.2
+    depth_loss_mult: float = 0.2          # scripts/train_block_data.sh:50
+    depth_loss_type: str = "DEPTH_UNCERTAINTY_WEIGHTED_LOSS"
+    uncertainty_weight: float = 1.0
+    depth_eps: float = 1e-6
+    sh_degree_interval: int = 1000
+    background_color: tuple = (0.0, 0.0, 0.0)
+    # Adam learning rates per group (Splatfacto defaults)
+    lr_means: float = 1.6e-4
+    lr_scales: float = 5e-3
+    lr_quats: float = 1e-3
+    lr_opac: float = 5e-2
+    lr_sh_dc: float = 2.5e-3
+    lr_sh_rest: float = 1.25e-4
+
+    def lrs(self) -> Dict[str, float]:
+        return dict(means=self.lr_means, log_scales=self.lr_scales, quats=self.lr_quats,
+                    opac_logit=self.lr_opac, sh_dc=self.lr_sh_dc, sh_rest=self.lr_sh_rest)
+
+
+@dataclasses.dataclass
+class View:
+    """One training view: camera + supervision images on the device.
+
+    ``depth`` (metres x dataparser scale, 0 = unsupervised) and ``uncertainty`` are what the
+    reference's plumbing writes as 16-bit mm PNGs (utils/fuse_touch_vision.py:372-376) and
+    registers in transforms.json (utils/add_depth_file_path_to_transforms.py:37-50).
+    """
+    cam: Camera
+    rgb: torch.Tensor                      # [H,W,3] in [0,1]
+    depth: Optional[torch.Tensor] = None   # [H,W]
+    uncertainty: Optional[torch.Tensor] = None  # [H,W]
+    n_valid_depth: Optional[int] = None    # cached count of depth>0 (dataset constant)
+
+    def valid_count(self) -> int:
+        if self.n_valid_depth is None:
+            self.n_valid_depth = int((self.depth > 0).sum().item()) if self.depth is not None else 0
+        return self.n_valid_depth
+
+
+class DepthGaussianSplattingModel:
+    """The trainable scene: flat SoA parameters + the render/loss/step methods."""
+
+    def __init__(self, config: ModelConfig, params: GaussianParams):
+        self.config = config
+        self.params = params
+        self.step = 0
+        self.populate_modules()
+
+    # -- nerfstudio Model surface -------------------------------------------------------------
+    def populate_modules(self):
+        self.optimizer = FusedAdam(self.params, self.config.lrs())
+        self.budget = ops.IntersectBudget()
+        self.last = {}
+
+    @property
+    def num_points(self) -> int:
+        return self.params.N
+
+    def active_sh_degree(self) -> int:
+        c = self.config
+        max_deg = int(round(math.sqrt(self.params.K))) - 1
+        if c.sh_degree_interval <= 0:
+            return min(c.sh_degree, max_deg)
+        return min(self.step // c.sh_degree_interval, c.sh_degree, max_deg)
+
+    def get_outputs(self, cam: Camera, sh_degree: Optional[int] = None) -> Dict[str, torch.Tensor]:
+        """Camera -> {rgb, depth, accumulation} (differentiable; autograd path)."""
+        p = self.params
+        deg = self.active_sh_degree() if sh_degree is None else sh_degree
+        rgb, depth_acc, alpha, radii = ops.render(p.means, p.log_scales, p.quats, p.opac_logit, p.sh,
+                                                  cam, deg, budget=self.budget)
+        depth = depth_acc / torch.clamp(alpha, min=1e-10)
+        return dict(rgb=rgb, depth=depth[..., None], accumulation=alpha[..., None],
+                    depth_acc=depth_acc, alpha=alpha, radii=radii)
+
+    def depth_loss(self, depth_acc, alpha, view: View) -> torch.Tensor:
+        """mean over valid (D_gt > 0) of (D_hat - D_gt)^2 [ / (uw * U + eps) ]."""
+        c = self.config
+        if c.depth_loss_type not in DEPTH_LOSS_TYPES:
+            raise ValueError(c.depth_loss_type)
+        m = view.depth > 0
+        cnt = m.sum()
+        dhat = depth_acc / torch.clamp(alpha, min=1e-10)
+        r2 = (dhat - view.depth) ** 2
+        if c.depth_loss_type == "DEPTH_UNCERTAINTY_WEIGHTED_LOSS":
+            r2 = r2 / (c.uncertainty_weight * view.uncertainty + c.depth_eps)
+        return torch.where(m, r2, torch.zeros_like(r2)).sum() / torch.clamp(cnt, min=1)
+
+    def get_loss_dict(self, outputs, view: View) -> Dict[str, torch.Tensor]:
+        c = self.config
+        H, W = view.rgb.shape[:2]
+        l1 = (outputs["rgb"] - view.rgb).abs().mean()
+        loss = {"main_loss": (1 - c.ssim_lambda) * l1}
+        if c.ssim_lambda > 0:
+            loss["main_loss"] = loss["main_loss"] + c.ssim_lambda * (1 - _SSIM.apply(outputs["rgb"], view.rgb))
+        if c.depth_loss_mult > 0 and view.depth is not None:
+            loss["depth_loss"] = c.depth_loss_mult * self.depth_loss(outputs["depth_acc"], outputs["alpha"], view)
+        return loss
+
+    @torch.no_grad()
+    def get_metrics_dict(self, outputs, view: View) -> Dict[str, torch.Tensor]:
+        mse = ((outputs["rgb"] - view.rgb) ** 2).mean()
+        m = {"psnr": -10.0 * torch.log10(mse), "gaussian_count": torch.tensor(self.num_points)}
+        if view.depth is not None:
+            valid = view.depth > 0
+            d = outputs["depth"][..., 0]
+            m["depth_mse"] = ((d - view.depth)[valid] ** 2).mean() if valid.any() else torch.tensor(0.0)
+        return m
+
+    @torch.no_grad()
+    def get_image_metrics_and_images(self, outputs, view: View):
+        """Eval metrics with the key names the reference aggregates
+        (experiment_utils/get_results.py:35-52); lpips needs pretrained weights and is omitted."""
+        mse = ((outputs["rgb"] - view.rgb) ** 2).mean()
+        ssim_sum, _ = ops.ssim_fwd_bwd(outputs["rgb"], view.rgb, want_grad=False)
+        H, W = view.rgb.shape[:2]
+        metrics = {"psnr": float(-10.0 * torch.log10(mse)), "ssim": float(ssim_sum) / (3 * H * W)}
+        if view.depth is not None:
+            valid = view.depth > 0
+            d = outputs["depth"][..., 0]
+            metrics["depth_mse"] = float(((d - view.depth)[valid] ** 2).mean()) if valid.any() else 0.0
+            metrics["supervised_depth_mse"] = metrics["depth_mse"]
+        images = {"img": torch.cat([view.rgb, outputs["rgb"]], dim=1),
+                  "depth": outputs["depth"], "accumulation": outputs["accumulation"]}
+        return metrics, images
+
+    # -- fused train step ---------------------------------------------------------------------
+    def loss_spec(self, view: View) -> dict:
+        c = self.config
+        H, W = view.rgb.shape[:2]
+        spec = dict(gt_rgb=view.rgb, l1_weight=(1 - c.ssim_lambda) / (3 * H * W))
+        if c.depth_loss_mult > 0 and view.depth is not None:
+            if c.depth_loss_type not in DEPTH_LOSS_TYPES:
+                raise ValueError(c.depth_loss_type)
+            cnt = max(view.valid_count(), 1)
+            spec.update(gt_depth=view.depth, depth_weight=c.depth_loss_mult / cnt,
+                        uncertainty=view.uncertainty if c.depth_loss_type == "DEPTH_UNCERTAINTY_WEIGHTED_LOSS" else None,
+                        uncertainty_weight=c.uncertainty_weight, eps=c.depth_eps)
+        return spec
+
+    def forward_backward(self, view: View, want_v_xy: bool = False):
+        """Forward + loss + backward of one view into ``params.grad`` (overwritten).  No host sync
+        unless ``budget.sync``.  Returns device tensors (l1+depth tile losses, ssim sum)."""
+        p, c, cam = self.params, self.config, view.cam
+        deg = self.active_sh_degree()
+        H, W = cam.H, cam.W
+        splats = ops.project_fwd(cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg)
+        group_base, tile_start, sorted_gid, _ = ops.bin_sort(cam, splats, self.budget)
+        rgb, depth_acc, fT, fidx = ops.rasterize_fwd(cam, splats, sorted_gid, tile_start)
+        v_img, ssim_sum = None, None
+        if c.ssim_lambda > 0:
+            ssim_sum, v_img = ops.ssim_fwd_bwd(rgb, view.rgb, weight=-c.ssim_lambda / (3 * H * W))
+        partials, tile_loss = ops.rasterize_bwd(cam, splats, group_base, sorted_gid, tile_start, rgb,
+                                                depth_acc, fT, fidx, v_rgb=v_img,
+                                                loss=self.loss_spec(view), want_tile_loss=True)
+        out = ops.project_bwd(cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, splats,
+                              group_base, partials, out=p.grad_views(), want_v_xy=want_v_xy)
+        self.last = dict(rgb=rgb, depth_acc=depth_acc, final_T=fT, splats=splats, v_xy=out[5],
+                         tile_loss=tile_loss, ssim_sum=ssim_sum)
+        return tile_loss, ssim_sum
+
+    def loss_from(self, tile_loss, ssim_sum, view: View) -> Dict[str, torch.Tensor]:
+        c = self.config
+        H, W = view.rgb.shape[:2]
+        t = tile_loss.sum(0)
+        main = t[0]
+        if ssim_sum is not None:
+            main = main + c.ssim_lambda * (1 - ssim_sum / (3 * H * W))
+        return {"main_loss": main, "depth_loss": t[1]}
+
+    def train_step(self, view: View, dp=None) -> None:
+        """One optimizer iteration on one view (per rank).  ``dp``: a parallel.GradSync or None."""
+        self.forward_backward(view)
+        scale = 1.0
+        if dp is not None:
+            scale = dp.all_reduce_(self.params.grad)
+        self.optimizer.step(grad_scale=scale)
+        self.step += 1
+
+    # -- checkpoint -----------------------------------------------------------------------------
+    def state_dict(self):
+        return dict(flat=self.params.flat, N=self.params.N, K=self.params.K, step=self.step,
+                    optim=self.optimizer.state_dict(), config=dataclasses.asdict(self.config))
+
+    def load_state_dict(self, sd):
+        assert sd["N"] == self.params.N and sd["K"] == self.params.K
+        self.params.flat.copy_(sd["flat"])
+        self.step = sd["step"]
+        self.optimizer.load_state_dict(sd["optim"])
+
+
+class _SSIM(torch.autograd.Function):
+    """Mean SSIM through the K10 kernel, differentiable w.r.t. the rendered image."""
+
+    @staticmethod
+    def forward(ctx, img, gt):
+        H, W = img.shape[:2]
+        tot, v = ops.ssim_fwd_bwd(img.contiguous(), gt.contiguous(), weight=1.0 / (3 * H * W))
+        ctx.save_for_backward(v)
+        return tot / (3 * H * W)
+
+    @staticmethod
+    def backward(ctx, g):
+        (v,) = ctx.saved_tensors
+        return v * g, None

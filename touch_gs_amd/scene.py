@@ -1,0 +1,85 @@
+"""Synthetic scene S(N, W, H, deg, seed) of SURVEY section 8(d) -- the workload bench.py measures.
+
+The reference's scenes live in an absent data submodule (``touch-gs-data``, .gitmodules:1-3), so
+throughput is quoted on this seeded generator.  Generation happens on the CPU with a
+``torch.Generator`` (bit-reproducible everywhere) and is copied to the device.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+from .camera import Camera
+
+SH_C0 = 0.28209479177387814
+
+
+def synthetic_gaussians(N: int, W: int, H: int, deg: int, seed: int) -> Tuple[Dict[str, torch.Tensor], dict]:
+    """z~U(2,6); x,y fill 1.1x the frustum; log-scales ~ N(log(7/fx), 0.6^2); quats ~ N(0,1)^4;
+    opacity logits ~ U(-2,2); SH dc = (U(0,1)-0.5)/C0, higher bands ~ N(0, 0.05^2)."""
+    g = torch.Generator().manual_seed(seed)
+    t30 = math.tan(math.radians(30.0))
+    fx = fy = (W / 2) / t30
+    u = lambda *s: torch.rand(*s, generator=g, dtype=torch.float64)
+    n = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
+    z = 2 + 4 * u(N)
+    x = (2 * u(N) - 1) * 1.1 * z * t30
+    y = (2 * u(N) - 1) * 1.1 * z * (H / W) * t30
+    means = torch.stack([x, y, z], 1)
+    log_scales = math.log(7.0 / fx) + 0.6 * n(N, 3)
+    quats = n(N, 4)
+    opac = -2 + 4 * u(N)
+    K = (deg + 1) ** 2
+    sh = torch.zeros(N, K, 3, dtype=torch.float64)
+    sh[:, 0, :] = (u(N, 3) - 0.5) / SH_C0
+    if K > 1:
+        sh[:, 1:, :] = 0.05 * n(N, K - 1, 3)
+    P = dict(means=means.float(), log_scales=log_scales.float(), quats=quats.float(),
+             opac_logit=opac.float(), sh=sh.float())
+    return P, dict(fx=fx, fy=fy, cx=W / 2, cy=H / 2, W=W, H=H)
+
+
+def orbit_viewmat(k: int, V: int, centre=(0.0, 0.0, 4.0)) -> np.ndarray:
+    """View k of V: rotation about the y axis through the scene centre by 2*pi*k/V (view 0 = I)."""
+    th = 2 * math.pi * k / V
+    c, s = math.cos(th), math.sin(th)
+    R = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], dtype=np.float64)
+    ctr = np.asarray(centre, dtype=np.float64)
+    M = np.eye(4)
+    M[:3, :3] = R
+    M[:3, 3] = ctr - R @ ctr
+    return M
+
+
+def make_camera(intr: dict, view: int = 0, n_views: int = 8, bg=(0.0, 0.0, 0.0)) -> Camera:
+    return Camera(orbit_viewmat(view, n_views), intr["fx"], intr["fy"], intr["cx"], intr["cy"],
+                  intr["W"], intr["H"], bg=bg)
+
+
+def supervision_maps(W: int, H: int, seed: int):
+    """Uncertainty ~ U(0.001, 5); 30 % of the pixels carry no depth supervision (D_gt = 0)."""
+    g = torch.Generator().manual_seed(seed + 777)
+    unc = 0.001 + (5 - 0.001) * torch.rand(H, W, generator=g)
+    masked = torch.rand(H, W, generator=g) < 0.3
+    return unc, masked
+
+
+def make_view(N: int, W: int, H: int, deg: int, seed: int, device, view: int = 0, n_views: int = 8):
+    """Ground truth for a view = render of the *other* scene S(.., seed+1000) through this library
+    (GT RGB, GT depth), plus the synthetic uncertainty / mask maps."""
+    from . import ops
+    from .model import View
+    P, intr = synthetic_gaussians(N, W, H, deg, seed + 1000)
+    cam = make_camera(intr, view, n_views)
+    D = {k: v.to(device).contiguous() for k, v in P.items()}
+    with torch.no_grad():
+        rgb, depth_acc, alpha, _ = ops.render(D["means"], D["log_scales"], D["quats"], D["opac_logit"],
+                                              D["sh"], cam, deg)
+        depth = depth_acc / torch.clamp(alpha, min=1e-10)
+    unc, masked = supervision_maps(W, H, seed)
+    depth = torch.where(masked.to(device), torch.zeros_like(depth), depth)
+    return View(cam=cam, rgb=rgb.clamp(0, 1).contiguous(), depth=depth.contiguous(),
+                uncertainty=unc.to(device).contiguous())
