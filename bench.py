@@ -41,7 +41,7 @@ def algorithmic_bytes(N, I, P, T, K):
     return b
 
 
-def cpu_baseline(N, W, H, deg, seed, frac=16):
+def cpu_baseline(N, W, H, deg, seed, frac=None):
     """Build's own scalar C restatement (oracle/ref_raster.c, fp32, OpenMP over tiles) timed on the
     host cores: full projection / binning / projection-backward, compositing fwd+bwd on the first
     1/frac of the tiles and extrapolated.  The reference's rasterizer source is unavailable."""
@@ -49,6 +49,8 @@ def cpu_baseline(N, W, H, deg, seed, frac=16):
     from oracle import torch_oracle as O
     import numpy as np
     R = RefC("f32")
+    if frac is None:  # ~10-30 s of CPU work: whole image on a many-core host, a band of tiles otherwise
+        frac = max(1, 64 // max(R.num_threads(), 1))
     P, c = O.synthetic_scene(N, W, H, deg, seed, dtype=torch.float32)
     n = lambda t: t.numpy()
     cam = R.cam_block(O.orbit_viewmat(0, 8).numpy(), c["fx"], c["fy"], c["cx"], c["cy"])

@@ -89,12 +89,15 @@ size_t tgs_sort_scratch_bytes(int64_t capacity);
  *     + `spherical_harmonics`; INRIA preprocess, App. A.1; spec App. B.1-B.5).
  * in : means[N,3] log_scales[N,3] quats[N,4] (w,x,y,z un-normalised) opac_logit[N]
  *      sh[N,sh_stride,3] (NULL or sh_deg<0 => colours taken from `colors_in`[N,3] or zero)
- * out: splats[N,12] = {x, y, depth, opacity, conic a, b, c, r, g, b, radius(int32 bits), 0};
- *      culled Gaussians have radius 0. */
+ * out: splats[N,12] = {x, y, depth, opacity, conic a, b, c, r, g, b, rect, 0} where rect (uint32
+ *      bits) = x0 | y0<<8 | w<<16 | h<<24 is the Gaussian's tile rectangle: the App. B.4 rect
+ *      intersected with the tiles in which alpha can reach 1/255 (output preserving; 0 = none);
+ *      culled Gaussians have conic 0.  Image sides are limited to 4080 px (255 tiles).
+ *      radii[N] (may be NULL) = the App. B.3 3-sigma pixel radius, 0 if culled. */
 int tgs_project_fwd(const TgsCamera* cam /*[host]*/, int N, const float* means,
                     const float* log_scales, const float* quats, const float* opac_logit,
                     const float* sh, int sh_stride, int sh_deg, const float* colors_in,
-                    float* splats, void* stream);
+                    float* splats, int32_t* radii, void* stream);
 
 /* K2-K5  tile binning + per-tile depth sort  (stands behind gsplat `map_gaussian_to_intersects`,
  *     the CUB radix sort and `get_tile_bin_edges` inside `rasterize_gaussians`; spec App. B.4, B.6).

@@ -45,12 +45,12 @@ def test_argument_validation_without_gpu():
     assert lib.tgs_num_tiles(1920, 1080) == 120 * 68
     assert lib.tgs_sort_scratch_bytes(1000) >= 28 * 1000
     cam = _lib.TgsCamera()  # W = H = 0 -> invalid
-    rc = lib.tgs_project_fwd(C.byref(cam), 10, None, None, None, None, None, 0, -1, None, None, None)
+    rc = lib.tgs_project_fwd(C.byref(cam), 10, None, None, None, None, None, 0, -1, None, None, None, None)
     assert rc == -1 and b"camera" in lib.tgs_last_error()
     cam.W, cam.H, cam.fx, cam.fy = 64, 64, 50.0, 50.0
-    rc = lib.tgs_project_fwd(C.byref(cam), 10, None, None, None, None, None, 0, -1, None, None, None)
+    rc = lib.tgs_project_fwd(C.byref(cam), 10, None, None, None, None, None, 0, -1, None, None, None, None)
     assert rc == -1 and b"null" in lib.tgs_last_error()
-    assert lib.tgs_project_fwd(C.byref(cam), 0, None, None, None, None, None, 0, -1, None, None, None) == 0
+    assert lib.tgs_project_fwd(C.byref(cam), 0, None, None, None, None, None, 0, -1, None, None, None, None) == 0
     with pytest.raises(RuntimeError):
         _lib.check(rc, "x")
     with pytest.raises(RuntimeError):  # CPU tensors are rejected: there is no CPU path

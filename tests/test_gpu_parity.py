@@ -20,18 +20,24 @@ TOL = 1e-4
 def _project(dev, P, cam, deg):
     from touch_gs_amd import ops
     D = to_dev(P, dev)
-    sp = ops.project_fwd(amd_cam(cam), D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], deg)
-    return D, sp
+    sp, radii = ops.project_fwd(amd_cam(cam), D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"],
+                                deg, want_radii=True)
+    return D, sp, radii
 
 
 @pytest.mark.parametrize("N,W,H,deg,seed", [(2000, 160, 96, 3, 1), (500, 80, 48, 0, 2), (3000, 200, 120, 2, 3),
                                             (1000, 100, 70, 1, 4)])
 def test_project_fwd(dev, N, W, H, deg, seed):
     P, cam = scene(N, W, H, deg, seed)
-    _, sp = _project(dev, P, cam, deg)
-    f = splat_fields(sp)
+    _, sp, radii = _project(dev, P, cam, deg)
+    f = splat_fields(sp, radii)
     pr = O.project(P["means"], P["log_scales"], P["quats"], P["opac_logit"], P["sh"], cam, deg)
     v = pr["valid"]
+    # the packed rect is a subset of the normative B.4 rect, and visible <=> radius > 0
+    assert torch.equal(f["visible"], f["radius"] > 0)
+    rr, orr = f["rect"], pr["rect"]
+    sub = (f["hits"] == 0) | ((rr[:, 0] >= orr[:, 0]) & (rr[:, 1] >= orr[:, 1]) & (rr[:, 2] <= orr[:, 2]) & (rr[:, 3] <= orr[:, 3]))
+    assert sub[f["radius"] == pr["radius"]].all()
     # integer decisions: radius may differ only where 3*sqrt(lam1) sits within fp32 noise of an integer
     same = (f["radius"] == pr["radius"])
     assert same.float().mean() > 0.995, f"radius mismatch fraction {1 - same.float().mean():.4f}"
@@ -51,11 +57,10 @@ def test_project_fwd(dev, N, W, H, deg, seed):
 def test_bin_sort_exact(dev, N, W, H, seed):
     from touch_gs_amd import ops
     P, cam = scene(N, W, H, 0, seed)
-    _, sp = _project(dev, P, cam, 0)
+    _, sp, _ = _project(dev, P, cam, 0)
     gb, ts, sg, st = ops.bin_sort(amd_cam(cam), sp)
     f = splat_fields(sp)
-    rect = rect_from(f["xy"], f["radius"], cam)
-    gid, tstart = O.bin_and_sort(rect, f["radius"] > 0, f["depth"], cam)
+    gid, tstart = O.bin_and_sort(f["rect"], f["hits"] > 0, f["depth"], cam)
     n, ovf = st.tolist()
     assert ovf == 0 and n == len(gid)
     assert np.array_equal(ts.cpu().numpy().astype(np.int64), tstart)
@@ -65,7 +70,7 @@ def test_bin_sort_exact(dev, N, W, H, seed):
 def _blend_inputs(dev, N, W, H, deg, seed, **kw):
     from touch_gs_amd import ops
     P, cam = scene(N, W, H, deg, seed, **kw)
-    D, sp = _project(dev, P, cam, deg)
+    D, sp, _ = _project(dev, P, cam, deg)
     acam = amd_cam(cam)
     gb, ts, sg, st = ops.bin_sort(acam, sp)
     n = st.tolist()[0]
@@ -127,7 +132,7 @@ def test_rasterize_bwd(dev, N, W, H, deg, seed):
 def test_project_bwd(dev, N, W, H, deg, seed):
     from touch_gs_amd import ops
     P, cam = scene(N, W, H, deg, seed)
-    D, sp = _project(dev, P, cam, deg)
+    D, sp, radii = _project(dev, P, cam, deg)
     g = torch.Generator().manual_seed(seed)
     v_splats = torch.zeros(N, 12, dtype=torch.float64)
     v_splats[:, :10] = torch.randn(N, 10, generator=g, dtype=torch.float64)
@@ -136,7 +141,7 @@ def test_project_bwd(dev, N, W, H, deg, seed):
                                                  v_splats=v_splats.float().to(dev), want_v_xy=True)
     Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
     pr = O.project(Pg["means"], Pg["log_scales"], Pg["quats"], Pg["opac_logit"], Pg["sh"], cam, deg)
-    f = splat_fields(sp)
+    f = splat_fields(sp, radii)
     vis = (f["radius"] > 0) & pr["valid"]
     vz = torch.where(vis[:, None], v_splats[:, :10], torch.zeros_like(v_splats[:, :10]))
     # geometry terms only flow for visible Gaussians; colour/opacity terms for all
@@ -265,7 +270,7 @@ def test_edge_cases(dev):
     sp = ops.project_fwd(acam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], 0)
     gb, ts, sg, st = ops.bin_sort(acam, sp)
     f = splat_fields(sp)
-    gid, tstart = O.bin_and_sort(rect_from(f["xy"], f["radius"], cam), f["radius"] > 0, f["depth"], cam)
+    gid, tstart = O.bin_and_sort(f["rect"], f["hits"] > 0, f["depth"], cam)
     n = st.tolist()[0]
     assert (np.diff(tstart).max() > 2048), "test must exercise the large-list sort class"
     assert n == len(gid) and np.array_equal(sg[:n].cpu().numpy().astype(np.int64), gid)
@@ -287,7 +292,7 @@ def test_sort_fallback_global(dev):
     sp = ops.project_fwd(acam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], 0)
     gb, ts, sg, st = ops.bin_sort(acam, sp)
     f = splat_fields(sp)
-    gid, tstart = O.bin_and_sort(rect_from(f["xy"], f["radius"], cam), f["radius"] > 0, f["depth"], cam)
+    gid, tstart = O.bin_and_sort(f["rect"], f["hits"] > 0, f["depth"], cam)
     n = st.tolist()[0]
     assert np.diff(tstart).max() > 16384
     assert n == len(gid) and np.array_equal(sg[:n].cpu().numpy().astype(np.int64), gid)
@@ -296,7 +301,7 @@ def test_sort_fallback_global(dev):
 def test_capacity_overflow_regrows(dev):
     from touch_gs_amd import ops
     P, cam = scene(4000, 160, 96, 0, 91)
-    D, sp = _project(dev, P, cam, 0)
+    D, sp, _ = _project(dev, P, cam, 0)
     b = ops.IntersectBudget(capacity=100)
     gb, ts, sg, st = ops.bin_sort(amd_cam(cam), sp, b)
     n, ovf = st.tolist()

@@ -28,12 +28,18 @@ def relerr(a, b, floor=1e-6):
     return np.abs(a - b) / (np.abs(b) + floor)
 
 
-def splat_fields(splats):
-    """HIP splat records [N,12] (cpu float32 tensor) -> dict of fp64 tensors + radius int."""
+def splat_fields(splats, radii=None):
+    """HIP splat records [N,12] -> dict of fp64 tensors + the packed tile rect (x0,y0,x1,y1)."""
     s = splats.detach().cpu()
-    return dict(xy=s[:, 0:2].double(), depth=s[:, 2].double(), opac=s[:, 3].double(),
-                conic=s[:, 4:7].double(), rgb=s[:, 7:10].double(),
-                radius=s[:, 10].contiguous().view(torch.int32).long())
+    r = s[:, 10].contiguous().view(torch.int32).long() & 0xFFFFFFFF
+    x0, y0, w, h = r & 255, (r >> 8) & 255, (r >> 16) & 255, (r >> 24) & 255
+    out = dict(xy=s[:, 0:2].double(), depth=s[:, 2].double(), opac=s[:, 3].double(),
+               conic=s[:, 4:7].double(), rgb=s[:, 7:10].double(),
+               rect=torch.stack([x0, y0, x0 + w, y0 + h], 1), hits=w * h,
+               visible=s[:, 4] > 0)
+    if radii is not None:
+        out["radius"] = radii.detach().cpu().long()
+    return out
 
 
 def rect_from(xy, radius, cam):

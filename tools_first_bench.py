@@ -14,7 +14,7 @@ def run(N, W, H, deg, seed, iters=10):
     sp = ops.project_fwd(cam, D['means'], D['log_scales'], D['quats'], D['opac_logit'], D['sh'], deg)
     gb, ts, sg, st = ops.bin_sort(cam, sp, budget)
     n = st.tolist()[0]
-    print(f'N={N} {W}x{H} I={n} tiles={cam.num_tiles} per-tile={n/cam.num_tiles:.0f} max-tile={int((ts[1:]-ts[:-1]).max())} visible={int((sp[:,10].view(torch.int32)>0).sum())}')
+    print(f'N={N} {W}x{H} I={n} tiles={cam.num_tiles} per-tile={n/cam.num_tiles:.0f} max-tile={int((ts[1:]-ts[:-1]).max())} visible={int((sp[:,4]>0).sum())}')
     budget.sync = False
     budget.capacity = int(n * 1.2)
     gt = torch.rand(H, W, 3, device=dev); dgt = torch.rand(H, W, device=dev) * 5; unc = torch.rand(H, W, device=dev)

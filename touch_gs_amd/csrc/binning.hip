@@ -36,15 +36,10 @@ __device__ __forceinline__ int group_load_scan(const CamK& cam, int N,
   unsigned dbits = 0;
   if (g < N) {
     const float* rec = splats + (size_t)g * TGS_SPLAT_FLOATS;
-    const float4 r0 = ld4(rec);
-    const int radius = __float_as_int(rec[10]);
-    if (radius > 0) {
-      int x1, y1;
-      tile_rect(r0.x, r0.y, radius, cam.TW, cam.TH, x0, y0, x1, y1);
-      w = x1 - x0;
-      hits = w * (y1 - y0);
-      dbits = __float_as_uint(r0.z);
-    }
+    int h;
+    unpack_rect(__float_as_uint(rec[10]), x0, y0, w, h);
+    hits = w * h;
+    dbits = __float_as_uint(rec[2]);
   }
   // wave-level inclusive scan, then across the 4 waves
   int incl = hits;

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_project_fwd(
     CamK cam, int N, const float* __restrict__ means, const float* __restrict__ log_scales,
     const float* __restrict__ quats, const float* __restrict__ opac_logit,
     const float* __restrict__ sh, int sh_stride, const float* __restrict__ colors_in,
-    float* __restrict__ splats) {
+    float* __restrict__ splats, int32_t* __restrict__ radii) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= N) return;
   const float m[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256) void k_project_fwd(
   geom_eval(cam, m, ls, q, G);
   float x2 = 0.f, y2 = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
   int radius = 0;
+  unsigned rect = 0u;
   if (G.tz > cam.near_plane) {
     const float rz = 1.0f / G.tz;
     x2 = cam.fx * G.tx * rz + cam.cx;
@@ -189,13 +190,29 @@ __global__ __launch_bounds__(256) void k_project_fwd(
       const int r = (int)ceilf(3.0f * sqrtf(lam1));
       int x0, y0, x1, y1;
       tile_rect(x2, y2, r, cam.TW, cam.TH, x0, y0, x1, y1);
-      if ((x1 - x0) * (y1 - y0) > 0) radius = r;
+      if ((x1 - x0) * (y1 - y0) > 0) {
+        radius = r;
+        // Output-preserving tightening: alpha = o*exp(-sigma) >= 1/255 only inside the ellipse
+        // d^T Cov^-1 d <= 2 ln(255 o), whose axis-aligned half extents are sqrt(tau2 * Cov_ii).
+        const float tau2 = 2.0f * logf(255.0f * opac);
+        if (tau2 > 0.f) {
+          const float ex = sqrtf(tau2 * G.c00) + 0.02f, ey = sqrtf(tau2 * G.c11) + 0.02f;
+          const int jx0 = (int)ceilf(x2 - ex - cam.pix_center), jx1 = (int)floorf(x2 + ex - cam.pix_center);
+          const int jy0 = (int)ceilf(y2 - ey - cam.pix_center), jy1 = (int)floorf(y2 + ey - cam.pix_center);
+          const int tx0 = max(x0, max(jx0, 0) >> 4), tx1 = min(x1 - 1, jx1 >> 4);
+          const int ty0 = max(y0, max(jy0, 0) >> 4), ty1 = min(y1 - 1, jy1 >> 4);
+          if (jx1 >= 0 && jy1 >= 0 && tx1 >= tx0 && ty1 >= ty0)
+            rect = pack_rect(tx0, ty0, tx1 - tx0 + 1, ty1 - ty0 + 1);
+        }
+      }
     }
   }
+  if (radius == 0) { ca = 0.f; cb = 0.f; cc = 0.f; }  // conic != 0  <=>  passed the App. B culls
   float* o = splats + (size_t)g * TGS_SPLAT_FLOATS;
   st4(o, make_float4(x2, y2, G.tz, opac));
   st4(o + 4, make_float4(ca, cb, cc, rgb[0]));
-  st4(o + 8, make_float4(rgb[1], rgb[2], __int_as_float(radius), 0.f));
+  st4(o + 8, make_float4(rgb[1], rgb[2], __uint_as_float(rect), 0.f));
+  if (radii) radii[g] = radius;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -207,13 +224,11 @@ __device__ __forceinline__ void sum_partials(const CamK& cam, const float* __res
 #pragma unroll
   for (int i = 0; i < 10; i++) v[i] = 0.f;
   const float* rec = splats + (size_t)g * TGS_SPLAT_FLOATS;
-  const float4 r0 = ld4(rec);
   const float4 r2 = ld4(rec + 8);
-  const int radius = __float_as_int(r2.z);
-  if (radius <= 0) return;
-  int x0, y0, x1, y1;
-  tile_rect(r0.x, r0.y, radius, cam.TW, cam.TH, x0, y0, x1, y1);
-  const int hits = (x1 - x0) * (y1 - y0);
+  int x0, y0, w, h;
+  unpack_rect(__float_as_uint(r2.z), x0, y0, w, h);
+  const int hits = w * h;
+  if (hits == 0) return;
   const size_t off = (size_t)group_base[g / TGS_GROUP] + (size_t)__float_as_int(r2.w);
   const float* p = partials + off * TGS_PARTIAL_FLOATS;
   for (int k = 0; k < hits; k++, p += TGS_PARTIAL_FLOATS) {
@@ -317,8 +332,9 @@ __global__ __launch_bounds__(256) void k_project_bwd(
   // ---- geometry backward (B.8) ----
   float vls[3] = {0.f, 0.f, 0.f};
   float vq[4] = {0.f, 0.f, 0.f, 0.f};
-  const int radius = __float_as_int(splats[(size_t)g * TGS_SPLAT_FLOATS + 10]);
-  if (radius > 0) {
+  // a Gaussian passed the App. B culls iff its conic was written (a > 0)
+  const bool visible = splats[(size_t)g * TGS_SPLAT_FLOATS + 4] > 0.f;
+  if (visible) {
     const float ls[3] = {log_scales[3 * g], log_scales[3 * g + 1], log_scales[3 * g + 2]};
     const float4 q4 = ld4(quats + 4 * (size_t)g);
     const float q[4] = {q4.x, q4.y, q4.z, q4.w};
@@ -411,9 +427,11 @@ __global__ __launch_bounds__(256) void k_project_bwd(
 extern "C" int tgs_project_fwd(const TgsCamera* cam, int N, const float* means,
                                const float* log_scales, const float* quats,
                                const float* opac_logit, const float* sh, int sh_stride, int sh_deg,
-                               const float* colors_in, float* splats, void* stream) {
+                               const float* colors_in, float* splats, int32_t* radii,
+                               void* stream) {
   TGS_CHECK_ARG(camera_ok(cam), "bad camera");
   TGS_CHECK_ARG(N >= 0, "N < 0");
+  TGS_CHECK_ARG(cam->W <= 4080 && cam->H <= 4080, "image side > 4080 px (255 tiles)");
   if (N == 0) return TGS_OK;
   TGS_CHECK_ARG(means && log_scales && quats && opac_logit && splats, "null pointer");
   if (!sh) sh_deg = -1;
@@ -424,7 +442,7 @@ extern "C" int tgs_project_fwd(const TgsCamera* cam, int N, const float* means,
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(D)                                                                              \
   hipLaunchKernelGGL(k_project_fwd<D>, grid, block, 0, s, k, N, means, log_scales, quats,      \
-                     opac_logit, sh, sh_stride, colors_in, splats)
+                     opac_logit, sh, sh_stride, colors_in, splats, radii)
   switch (sh_deg) {
     case 0: LAUNCH(0); break;
     case 1: LAUNCH(1); break;

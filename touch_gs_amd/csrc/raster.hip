@@ -7,25 +7,33 @@
 // of the two full rasterizations Splatfacto issues.
 //
 // MI355X mapping (not a warp-shaped CUDA tiling):
-//  * one wave64 owns one 16x16 tile; lane l owns the 4 pixels (x = l&15, y = (l>>4) + 4k).
-//    No workgroup barriers, no cross-wave reduction; the 4 pixels of a lane share the dx terms
-//    and give 4-way ILP on the exp chain.
-//  * the tile's Gaussian list is staged 64 records at a time through LDS (each lane gathers one
-//    48-B record with three 16-B loads) and read back as wave-uniform broadcast ds_read_b128.
-//  * backward: each lane first sums its 4 pixels in registers, then a 6-step DPP wave reduction
-//    yields the tile's total for that Gaussian; lane j of the batch keeps Gaussian j's 10 sums and
-//    the batch is written as 64 contiguous 48-B partial records.  There are NO float atomics:
-//    cross-tile accumulation is a segmented sum in K8 (deterministic, and it avoids cross-XCD
-//    memory-side atomics, which are the expensive primitive on an 8-chiplet part).
+//  * one wave64 owns one 16x16 tile.  Lane l owns 4 pixels, one per 8x8 quadrant ("slot" k):
+//    (x, y) = (8*(k&1) + (l&7), 8*(k>>1) + (l>>3)).  No workgroup barriers, no cross-wave traffic.
+//  * the tile's Gaussian list is staged 64 records at a time through LDS.  While staging, lane j
+//    turns Gaussian j into a tile-centred quadratic  s(u,v) = c0 + c1 u + c2 v + c3 u^2 + c4 uv +
+//    c5 v^2  with log2(e) and -log2(opacity) folded in, so that alpha = exp2(-s) costs 5 FMAs + one
+//    v_exp per pixel, and into a 4-bit quadrant mask (which 8x8 quadrants can reach
+//    alpha >= 1/255).  The blend loop reads the record back as wave-uniform broadcast
+//    ds_read_b128 and skips whole quadrants with scalar branches; the per-pixel update is
+//    branch-free (v_cndmask), so the 4 pixels of a lane pipeline through the exp unit.
+//  * backward: per-pixel state is (T, S.v) only; each lane accumulates, over its <= 4 pixels,
+//    10 sums per Gaussian (v_rgb, v_depth and the six pixel-coordinate moments of
+//    q = alpha * v_alpha); a multiplexed DPP butterfly (35 VALU ops for all 10 values instead of
+//    10 x 6) leaves value i in lane i, which drops it into an LDS transpose buffer; at the end
+//    of the batch lane j converts Gaussian j's moments into (v_xy, v_conic, v_opacity) and stores
+//    one 48-B partial record.  There are NO float atomics: cross-tile accumulation is a segmented
+//    sum in K8 (deterministic, and it avoids cross-XCD memory-side atomics).
 //  * blockIdx -> tile mapping gives each XCD a contiguous band of tiles so the gathered splat
 //    records of neighbouring tiles stay in that XCD's 4 MB L2.
 #include "tgs_common.h"
 
 namespace {
 
-constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float ALPHA_MAX = 0.999f;
 constexpr float T_STOP = 1e-4f;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LOG2_255 = 7.994353436858858f;   // alpha >= 1/255  <=>  s <= log2(255)
+constexpr float LN2 = 0.6931471805599453f;
 
 __device__ __forceinline__ int xcd_tile(int b, int T) {
   const int q = (T + 7) >> 3;          // tiles per XCD band
@@ -40,6 +48,71 @@ struct LossK {
   int on;
 };
 
+// Gaussian -> tile-centred quadratic + quadrant mask.  (gx, gy) = centre relative to the tile
+// centre, in pixel-centre coordinates (pixel (i,j) of the tile sits at u = i - 7.5, v = j - 7.5).
+struct TileRec {
+  float4 a;  // c0 c1 c2 c3
+  float4 b;  // c4 c5 L depth       L = -log2(opacity):  sigma >= 0  <=>  s >= L
+  float4 c;  // r g b mask(bits)
+};
+
+__device__ __forceinline__ TileRec make_tile_rec(float4 r0, float4 r1, float4 r2, float tcx, float tcy) {
+  // r0 = {x, y, depth, opac}  r1 = {a, b, c, r}  r2 = {g, b, rect, off}
+  const float gx = r0.x - tcx, gy = r0.y - tcy;
+  const float A = r1.x, B = r1.y, Cc = r1.z;
+  const float L = -__log2f(r0.w);
+  TileRec t;
+  t.a.x = LOG2E * (0.5f * A * gx * gx + B * gx * gy + 0.5f * Cc * gy * gy) + L;
+  t.a.y = -LOG2E * (A * gx + B * gy);
+  t.a.z = -LOG2E * (B * gx + Cc * gy);
+  t.a.w = 0.5f * LOG2E * A;
+  t.b.x = LOG2E * B;
+  t.b.y = 0.5f * LOG2E * Cc;
+  t.b.z = L;
+  t.b.w = r0.z;
+  // quadrant mask from the extents of {alpha >= 1/255}: |dx| <= sqrt(tau2 * Cov_xx)
+  unsigned mask = 0u;
+  const float tau2 = 2.0f * LN2 * (LOG2_255 - L);
+  const float det = A * Cc - B * B;
+  if (tau2 > 0.f && det > 0.f) {
+    const float idet = 1.0f / det;
+    const float ex = sqrtf(tau2 * Cc * idet) + 0.02f, ey = sqrtf(tau2 * A * idet) + 0.02f;
+    const bool x_lo = (gx + ex >= -7.5f) && (gx - ex <= -0.5f);
+    const bool x_hi = (gx + ex >= 0.5f) && (gx - ex <= 7.5f);
+    const bool y_lo = (gy + ey >= -7.5f) && (gy - ey <= -0.5f);
+    const bool y_hi = (gy + ey >= 0.5f) && (gy - ey <= 7.5f);
+    mask = (unsigned)(x_lo && y_lo) | ((unsigned)(x_hi && y_lo) << 1) |
+           ((unsigned)(x_lo && y_hi) << 2) | ((unsigned)(x_hi && y_hi) << 3);
+  }
+  t.c = make_float4(r1.w, r2.x, r2.y, __uint_as_float(mask));
+  return t;
+}
+
+// per-lane pixel constants of slot k
+struct PixConst {
+  float u[2], v[2], uu[2], vv[2], uv[4];
+};
+
+__device__ __forceinline__ PixConst make_pix_const(int lane) {
+  PixConst p;
+  p.u[0] = (float)(lane & 7) - 7.5f; p.u[1] = p.u[0] + 8.f;
+  p.v[0] = (float)(lane >> 3) - 7.5f; p.v[1] = p.v[0] + 8.f;
+#pragma unroll
+  for (int i = 0; i < 2; i++) { p.uu[i] = p.u[i] * p.u[i]; p.vv[i] = p.v[i] * p.v[i]; }
+#pragma unroll
+  for (int k = 0; k < 4; k++) p.uv[k] = p.u[k & 1] * p.v[k >> 1];
+  return p;
+}
+
+__device__ __forceinline__ float eval_s(const float4& a, const float4& b, const PixConst& p, int k) {
+  float s = fmaf(a.y, p.u[k & 1], a.x);
+  s = fmaf(a.z, p.v[k >> 1], s);
+  s = fmaf(a.w, p.uu[k & 1], s);
+  s = fmaf(b.x, p.uv[k], s);
+  s = fmaf(b.y, p.vv[k >> 1], s);
+  return s;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K6 forward
 // ---------------------------------------------------------------------------------------------
@@ -51,15 +124,16 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
   if (tile >= T_total) return;
   const int lane = threadIdx.x;
   const int ty = tile / cam.TW, tx = tile - ty * cam.TW;
-  const int px = tx * TGS_BLOCK + (lane & 15);
-  const int py0 = ty * TGS_BLOCK + (lane >> 4);
-  const float pxf = (float)px + cam.pix_center;
-  float pyf[4];
+  const float tcx = (float)(tx * TGS_BLOCK + 8) - 0.5f + cam.pix_center;  // tile centre
+  const float tcy = (float)(ty * TGS_BLOCK + 8) - 0.5f + cam.pix_center;
+  const PixConst pc = make_pix_const(lane);
+  int pxi[4], pyi[4];
   bool live[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    pyf[k] = (float)(py0 + 4 * k) + cam.pix_center;
-    live[k] = (px < cam.W) && (py0 + 4 * k < cam.H);
+    pxi[k] = tx * TGS_BLOCK + 8 * (k & 1) + (lane & 7);
+    pyi[k] = ty * TGS_BLOCK + 8 * (k >> 1) + (lane >> 3);
+    live[k] = (pxi[k] < cam.W) && (pyi[k] < cam.H);
   }
   float T[4] = {1.f, 1.f, 1.f, 1.f};
   float Cr[4] = {0.f, 0.f, 0.f, 0.f}, Cg[4] = {0.f, 0.f, 0.f, 0.f}, Cb[4] = {0.f, 0.f, 0.f, 0.f};
@@ -77,9 +151,15 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
     n0 = ld4(r); n1 = ld4(r + 4); n2 = ld4(r + 8);
   }
   for (int base = start; base < end; base += 64) {
-    if (__ballot(live[0] | live[1] | live[2] | live[3]) == 0ull) break;
+    unsigned slot_live = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) slot_live |= (__ballot(live[k]) != 0ull) ? (1u << k) : 0u;
+    if (slot_live == 0u) break;
     __syncthreads();
-    recs[lane * 3] = n0; recs[lane * 3 + 1] = n1; recs[lane * 3 + 2] = n2;
+    if (base + lane < end) {
+      const TileRec t = make_tile_rec(n0, n1, n2, tcx, tcy);
+      recs[lane * 3] = t.a; recs[lane * 3 + 1] = t.b; recs[lane * 3 + 2] = t.c;
+    }
     __syncthreads();
     if (base + 64 + lane < end) {
       const float* r = splats + (size_t)sorted_gid[base + 64 + lane] * TGS_SPLAT_FLOATS;
@@ -87,39 +167,35 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
     }
     const int cnt = min(64, end - base);
     for (int j = 0; j < cnt; j++) {
-      const float4 r0 = recs[j * 3], r1 = recs[j * 3 + 1], r2 = recs[j * 3 + 2];
-      // r0 = {x, y, depth, opac}  r1 = {a, b, c, r}  r2 = {g, b, -, -}
-      const float dx = r0.x - pxf;
-      const float hadx2 = 0.5f * r1.x * dx * dx;
-      const float bdx = r1.y * dx;
-      const float hc = 0.5f * r1.z;
+      const float4 qc = recs[j * 3 + 2];
+      const unsigned m = __builtin_amdgcn_readfirstlane(__float_as_uint(qc.w)) & slot_live;
+      if (m == 0u) continue;
+      const float4 qa = recs[j * 3], qb = recs[j * 3 + 1];
       const int pos = base - start + j;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        if (live[k]) {
-          const float dy = r0.y - pyf[k];
-          const float sigma = fmaf(dy, fmaf(hc, dy, bdx), hadx2);
-          const float al = fminf(ALPHA_MAX, r0.w * __expf(-sigma));
-          if (sigma >= 0.f && al >= ALPHA_MIN) {
-            const float Tn = T[k] * (1.f - al);
-            if (Tn <= T_STOP) {
-              live[k] = false;
-            } else {
-              const float w = al * T[k];
-              Cr[k] = fmaf(w, r1.w, Cr[k]); Cg[k] = fmaf(w, r2.x, Cg[k]);
-              Cb[k] = fmaf(w, r2.y, Cb[k]); D[k] = fmaf(w, r0.z, D[k]);
-              T[k] = Tn; last[k] = pos;
-            }
-          }
+        if (m & (1u << k)) {  // wave-uniform
+          const float s = eval_s(qa, qb, pc, k);
+          const bool valid = live[k] & (s >= qb.z) & (s <= LOG2_255);
+          float al = fminf(ALPHA_MAX, __builtin_amdgcn_exp2f(-s));
+          al = valid ? al : 0.f;
+          const float Tn = fmaf(-al, T[k], T[k]);
+          const bool stop = valid & (Tn <= T_STOP);
+          float w = al * T[k];
+          w = stop ? 0.f : w;
+          Cr[k] = fmaf(w, qc.x, Cr[k]); Cg[k] = fmaf(w, qc.y, Cg[k]);
+          Cb[k] = fmaf(w, qc.z, Cb[k]); D[k] = fmaf(w, qb.w, D[k]);
+          T[k] = stop ? T[k] : Tn;
+          last[k] = (valid & !stop) ? pos : last[k];
+          live[k] = live[k] & !stop;
         }
       }
     }
   }
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const int py = py0 + 4 * k;
-    if (px < cam.W && py < cam.H) {
-      const size_t p = (size_t)py * cam.W + px;
+    if (pxi[k] < cam.W && pyi[k] < cam.H) {
+      const size_t p = (size_t)pyi[k] * cam.W + pxi[k];
       out_rgb[3 * p] = Cr[k] + T[k] * cam.bg[0];
       out_rgb[3 * p + 1] = Cg[k] + T[k] * cam.bg[1];
       out_rgb[3 * p + 2] = Cb[k] + T[k] * cam.bg[2];
@@ -133,12 +209,42 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
 // ---------------------------------------------------------------------------------------------
 // K7 backward
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ size_t pair_index(const CamK& cam, const int32_t* __restrict__ group_base,
-                                             int gid, float4 r0, float4 r2, int tx, int ty) {
-  int x0, y0, x1, y1;
-  tile_rect(r0.x, r0.y, __float_as_int(r2.z), cam.TW, cam.TH, x0, y0, x1, y1);
+__device__ __forceinline__ size_t pair_index(const int32_t* __restrict__ group_base, int gid,
+                                             float4 r2, int tx, int ty) {
+  int x0, y0, w, h;
+  unpack_rect(__float_as_uint(r2.z), x0, y0, w, h);
   return (size_t)group_base[gid / TGS_GROUP] + (size_t)__float_as_int(r2.w) +
-         (size_t)((ty - y0) * (x1 - x0) + (tx - x0));
+         (size_t)((ty - y0) * w + (tx - x0));
+}
+
+// one multiplexed butterfly step: lanes whose `bit` is clear keep A, the others keep B; each lane
+// adds its partner's copy of the value it keeps.  Halves the number of live registers.
+template <int CTRL>
+__device__ __forceinline__ float mux_step(float A, float B, bool bit) {
+  const float keep = bit ? B : A;
+  const float send = bit ? A : B;
+  const int s = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), CTRL, 0xf, 0xf, false);
+  return keep + __builtin_bit_cast(float, s);
+}
+
+// Sums v[0..9] over the 64 lanes; lane i (and i+16, i+32, i+48) ends up holding the total of v[i].
+__device__ __forceinline__ float butterfly10(const float* v, bool b0, bool b1, bool b2, bool b3) {
+  const float R0 = mux_step<0xB1>(v[0], v[1], b0);   // quad_perm [1,0,3,2]
+  const float R1 = mux_step<0xB1>(v[2], v[3], b0);
+  const float R2 = mux_step<0xB1>(v[4], v[5], b0);
+  const float R3 = mux_step<0xB1>(v[6], v[7], b0);
+  const float R4 = mux_step<0xB1>(v[8], v[9], b0);
+  const float Q0 = mux_step<0x4E>(R0, R1, b1);       // quad_perm [2,3,0,1]
+  const float Q1 = mux_step<0x4E>(R2, R3, b1);
+  const float Q2 = mux_step<0x4E>(R4, 0.f, b1);
+  const float P0 = mux_step<0x124>(Q0, Q1, b2);      // row_ror:4
+  const float P1 = mux_step<0x124>(Q2, 0.f, b2);
+  float O = mux_step<0x128>(P0, P1, b3);             // row_ror:8  -> per row: lane i = sum of v[i]
+  // lane-wise sum of the four rows (each lane of a row holds a different value, so the
+  // single-lane row_bcast DPP forms do not apply): two ds_bpermute exchanges
+  O += __shfl_xor(O, 16);
+  O += __shfl_xor(O, 32);
+  return O;
 }
 
 __global__ __launch_bounds__(64) void k_raster_bwd(
@@ -153,21 +259,20 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
   if (tile >= T_total) return;
   const int lane = threadIdx.x;
   const int ty = tile / cam.TW, tx = tile - ty * cam.TW;
-  const int px = tx * TGS_BLOCK + (lane & 15);
-  const int py0 = ty * TGS_BLOCK + (lane >> 4);
-  const float pxf = (float)px + cam.pix_center;
+  const float tcx = (float)(tx * TGS_BLOCK + 8) - 0.5f + cam.pix_center;
+  const float tcy = (float)(ty * TGS_BLOCK + 8) - 0.5f + cam.pix_center;
+  const PixConst pc = make_pix_const(lane);
   const int start = tile_start[tile], end = tile_start[tile + 1];
   const int n = end - start;
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
 
-  float pyf[4], T[4], vCr[4], vCg[4], vCb[4], vD[4], vAT[4];
-  float Sr[4] = {0.f, 0.f, 0.f, 0.f}, Sg[4] = {0.f, 0.f, 0.f, 0.f}, Sb[4] = {0.f, 0.f, 0.f, 0.f};
-  float SD[4] = {0.f, 0.f, 0.f, 0.f};
+  float T[4], Sv[4] = {0.f, 0.f, 0.f, 0.f}, vCr[4], vCg[4], vCb[4], vD[4], vAT[4];
   int last[4];
   float l_l1 = 0.f, l_dep = 0.f;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const int py = py0 + 4 * k;
-    pyf[k] = (float)py + cam.pix_center;
+    const int px = tx * TGS_BLOCK + 8 * (k & 1) + (lane & 7);
+    const int py = ty * TGS_BLOCK + 8 * (k >> 1) + (lane >> 3);
     T[k] = 1.f; vCr[k] = vCg[k] = vCb[k] = vD[k] = vAT[k] = 0.f; last[k] = -1;
     if (px < cam.W && py < cam.H) {
       const size_t p = (size_t)py * cam.W + px;
@@ -220,88 +325,93 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int pos = maxlast + 1 + lane; pos < n; pos += 64) {
     const int gid = sorted_gid[start + pos];
-    const float* r = splats + (size_t)gid * TGS_SPLAT_FLOATS;
-    const size_t P = pair_index(cam, group_base, gid, ld4(r), ld4(r + 8), tx, ty);
+    const size_t P = pair_index(group_base, gid, ld4(splats + (size_t)gid * TGS_SPLAT_FLOATS + 8), tx, ty);
     float* o = partials + P * TGS_PARTIAL_FLOATS;
     st4(o, z4); st4(o + 4, z4); st4(o + 8, z4);
   }
 
   __shared__ float4 recs[64 * 3];
+  __shared__ float4 sums[64 * 4];  // [Gaussian j][16 slots], slot i < 10 = total of value i
   for (int base = (maxlast >= 0 ? (maxlast >> 6) << 6 : -1); base >= 0; base -= 64) {
     const int cnt = min(64, maxlast + 1 - base);
     size_t P = 0;
+    float4 a0 = z4, a1 = z4;
+    unsigned slot_live = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) slot_live |= (__ballot(last[k] >= base) != 0ull) ? (1u << k) : 0u;
     __syncthreads();
     if (lane < cnt) {
       const int gid = sorted_gid[start + base + lane];
       const float* r = splats + (size_t)gid * TGS_SPLAT_FLOATS;
-      const float4 a0 = ld4(r), a1 = ld4(r + 4), a2 = ld4(r + 8);
-      recs[lane * 3] = a0; recs[lane * 3 + 1] = a1; recs[lane * 3 + 2] = a2;
-      P = pair_index(cam, group_base, gid, a0, a2, tx, ty);
+      a0 = ld4(r); a1 = ld4(r + 4);
+      const float4 a2 = ld4(r + 8);
+      const TileRec t = make_tile_rec(a0, a1, a2, tcx, tcy);
+      recs[lane * 3] = t.a; recs[lane * 3 + 1] = t.b; recs[lane * 3 + 2] = t.c;
+      P = pair_index(group_base, gid, a2, tx, ty);
     }
+    sums[lane * 4] = z4; sums[lane * 4 + 1] = z4; sums[lane * 4 + 2] = z4;
     __syncthreads();
-    float hold[10];
-#pragma unroll
-    for (int c = 0; c < 10; c++) hold[c] = 0.f;
 
     for (int j = cnt - 1; j >= 0; j--) {
-      const float4 r0 = recs[j * 3], r1 = recs[j * 3 + 1], r2 = recs[j * 3 + 2];
+      const float4 qc = recs[j * 3 + 2];
+      const unsigned m = __builtin_amdgcn_readfirstlane(__float_as_uint(qc.w)) & slot_live;
+      if (m == 0u) continue;
+      const float4 qa = recs[j * 3], qb = recs[j * 3 + 1];
       const int pos = base + j;
-      const float dx = r0.x - pxf;
-      const float hadx2 = 0.5f * r1.x * dx * dx;
-      const float bdx = r1.y * dx;
-      const float hc = 0.5f * r1.z;
+      // acc: 0..2 v_rgb, 3 v_depth, 4 Q0 = sum q, 5 Qu, 6 Qv, 7 Quu, 8 Quv, 9 Qvv
       float acc[10];
 #pragma unroll
       for (int c = 0; c < 10; c++) acc[c] = 0.f;
       bool any = false;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        if (pos <= last[k]) {
-          const float dy = r0.y - pyf[k];
-          const float sigma = fmaf(dy, fmaf(hc, dy, bdx), hadx2);
-          const float ex = __expf(-sigma);
-          const float al = fminf(ALPHA_MAX, r0.w * ex);
-          if (sigma >= 0.f && al >= ALPHA_MIN) {
-            any = true;
-            const float ra = 1.0f / (1.f - al);
-            const float Tb = T[k] * ra;  // transmittance in front of this Gaussian
-            T[k] = Tb;
-            const float w = al * Tb;
-            acc[7] = fmaf(w, vCr[k], acc[7]);
-            acc[8] = fmaf(w, vCg[k], acc[8]);
-            acc[9] = fmaf(w, vCb[k], acc[9]);
-            acc[2] = fmaf(w, vD[k], acc[2]);
-            float va = (r1.w * Tb - Sr[k] * ra) * vCr[k];
-            va = fmaf(r2.x * Tb - Sg[k] * ra, vCg[k], va);
-            va = fmaf(r2.y * Tb - Sb[k] * ra, vCb[k], va);
-            va = fmaf(r0.z * Tb - SD[k] * ra, vD[k], va);
-            va = fmaf(vAT[k], ra, va);
-            Sr[k] = fmaf(w, r1.w, Sr[k]); Sg[k] = fmaf(w, r2.x, Sg[k]);
-            Sb[k] = fmaf(w, r2.y, Sb[k]); SD[k] = fmaf(w, r0.z, SD[k]);
-            acc[3] = fmaf(ex, va, acc[3]);             // d/d opacity
-            const float vs = -r0.w * ex * va;          // d/d sigma
-            const float vsdx = vs * dx, vsdy = vs * dy;
-            acc[4] = fmaf(0.5f * vsdx, dx, acc[4]);    // conic a
-            acc[5] = fmaf(vsdx, dy, acc[5]);           // conic b
-            acc[6] = fmaf(0.5f * vsdy, dy, acc[6]);    // conic c
-            acc[0] = fmaf(vs, fmaf(r1.x, dx, r1.y * dy), acc[0]);  // mean2d x
-            acc[1] = fmaf(vs, fmaf(r1.y, dx, r1.z * dy), acc[1]);  // mean2d y
-          }
+        if (m & (1u << k)) {  // wave-uniform
+          const float s = eval_s(qa, qb, pc, k);
+          const bool valid = (pos <= last[k]) & (s >= qb.z) & (s <= LOG2_255);
+          const float e2 = __builtin_amdgcn_exp2f(-s);          // = opacity * exp(-sigma)
+          float al = fminf(ALPHA_MAX, e2);
+          al = valid ? al : 0.f;
+          const float ra = __builtin_amdgcn_rcpf(1.f - al);
+          const float Tb = T[k] * ra;                            // transmittance in front of g
+          T[k] = Tb;
+          const float w = al * Tb;
+          acc[0] = fmaf(w, vCr[k], acc[0]); acc[1] = fmaf(w, vCg[k], acc[1]);
+          acc[2] = fmaf(w, vCb[k], acc[2]); acc[3] = fmaf(w, vD[k], acc[3]);
+          float cv = qc.x * vCr[k];
+          cv = fmaf(qc.y, vCg[k], cv); cv = fmaf(qc.z, vCb[k], cv); cv = fmaf(qb.w, vD[k], cv);
+          const float va = fmaf(Tb, cv, ra * (vAT[k] - Sv[k]));  // dL/d alpha
+          Sv[k] = fmaf(w, cv, Sv[k]);
+          float q = e2 * va;
+          q = valid ? q : 0.f;
+          acc[4] += q;
+          acc[5] = fmaf(q, pc.u[k & 1], acc[5]); acc[6] = fmaf(q, pc.v[k >> 1], acc[6]);
+          acc[7] = fmaf(q, pc.uu[k & 1], acc[7]); acc[8] = fmaf(q, pc.uv[k], acc[8]);
+          acc[9] = fmaf(q, pc.vv[k >> 1], acc[9]);
+          any |= valid;
         }
       }
       if (__ballot(any) != 0ull) {
-#pragma unroll
-        for (int c = 0; c < 10; c++) {
-          const float tot = wave_sum(acc[c]);
-          hold[c] = (lane == j) ? tot : hold[c];
-        }
+        const float O = butterfly10(acc, b0, b1, b2, b3);
+        if (lane < 16) reinterpret_cast<float*>(sums)[j * 16 + lane] = O;
       }
     }
+    __syncthreads();
     if (lane < cnt) {
+      const float4 s0 = sums[lane * 4], s1 = sums[lane * 4 + 1], s2 = sums[lane * 4 + 2];
+      // s0 = {v_r, v_g, v_b, v_depth}  s1 = {Q0, Qu, Qv, Quu}  s2 = {Quv, Qvv, -, -}
+      const float gx = a0.x - tcx, gy = a0.y - tcy;
+      const float A = a1.x, B = a1.y, Cc = a1.z;
+      const float Q0 = s1.x, Qu = s1.y, Qv = s1.z, Quu = s1.w, Quv = s2.x, Qvv = s2.y;
+      // v_sigma = -q, Delta = (gx - u, gy - v):  M* = sum v_sigma * Delta-monomials
+      const float Mx = -(gx * Q0 - Qu), My = -(gy * Q0 - Qv);
+      const float Mxx = -(gx * gx * Q0 - 2.f * gx * Qu + Quu);
+      const float Mxy = -(gx * gy * Q0 - gx * Qv - gy * Qu + Quv);
+      const float Myy = -(gy * gy * Q0 - 2.f * gy * Qv + Qvv);
       float* o = partials + P * TGS_PARTIAL_FLOATS;
-      st4(o, make_float4(hold[0], hold[1], hold[2], hold[3]));
-      st4(o + 4, make_float4(hold[4], hold[5], hold[6], hold[7]));
-      st4(o + 8, make_float4(hold[8], hold[9], 0.f, 0.f));
+      // {v_x, v_y, v_depth, v_opacity, v_a, v_b, v_c, v_r, v_g, v_b}
+      st4(o, make_float4(A * Mx + B * My, B * Mx + Cc * My, s0.w, Q0 / a0.w));
+      st4(o + 4, make_float4(0.5f * Mxx, Mxy, 0.5f * Myy, s0.x));
+      st4(o + 8, make_float4(s0.y, s0.z, 0.f, 0.f));
     }
   }
 }

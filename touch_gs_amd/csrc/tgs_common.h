@@ -79,8 +79,7 @@ static inline bool camera_ok(const TgsCamera* c) {
 // ---------------------------------------------------------------------------------------------
 #ifdef __HIPCC__
 
-// App. B.4 tile rectangle.  ONE definition shared by every kernel so that the pair index of a
-// (tile, Gaussian) intersection is computed identically everywhere.
+// App. B.4 tile rectangle (the normative 3-sigma rule).
 __device__ __forceinline__ void tile_rect(float u, float v, int radius, int TW, int TH,
                                           int& x0, int& y0, int& x1, int& y1) {
   const float r = (float)radius;
@@ -89,6 +88,16 @@ __device__ __forceinline__ void tile_rect(float u, float v, int radius, int TW, 
   x1 = min(max((int)((u + r) * inv) + 1, 0), TW);
   y0 = min(max((int)((v - r) * inv), 0), TH);
   y1 = min(max((int)((v + r) * inv) + 1, 0), TH);
+}
+
+// Splat slot 10 holds the Gaussian's tile rectangle packed as x0 | y0<<8 | w<<16 | h<<24
+// (image sides are limited to 255 tiles = 4080 px).  It is the B.4 rect intersected with the
+// tiles that contain at least one pixel where alpha can reach 1/255 (output preserving).
+__device__ __forceinline__ unsigned pack_rect(int x0, int y0, int w, int h) {
+  return (unsigned)x0 | ((unsigned)y0 << 8) | ((unsigned)w << 16) | ((unsigned)h << 24);
+}
+__device__ __forceinline__ void unpack_rect(unsigned r, int& x0, int& y0, int& w, int& h) {
+  x0 = r & 255u; y0 = (r >> 8) & 255u; w = (r >> 16) & 255u; h = r >> 24;
 }
 
 // wave64 sum via DPP (no LDS, no ds_bpermute).  Total lands in lane 63; the helper returns it

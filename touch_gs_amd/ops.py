@@ -75,17 +75,19 @@ _default_budget = IntersectBudget()
 # ------------------------------------------------------------------------------------------------
 # thin wrappers (one per C entry point)
 # ------------------------------------------------------------------------------------------------
-def project_fwd(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_deg: int, colors=None):
-    """K1 -> splats [N,12].  (tgs_project_fwd)"""
+def project_fwd(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_deg: int, colors=None,
+                want_radii: bool = False):
+    """K1 -> splats [N,12] (, radii int32 [N]).  (tgs_project_fwd)"""
     lib = _lib.load()
     N = means.shape[0]
     splats = torch.empty(N, SPLAT_FLOATS, dtype=torch.float32, device=means.device)
+    radii = torch.empty(N, dtype=torch.int32, device=means.device) if want_radii else None
     cs = cam.c_struct()
     sh_stride = sh.shape[1] if sh is not None else 0
     check(lib.tgs_project_fwd(C.byref(cs), N, ptr(means), ptr(log_scales), ptr(quats), ptr(opac_logit),
                               ptr(sh), sh_stride, sh_deg if sh is not None else -1, ptr(colors),
-                              ptr(splats), _stream()), "tgs_project_fwd")
-    return splats
+                              ptr(splats), ptr(radii), _stream()), "tgs_project_fwd")
+    return (splats, radii) if want_radii else splats
 
 
 def bin_sort(cam: Camera, splats, budget: Optional[IntersectBudget] = None):
@@ -209,7 +211,7 @@ class _Render(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, log_scales, quats, opac_logit, sh, means2d, cam, sh_deg, budget):
         means, log_scales, quats, opac_logit, sh = map(_f32c, (means, log_scales, quats, opac_logit, sh))
-        splats = project_fwd(cam, means, log_scales, quats, opac_logit, sh, sh_deg)
+        splats, radii = project_fwd(cam, means, log_scales, quats, opac_logit, sh, sh_deg, want_radii=True)
         group_base, tile_start, sorted_gid, _ = bin_sort(cam, splats, budget)
         rgb, depth, fT, fidx = rasterize_fwd(cam, splats, sorted_gid, tile_start)
         ctx.cam, ctx.sh_deg = cam, sh_deg
@@ -217,7 +219,6 @@ class _Render(torch.autograd.Function):
         ctx.save_for_backward(means, log_scales, quats, opac_logit, sh, splats, group_base,
                               tile_start, sorted_gid, rgb, depth, fT, fidx)
         alpha = 1.0 - fT
-        radii = splats[:, 10].view(torch.int32)
         ctx.mark_non_differentiable(radii)
         return rgb, depth, alpha, radii
 
@@ -293,13 +294,12 @@ class _ProjectGaussians(torch.autograd.Function):
         zero = torch.zeros(N, dtype=torch.float32, device=means3d.device)
         cam = Camera(cam.viewmat, cam.fx, cam.fy, cam.cx, cam.cy, cam.W, cam.H, cam.near,
                      cam.pix_center, cam.bg, float(glob_scale))
-        splats = project_fwd(cam, means3d, log_scales, quats, zero, None, -1)
+        splats, radii = project_fwd(cam, means3d, log_scales, quats, zero, None, -1, want_radii=True)
         ctx.cam = cam
         ctx.save_for_backward(means3d, log_scales, quats, zero, splats)
         xys = splats[:, 0:2].contiguous()
         depths = splats[:, 2].contiguous()
         conics = splats[:, 4:7].contiguous()
-        radii = splats[:, 10].contiguous().view(torch.int32)
         ctx.mark_non_differentiable(radii)
         return xys, depths, radii, conics
 
