@@ -168,7 +168,7 @@ def main():
             e[3].record()
             ssim_sum, v_img = ops.ssim_fwd_bwd(rgb, view.rgb, weight=-cfg.ssim_lambda / (3 * H * W))
             e[4].record()
-            partials, tl = ops.rasterize_bwd(view.cam, sp, gb, sg, ts, rgb, dacc, fT, fidx, v_rgb=v_img,
+            partials, tl = ops.rasterize_bwd(view.cam, sp, gb, sg, ts, rgb, dacc, fT, v_rgb=v_img,
                                              loss=model.loss_spec(view), want_tile_loss=True)
             e[5].record()
             ops.project_bwd(view.cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, sp, gb, partials,

@@ -116,7 +116,8 @@ int tgs_bin_sort(const TgsCamera* cam /*[host]*/, int N, float* splats, int32_t*
 /* K6  per-tile front-to-back compositing of RGB + depth in ONE pass  (stands behind gsplat
  *     `rasterize_gaussians` fwd, called twice by Splatfacto for rgb and depth; spec App. B.6).
  * out: out_rgb[H,W,3] (incl. background)  out_depth[H,W] (= sum w*depth, NOT divided by alpha)
- *      final_T[H,W]  final_idx[H,W] (list position of the last contributor, -1 if none) */
+ *      final_T[H,W]  final_idx[H,W] (list position of the last contributor, -1 if none; may be
+ *      NULL -- the backward does not need it) */
 int tgs_rasterize_fwd(const TgsCamera* cam /*[host]*/, const float* splats,
                       const int32_t* sorted_gid, const int32_t* tile_start,
                       float* out_rgb, float* out_depth, float* final_T, int32_t* final_idx,
@@ -124,7 +125,8 @@ int tgs_rasterize_fwd(const TgsCamera* cam /*[host]*/, const float* splats,
 
 /* K7  compositing backward with the tactile depth/uncertainty loss fused in  (stands behind
  *     gsplat `rasterize_gaussians` bwd; spec App. B.7).
- * in : v_rgb[H,W,3] v_depth[H,W] v_alpha[H,W] upstream grads (each may be NULL);
+ * in : out_rgb, out_depth, final_T of the forward (required);
+ *      v_rgb[H,W,3] v_depth[H,W] v_alpha[H,W] upstream grads (each may be NULL);
  *      loss (may be NULL) adds dL/d(out) of the fused loss computed from out_rgb/out_depth/final_T;
  * out: partials[#intersections,12] one record per (tile,Gaussian) pair, addressed by the pair's
  *      pre-sort index = group_base[g/256] + splat[g].slot11 + index of the tile in g's rect:
@@ -133,7 +135,7 @@ int tgs_rasterize_fwd(const TgsCamera* cam /*[host]*/, const float* splats,
 int tgs_rasterize_bwd(const TgsCamera* cam /*[host]*/, const float* splats,
                       const int32_t* group_base, const int32_t* sorted_gid,
                       const int32_t* tile_start, const float* out_rgb, const float* out_depth,
-                      const float* final_T, const int32_t* final_idx,
+                      const float* final_T,
                       const float* v_rgb, const float* v_depth, const float* v_alpha,
                       const TgsLossSpec* loss /*[host]*/, float* partials, float* tile_loss,
                       void* stream);

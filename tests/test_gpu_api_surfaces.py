@@ -1,0 +1,165 @@
+"""GPU tests of the drop-in operator surfaces: gsplat-0.1 shaped ops, INRIA-shaped
+GaussianRasterizer, the Splatfacto-style model (autograd path == fused path) and the trainer."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_oracle as O
+from tests.util import amd_cam, relerr, scene, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gsplat_shaped_ops_match_fused_path_and_oracle(dev):
+    from touch_gs_amd import ops
+    N, W, H, deg = 3000, 160, 96, 3
+    P, cam = scene(N, W, H, deg, 101)
+    acam = amd_cam(cam)
+    D = {k: v.requires_grad_(True) for k, v in to_dev(P, dev).items()}
+    viewmat = torch.from_numpy(cam.viewmat.numpy()).float().to(dev)
+    # --- the way Splatfacto calls the ops ---
+    scales = torch.exp(D["log_scales"])
+    xys, depths, radii, conics, comp, num_tiles_hit, cov3d = ops.project_gaussians(
+        D["means"], scales, 1.0, D["quats"], viewmat, cam.fx, cam.fy, cam.cx, cam.cy, H, W, 16)
+    campos = torch.from_numpy(cam.campos().numpy()).float().to(dev)
+    viewdirs = D["means"].detach() - campos
+    rgbs = torch.clamp(ops.spherical_harmonics(deg, viewdirs, D["sh"]) + 0.5, min=0.0)
+    bg = torch.tensor(cam.bg, device=dev)
+    rgb, alpha = ops.rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, rgbs, torch.sigmoid(D["opac_logit"])[:, None],
+                                         H, W, 16, background=bg, return_alpha=True)
+    depth_im = ops.rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, depths[:, None].repeat(1, 3),
+                                       torch.sigmoid(D["opac_logit"])[:, None], H, W, 16,
+                                       background=torch.zeros(3, device=dev))[..., 0]
+    assert cov3d.shape == (N, 6) and comp.shape == (N,) and num_tiles_hit.dtype == torch.int32
+    # --- fused path on the same parameters ---
+    D2 = {k: v.detach().clone().requires_grad_(True) for k, v in D.items()}
+    rgb2, dacc2, alpha2, radii2 = ops.render(D2["means"], D2["log_scales"], D2["quats"], D2["opac_logit"], D2["sh"], acam, deg)
+    assert torch.equal(radii, radii2)
+    assert torch.allclose(rgb, rgb2, atol=2e-5) and torch.allclose(alpha, alpha2, atol=2e-5)
+    assert torch.allclose(depth_im, dacc2, atol=2e-4, rtol=1e-4)
+    # --- gradients through the two-op path equal the fused path's ---
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(H, W, 3, generator=g).to(dev)
+    wd = torch.randn(H, W, generator=g).to(dev)
+    ((rgb * w).sum() + (depth_im * wd).sum()).backward()
+    ((rgb2 * w).sum() + (dacc2 * wd).sum()).backward()
+    for k in D:
+        if k == "means":  # the stand-alone SH op is fed detached view directions (as gsplat callers do)
+            continue
+        a, b = D[k].grad, D2[k].grad
+        assert (a - b).abs().max().item() < 2e-3 * b.abs().max().item() + 1e-6, k
+    # --- and the oracle ---
+    out, *_ = O.render(P["means"], P["log_scales"], P["quats"], P["opac_logit"], P["sh"], cam, deg)
+    e = relerr(rgb.detach().cpu().numpy(), out["rgb"].detach().numpy(), floor=1e-2)
+    assert np.quantile(e, 0.99) < 1e-4
+
+
+def test_inria_shaped_rasterizer(dev):
+    from touch_gs_amd import ops
+    from touch_gs_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    N, W, H, deg = 2000, 128, 80, 2
+    P, cam = scene(N, W, H, deg, 111)
+    D = to_dev(P, dev)
+    V = torch.from_numpy(cam.viewmat.numpy()).float().to(dev)
+    tanfovx, tanfovy = W / (2 * cam.fx), H / (2 * cam.fy)
+    rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=tanfovx, tanfovy=tanfovy,
+                                       bg=torch.tensor(cam.bg, device=dev), scale_modifier=1.0,
+                                       viewmatrix=V.T.contiguous(), projmatrix=torch.eye(4, device=dev), sh_degree=deg,
+                                       campos=torch.from_numpy(cam.campos().numpy()).float().to(dev))
+    means = D["means"].clone().requires_grad_(True)
+    means2D = torch.zeros(N, 3, device=dev, requires_grad=True)
+    opac = torch.sigmoid(D["opac_logit"])[:, None].clone().requires_grad_(True)
+    scales = torch.exp(D["log_scales"]).clone().requires_grad_(True)
+    rot = torch.nn.functional.normalize(D["quats"]).clone().requires_grad_(True)
+    shs = D["sh"].clone().requires_grad_(True)
+    color, radii, depth, alpha = GaussianRasterizer(rs, return_depth=True)(means, means2D, opac, shs=shs, scales=scales, rotations=rot)
+    assert color.shape == (3, H, W) and radii.shape == (N,)
+    out, pr, *_ = O.render(P["means"], P["log_scales"], P["quats"], P["opac_logit"], P["sh"], cam, deg)
+    e = relerr(color.permute(1, 2, 0).detach().cpu().numpy(), out["rgb"].detach().numpy(), floor=1e-2)
+    assert np.quantile(e, 0.99) < 1e-4
+    color.sum().backward()
+    assert means2D.grad is not None and means2D.grad[:, :2].abs().sum() > 0 and float(means2D.grad[:, 2].abs().sum()) == 0
+    assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in (means, opac, scales, rot, shs))
+    # colours_precomp path == SH degree 0 with the same colours
+    cols = torch.rand(N, 3, device=dev)
+    c1, _ = GaussianRasterizer(rs)(means.detach(), None, opac.detach(), colors_precomp=cols, scales=scales.detach(), rotations=rot.detach())
+    sh0 = ((cols - 0.5) / 0.28209479177387814)[:, None, :].contiguous()
+    rs0 = rs._replace(sh_degree=0)
+    c2, _ = GaussianRasterizer(rs0)(means.detach(), None, opac.detach(), shs=sh0, scales=scales.detach(), rotations=rot.detach())
+    assert torch.allclose(c1, c2, atol=1e-6)
+    with pytest.raises(Exception):
+        GaussianRasterizer(rs)(means, means2D, opac, scales=scales, rotations=rot)
+
+
+def test_model_autograd_path_equals_fused_path(dev):
+    from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig, View
+    from touch_gs_amd.optim import GaussianParams
+    N, W, H, deg = 3000, 160, 96, 3
+    P, cam = scene(N, W, H, deg, 121)
+    g = torch.Generator().manual_seed(5)
+    view = View(cam=amd_cam(cam), rgb=torch.rand(H, W, 3, generator=g).to(dev),
+                depth=(torch.rand(H, W, generator=g) * 5 * (torch.rand(H, W, generator=g) > 0.3)).to(dev),
+                uncertainty=(torch.rand(H, W, generator=g) * 5 + 1e-3).to(dev))
+    for loss_type, mult, uw in (("DEPTH_UNCERTAINTY_WEIGHTED_LOSS", 0.2, 1.0), ("SIMPLE_LOSS", 0.5, 1.0),
+                                ("DEPTH_UNCERTAINTY_WEIGHTED_LOSS", 0.005, 0.01)):  # the reference's three settings
+        cfg = ModelConfig(sh_degree=deg, sh_degree_interval=0, depth_loss_mult=mult, depth_loss_type=loss_type,
+                          uncertainty_weight=uw)
+        params = GaussianParams.from_tensors(*[P[k].float().to(dev) for k in GaussianParams.NAMES])
+        model = DepthGaussianSplattingModel(cfg, params)
+        tl, ss = model.forward_backward(view)
+        fused = {k: float(v) for k, v in model.loss_from(tl, ss, view).items()}
+        fused_grads = {k: params.g[k].clone() for k in GaussianParams.NAMES}
+        leaves = [getattr(params, k).detach().clone().requires_grad_(True) for k in GaussianParams.NAMES]
+        p2 = GaussianParams.from_tensors(*[t.detach() for t in leaves])
+        for k, t in zip(GaussianParams.NAMES, leaves):
+            setattr(p2, k, t)
+        m2 = DepthGaussianSplattingModel(cfg, p2)
+        out = m2.get_outputs(view.cam)
+        ld = m2.get_loss_dict(out, view)
+        sum(ld.values()).backward()
+        assert abs(float(ld["main_loss"]) - fused["main_loss"]) < 1e-4 * abs(fused["main_loss"])
+        assert abs(float(ld["depth_loss"]) - fused["depth_loss"]) < 1e-4 * abs(fused["depth_loss"]) + 1e-9
+        for k, t in zip(GaussianParams.NAMES, leaves):
+            scale = fused_grads[k].abs().max().item()
+            assert (t.grad - fused_grads[k]).abs().max().item() < 5e-4 * scale, (loss_type, k)
+        md = m2.get_metrics_dict(out, view)
+        assert "psnr" in md and "depth_mse" in md
+        metrics, images = m2.get_image_metrics_and_images(out, view)
+        assert {"psnr", "ssim", "depth_mse", "supervised_depth_mse"} <= set(metrics) and "img" in images
+
+
+def test_training_reduces_loss_and_checkpoint_roundtrip(dev, tmp_path):
+    from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
+    from touch_gs_amd.optim import GaussianParams
+    from touch_gs_amd.scene import make_view, synthetic_gaussians
+    N, W, H, deg = 5000, 160, 96, 1
+    views = [make_view(N, W, H, deg, 7, dev, view=v, n_views=4) for v in range(4)]
+    P, _ = synthetic_gaussians(N, W, H, deg, 99)
+    params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
+    model = DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=0, lr_means=2e-3), params)
+    losses = []
+    for step in range(60):
+        v = views[step % 4]
+        model.train_step(v)
+        if step % 4 == 0:
+            losses.append(sum(float(x) for x in model.loss_from(model.last["tile_loss"], model.last["ssim_sum"], v).values()))
+    assert losses[-1] < 0.9 * losses[0], losses
+    sd = model.state_dict()
+    torch.save(sd, tmp_path / "m.ckpt")
+    p2 = GaussianParams.allocate(N, (deg + 1) ** 2, dev)
+    m2 = DepthGaussianSplattingModel(model.config, p2)
+    m2.load_state_dict(torch.load(tmp_path / "m.ckpt"))
+    assert torch.equal(p2.flat, params.flat) and m2.step == model.step
+    model.train_step(views[0]); m2.train_step(views[0])
+    assert torch.equal(p2.flat, params.flat)  # deterministic kernels: identical continuation
+
+
+def test_trainer_cli_synthetic(dev, tmp_path):
+    from touch_gs_amd import train
+    run = train.main(["--synthetic", "3000", "128", "80", "--max-num-iterations", "12", "--steps-per-eval", "6",
+                      "--steps-per-save", "12", "--sh-degree", "1", "--output-dir", str(tmp_path)])
+    import json, os
+    ev = json.load(open(os.path.join(run, "eval.json")))
+    assert {"psnr", "ssim", "depth_mse"} <= set(ev["results"]) and os.path.exists(os.path.join(run, "step-000000012.ckpt"))

@@ -81,7 +81,9 @@ def _blend_inputs(dev, N, W, H, deg, seed, **kw):
 def test_rasterize_fwd(dev, N, W, H, deg, seed):
     from touch_gs_amd import ops
     P, cam, acam, D, sp, gb, ts, sg, n = _blend_inputs(dev, N, W, H, deg, seed)
-    rgb, depth, fT, fidx = ops.rasterize_fwd(acam, sp, sg, ts)
+    rgb, depth, fT, fidx = ops.rasterize_fwd(acam, sp, sg, ts, want_idx=True)
+    rgb2, depth2, fT2, none_idx = ops.rasterize_fwd(acam, sp, sg, ts)
+    assert none_idx is None and torch.equal(rgb, rgb2) and torch.equal(depth, depth2) and torch.equal(fT, fT2)
     f = splat_fields(sp)
     out = O.blend(f["xy"], f["conic"], f["opac"], f["rgb"], f["depth"],
                   sg[:n].cpu().numpy().astype(np.int64), ts.cpu().numpy().astype(np.int64), cam, want_margin=True)
@@ -105,7 +107,7 @@ def test_rasterize_bwd(dev, N, W, H, deg, seed):
     v_rgb = torch.randn(H, W, 3, generator=g, dtype=torch.float64)
     v_d = torch.randn(H, W, generator=g, dtype=torch.float64)
     v_a = torch.randn(H, W, generator=g, dtype=torch.float64)
-    partials, _ = ops.rasterize_bwd(acam, sp, gb, sg, ts, rgb, depth, fT, fidx,
+    partials, _ = ops.rasterize_bwd(acam, sp, gb, sg, ts, rgb, depth, fT,
                                     v_rgb.float().to(dev), v_d.float().to(dev), v_a.float().to(dev))
     v = ops.reduce_partials(acam, sp, gb, partials).cpu().double()
     f = splat_fields(sp)
@@ -125,7 +127,7 @@ def test_rasterize_bwd(dev, N, W, H, deg, seed):
         # ambiguous threshold decisions (1 - frac_clear of them) perturb a few entries
         bad = (err > 1e-3 * scale + 1e-4 * ref[k].abs()).double().mean().item()
         assert bad < 0.02 + 5 * (1 - frac_clear), (k, bad, frac_clear)
-        assert np.median(relerr(got[k].numpy(), ref[k].numpy(), floor=1e-3 * scale)) < 1e-5, k
+        assert np.median(relerr(got[k].numpy(), ref[k].numpy(), floor=1e-3 * scale)) < 3e-5, k
 
 
 @pytest.mark.parametrize("N,W,H,deg,seed", [(1500, 128, 80, 3, 31), (400, 64, 48, 2, 32), (400, 64, 48, 0, 33)])
@@ -222,7 +224,7 @@ def test_fused_loss_matches_autograd_path(dev):
         cnt = int((dgt > 0).sum())
         spec = dict(gt_rgb=gt, gt_depth=dgt, uncertainty=unc if loss_type != "SIMPLE_LOSS" else None,
                     l1_weight=1.0 / (3 * H * W), depth_weight=0.3 / cnt, uncertainty_weight=uw, eps=1e-6)
-        partials, tl = ops.rasterize_bwd(acam, sp, gb, sg, ts, r2, d2, fT, fidx, loss=spec, want_tile_loss=True)
+        partials, tl = ops.rasterize_bwd(acam, sp, gb, sg, ts, r2, d2, fT, loss=spec, want_tile_loss=True)
         vm, vls, vq, vol, vsh, _ = ops.project_bwd(acam, D["means"], D["log_scales"], D["quats"], D["opac_logit"],
                                                    D["sh"], deg, sp, gb, partials)
         assert abs(tl.sum().item() - L.item()) < 1e-4 * abs(L.item())

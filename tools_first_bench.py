@@ -30,7 +30,8 @@ def run(N, W, H, deg, seed, iters=10):
     sp = T(lambda: ops.project_fwd(cam, D['means'], D['log_scales'], D['quats'], D['opac_logit'], D['sh'], deg), 'project_fwd')
     gb, ts, sg, st = T(lambda: ops.bin_sort(cam, sp, budget), 'bin_sort')
     rgb, depth, fT, fidx = T(lambda: ops.rasterize_fwd(cam, sp, sg, ts), 'raster_fwd')
-    partials, tl = T(lambda: ops.rasterize_bwd(cam, sp, gb, sg, ts, rgb, depth, fT, fidx, loss=spec, want_tile_loss=True), 'raster_bwd')
+    fidx = ops.rasterize_fwd(cam, sp, sg, ts, want_idx=True)[3]
+    partials, tl = T(lambda: ops.rasterize_bwd(cam, sp, gb, sg, ts, rgb, depth, fT, loss=spec, want_tile_loss=True), 'raster_bwd')
     T(lambda: ops.project_bwd(cam, D['means'], D['log_scales'], D['quats'], D['opac_logit'], D['sh'], deg, sp, gb, partials), 'project_bwd')
     T(lambda: ops.ssim_fwd_bwd(rgb, gt, -0.2/(3*H*W)), 'ssim')
     print('  alpha mean', float((1-fT).mean()), 'mean last idx', float(fidx.float().mean()))

@@ -175,18 +175,21 @@ __device__ __forceinline__ int next_pow2(int n) {
 // One workgroup per tile; tiles whose list length is outside (LO, CAP] belong to another class.
 template <int CAP, int THREADS, int LO>
 __global__ __launch_bounds__(THREADS) void k_sort_tiles_lds(
-    const int32_t* __restrict__ tile_start, const unsigned long long* __restrict__ pairs,
+    int T, const int32_t* __restrict__ tile_start, const unsigned long long* __restrict__ pairs,
     int32_t* __restrict__ sorted_gid) {
   __shared__ unsigned long long keys[CAP];
-  const int tile = blockIdx.x;
+  const int tid = threadIdx.x;
+  // grid-stride over tiles: the rare long-list classes are launched with a small grid so that an
+  // empty class costs ~2 us instead of a full grid of 128-KB-LDS workgroups
+  for (int tile = blockIdx.x; tile < T; tile += gridDim.x) {
   const int s = tile_start[tile];
   const int n = tile_start[tile + 1] - s;
-  if (n <= LO || n > CAP) return;
-  const int tid = threadIdx.x;
+  if (n <= LO || n > CAP) continue;
   if (n == 1) {
     if (tid == 0) sorted_gid[s] = (int)(pairs[s] & 0xffffffffull);
-    return;
+    continue;
   }
+  __syncthreads();  // keys[] reuse across iterations
   const int np2 = next_pow2(n);
   for (int i = tid; i < np2; i += THREADS) keys[i] = (i < n) ? pairs[s + i] : ~0ull;
   __syncthreads();
@@ -203,19 +206,20 @@ __global__ __launch_bounds__(THREADS) void k_sort_tiles_lds(
     }
   }
   for (int i = tid; i < n; i += THREADS) sorted_gid[s + i] = (int)(keys[i] & 0xffffffffull);
+  }
 }
 
 // Fallback for lists longer than the largest LDS class: the same network in global memory, on a
 // power-of-two padded copy at fb[2*s ...) (next_pow2(n) < 2n, so per-tile regions never overlap).
 template <int LO>
 __global__ __launch_bounds__(1024) void k_sort_tiles_global(
-    const int32_t* __restrict__ tile_start, const unsigned long long* __restrict__ pairs,
+    int T, const int32_t* __restrict__ tile_start, const unsigned long long* __restrict__ pairs,
     unsigned long long* __restrict__ fb, int32_t* __restrict__ sorted_gid) {
-  const int tile = blockIdx.x;
+  const int tid = threadIdx.x;
+  for (int tile = blockIdx.x; tile < T; tile += gridDim.x) {
   const int s = tile_start[tile];
   const int n = tile_start[tile + 1] - s;
-  if (n <= LO) return;
-  const int tid = threadIdx.x;
+  if (n <= LO) continue;
   const int np2 = next_pow2(n);
   unsigned long long* keys = fb + 2 * (size_t)s;
   for (int i = tid; i < np2; i += 1024) keys[i] = (i < n) ? pairs[s + i] : ~0ull;
@@ -234,6 +238,7 @@ __global__ __launch_bounds__(1024) void k_sort_tiles_global(
     }
   }
   for (int i = tid; i < n; i += 1024) sorted_gid[s + i] = (int)(keys[i] & 0xffffffffull);
+  }
 }
 
 constexpr int SORT_CAP_A = 2048;   // 16 KB LDS, 256 threads
@@ -280,14 +285,15 @@ extern "C" int tgs_bin_sort(const TgsCamera* cam, int N, float* splats, int32_t*
     hipLaunchKernelGGL(k_fill_bins, dim3(G), dim3(TGS_GROUP), 0, s, k, N, splats, group_base,
                        tile_start, rank, (uint2*)pairs, status);
     TGS_CHECK_LAUNCH();
-    hipLaunchKernelGGL((k_sort_tiles_lds<SORT_CAP_A, 256, 0>), dim3(T), dim3(256), 0, s,
+    const int small_grid = T < 256 ? T : 256;
+    hipLaunchKernelGGL((k_sort_tiles_lds<SORT_CAP_A, 256, 0>), dim3(T), dim3(256), 0, s, T,
                        tile_start, pairs, sorted_gid);
     TGS_CHECK_LAUNCH();
-    hipLaunchKernelGGL((k_sort_tiles_lds<SORT_CAP_B, 1024, SORT_CAP_A>), dim3(T), dim3(1024), 0, s,
-                       tile_start, pairs, sorted_gid);
+    hipLaunchKernelGGL((k_sort_tiles_lds<SORT_CAP_B, 1024, SORT_CAP_A>), dim3(small_grid),
+                       dim3(1024), 0, s, T, tile_start, pairs, sorted_gid);
     TGS_CHECK_LAUNCH();
-    hipLaunchKernelGGL((k_sort_tiles_global<SORT_CAP_B>), dim3(T), dim3(1024), 0, s, tile_start,
-                       pairs, fb, sorted_gid);
+    hipLaunchKernelGGL((k_sort_tiles_global<SORT_CAP_B>), dim3(small_grid), dim3(1024), 0, s, T,
+                       tile_start, pairs, fb, sorted_gid);
     TGS_CHECK_LAUNCH();
   }
   return TGS_OK;

@@ -13,19 +13,11 @@ namespace {
 
 struct AdamK {
   long long e_means, e_scales, e_quats, e_opac, e_total;  // start of the NEXT segment (elements)
-  int sh_row;                                             // 3*K floats per Gaussian in the SH block
+  unsigned sh_row;                                        // 3*K floats per Gaussian in the SH block
+  unsigned row_step;                                      // (4 * grid stride) mod sh_row
   float lr_means, lr_scales, lr_quats, lr_opac, lr_dc, lr_rest;
   float b1, b2, eps, ibc1, isq_bc2, gscale;
 };
-
-__device__ __forceinline__ float lr_of(const AdamK& a, long long e) {
-  if (e < a.e_means) return a.lr_means;
-  if (e < a.e_scales) return a.lr_scales;
-  if (e < a.e_quats) return a.lr_quats;
-  if (e < a.e_opac) return a.lr_opac;
-  const long long r = (e - a.e_opac) % a.sh_row;
-  return r < 3 ? a.lr_dc : a.lr_rest;
-}
 
 __device__ __forceinline__ void adam1(const AdamK& a, float lr, float& p, float g, float& m, float& v) {
   g *= a.gscale;
@@ -35,26 +27,39 @@ __device__ __forceinline__ void adam1(const AdamK& a, float lr, float& p, float 
   p -= lr * (m * a.ibc1) / denom;
 }
 
+// One float4 per thread per grid-stride iteration.  Segment starts are multiples of 4 floats, so
+// a float4 never straddles two parameter groups; inside the SH block the DC/rest split needs the
+// element's position in its 3K-float row, which is tracked incrementally (one 64-bit modulo per
+// thread when it first enters the block, none in the steady state).
 __global__ __launch_bounds__(256) void k_adam(AdamK a, float* __restrict__ p,
                                               const float* __restrict__ g, float* __restrict__ m,
                                               float* __restrict__ v) {
   const long long n4 = a.e_total >> 2;
   const long long stride = (long long)gridDim.x * blockDim.x;
+  unsigned r = 0;
+  bool in_sh = false;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    float4 P = ld4(p + 4 * i), G = ld4(g + 4 * i), M = ld4(m + 4 * i), V = ld4(v + 4 * i);
     const long long e = 4 * i;
-    adam1(a, lr_of(a, e), P.x, G.x, M.x, V.x);
-    adam1(a, lr_of(a, e + 1), P.y, G.y, M.y, V.y);
-    adam1(a, lr_of(a, e + 2), P.z, G.z, M.z, V.z);
-    adam1(a, lr_of(a, e + 3), P.w, G.w, M.w, V.w);
-    st4(p + 4 * i, P); st4(m + 4 * i, M); st4(v + 4 * i, V);
-  }
-  // tail (< 4 elements)
-  if (blockIdx.x == 0 && threadIdx.x < (a.e_total & 3)) {
-    const long long e = (n4 << 2) + threadIdx.x;
-    float P = p[e], M = m[e], V = v[e];
-    adam1(a, lr_of(a, e), P, g[e], M, V);
-    p[e] = P; m[e] = M; v[e] = V;
+    float4 P = ld4(p + e), G = ld4(g + e), M = ld4(m + e), V = ld4(v + e);
+    float l0, l1, l2, l3;
+    if (e < a.e_opac) {
+      const float lr = e < a.e_means ? a.lr_means : (e < a.e_scales ? a.lr_scales
+                                                  : (e < a.e_quats ? a.lr_quats : a.lr_opac));
+      l0 = l1 = l2 = l3 = lr;
+    } else {
+      if (!in_sh) { r = (unsigned)((e - a.e_opac) % a.sh_row); in_sh = true; }
+      else { r += a.row_step; r = r >= a.sh_row ? r - a.sh_row : r; }
+      const unsigned r1 = r + 1 >= a.sh_row ? r + 1 - a.sh_row : r + 1;
+      const unsigned r2 = r + 2 >= a.sh_row ? r + 2 - a.sh_row : r + 2;
+      const unsigned r3 = r + 3 >= a.sh_row ? r + 3 - a.sh_row : r + 3;
+      l0 = r < 3 ? a.lr_dc : a.lr_rest; l1 = r1 < 3 ? a.lr_dc : a.lr_rest;
+      l2 = r2 < 3 ? a.lr_dc : a.lr_rest; l3 = r3 < 3 ? a.lr_dc : a.lr_rest;
+    }
+    adam1(a, l0, P.x, G.x, M.x, V.x);
+    adam1(a, l1, P.y, G.y, M.y, V.y);
+    adam1(a, l2, P.z, G.z, M.z, V.z);
+    adam1(a, l3, P.w, G.w, M.w, V.w);
+    st4(p + e, P); st4(m + e, M); st4(v + e, V);
   }
 }
 
@@ -74,7 +79,7 @@ extern "C" int tgs_adam_step(int N, int sh_stride, float* params, const float* g
   a.e_scales = al4(a.e_means + 3ll * N);    // quats start
   a.e_quats = a.e_scales + 4ll * N;         // opac_logit start
   a.e_opac = al4(a.e_quats + N);            // sh start
-  a.sh_row = sh_stride > 0 ? 3 * sh_stride : 1;
+  a.sh_row = sh_stride > 0 ? 3u * (unsigned)sh_stride : 4u;
   a.e_total = al4(a.e_opac + (long long)N * sh_stride * 3);
   a.lr_means = spec->lr_means; a.lr_scales = spec->lr_scales; a.lr_quats = spec->lr_quats;
   a.lr_opac = spec->lr_opac; a.lr_dc = spec->lr_sh_dc; a.lr_rest = spec->lr_sh_rest;
@@ -86,6 +91,7 @@ extern "C" int tgs_adam_step(int N, int sh_stride, float* params, const float* g
   long long blocks = (n4 + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 blocks per CU
   if (blocks < 1) blocks = 1;
+  a.row_step = (unsigned)((4ll * blocks * 256) % a.sh_row);
   hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, params,
                      grads, exp_avg, exp_avg_sq);
   TGS_CHECK_LAUNCH();

@@ -16,7 +16,9 @@
 //    alpha >= 1/255).  The blend loop reads the record back as wave-uniform broadcast
 //    ds_read_b128 and skips whole quadrants with scalar branches; the per-pixel update is
 //    branch-free (v_cndmask), so the 4 pixels of a lane pipeline through the exp unit.
-//  * backward: per-pixel state is (T, S.v) only; each lane accumulates, over its <= 4 pixels,
+//  * backward: walks the list front to back like the forward (identical decisions, no stored
+//    last-contributor index, no T/(1-alpha) division chain); per-pixel state is (T, prefix.v)
+//    only; each lane accumulates, over its <= 4 pixels,
 //    10 sums per Gaussian (v_rgb, v_depth and the six pixel-coordinate moments of
 //    q = alpha * v_alpha); a multiplexed DPP butterfly (35 VALU ops for all 10 values instead of
 //    10 x 6) leaves value i in lane i, which drops it into an LDS transpose buffer; at the end
@@ -33,7 +35,6 @@ constexpr float ALPHA_MAX = 0.999f;
 constexpr float T_STOP = 1e-4f;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LOG2_255 = 7.994353436858858f;   // alpha >= 1/255  <=>  s <= log2(255)
-constexpr float LN2 = 0.6931471805599453f;
 
 __device__ __forceinline__ int xcd_tile(int b, int T) {
   const int q = (T + 7) >> 3;          // tiles per XCD band
@@ -70,19 +71,37 @@ __device__ __forceinline__ TileRec make_tile_rec(float4 r0, float4 r1, float4 r2
   t.b.y = 0.5f * LOG2E * Cc;
   t.b.z = L;
   t.b.w = r0.z;
-  // quadrant mask from the extents of {alpha >= 1/255}: |dx| <= sqrt(tau2 * Cov_xx)
+  // quadrant mask: does {alpha >= 1/255} = {s <= log2 255} reach any pixel centre of the 8x8
+  // quadrant?  Exact test: minimise the convex quadratic s over the quadrant's rectangle of pixel
+  // centres (interior point if the centre projects inside, else the best point on the 4 edges).
   unsigned mask = 0u;
-  const float tau2 = 2.0f * LN2 * (LOG2_255 - L);
-  const float det = A * Cc - B * B;
-  if (tau2 > 0.f && det > 0.f) {
-    const float idet = 1.0f / det;
-    const float ex = sqrtf(tau2 * Cc * idet) + 0.02f, ey = sqrtf(tau2 * A * idet) + 0.02f;
-    const bool x_lo = (gx + ex >= -7.5f) && (gx - ex <= -0.5f);
-    const bool x_hi = (gx + ex >= 0.5f) && (gx - ex <= 7.5f);
-    const bool y_lo = (gy + ey >= -7.5f) && (gy - ey <= -0.5f);
-    const bool y_hi = (gy + ey >= 0.5f) && (gy - ey <= 7.5f);
-    mask = (unsigned)(x_lo && y_lo) | ((unsigned)(x_hi && y_lo) << 1) |
-           ((unsigned)(x_lo && y_hi) << 2) | ((unsigned)(x_hi && y_hi) << 3);
+  const float slack = LOG2_255 + 1e-3f;
+  if (L < LOG2_255) {
+    const float c0 = t.a.x, c1 = t.a.y, c2 = t.a.z, c3 = t.a.w, c4 = t.b.x, c5 = t.b.y;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float u0 = (k & 1) ? 0.5f : -7.5f, u1 = u0 + 7.f;
+      const float v0 = (k >> 1) ? 0.5f : -7.5f, v1 = v0 + 7.f;
+      float best;
+      if (gx >= u0 && gx <= u1 && gy >= v0 && gy <= v1) {
+        best = L;  // the centre itself (s = L there) lies inside the rectangle
+      } else {
+        // edges v = const: s(u) = c3 u^2 + (c1 + c4 v) u + (c0 + c2 v + c5 v^2), minimised at clamped u*
+        best = 3.0e38f;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const float v = e ? v1 : v0;
+          const float lin = fmaf(c4, v, c1);
+          const float us = fminf(fmaxf(-0.5f * lin / c3, u0), u1);
+          best = fminf(best, fmaf(us, fmaf(c3, us, lin), fmaf(v, fmaf(c5, v, c2), c0)));
+          const float u = e ? u1 : u0;
+          const float lin2 = fmaf(c4, u, c2);
+          const float vs = fminf(fmaxf(-0.5f * lin2 / c5, v0), v1);
+          best = fminf(best, fmaf(vs, fmaf(c5, vs, lin2), fmaf(u, fmaf(c3, u, c1), c0)));
+        }
+      }
+      mask |= (best <= slack) ? (1u << k) : 0u;
+    }
   }
   t.c = make_float4(r1.w, r2.x, r2.y, __uint_as_float(mask));
   return t;
@@ -116,6 +135,22 @@ __device__ __forceinline__ float eval_s(const float4& a, const float4& b, const 
 // ---------------------------------------------------------------------------------------------
 // K6 forward
 // ---------------------------------------------------------------------------------------------
+// One compositing step of pixel slot k against the staged Gaussian (qa, qb, qc); shared verbatim
+// by the forward and the backward so that both take bit-identical threshold decisions.
+//   smax : log2(255) while the pixel is live, -inf once it has stopped (folds `live` into the
+//          alpha >= 1/255 test).  The sigma < 0 skip of App. B.6 cannot trigger: K1 only emits
+//          positive-definite conics, for which sigma >= 0 up to rounding.
+//   returns the contributing alpha (0 if skipped or if this Gaussian stops the pixel).
+__device__ __forceinline__ float blend_step(float s, float& T, float& smax, float& Tnew, bool& go) {
+  const float al = fminf(ALPHA_MAX, __builtin_amdgcn_exp2f(-s));
+  const bool ok = s <= smax;
+  Tnew = fmaf(-al, T, T);
+  go = ok & (Tnew > T_STOP);
+  smax = (ok & !go) ? -3.0e38f : smax;  // stop: T' <= 1e-4, this Gaussian excluded
+  return go ? al : 0.f;
+}
+
+template <bool WANT_IDX>
 __global__ __launch_bounds__(64) void k_raster_fwd(
     CamK cam, int T_total, const float* __restrict__ splats, const int32_t* __restrict__ sorted_gid,
     const int32_t* __restrict__ tile_start, float* __restrict__ out_rgb,
@@ -128,12 +163,12 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
   const float tcy = (float)(ty * TGS_BLOCK + 8) - 0.5f + cam.pix_center;
   const PixConst pc = make_pix_const(lane);
   int pxi[4], pyi[4];
-  bool live[4];
+  float smax[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     pxi[k] = tx * TGS_BLOCK + 8 * (k & 1) + (lane & 7);
     pyi[k] = ty * TGS_BLOCK + 8 * (k >> 1) + (lane >> 3);
-    live[k] = (pxi[k] < cam.W) && (pyi[k] < cam.H);
+    smax[k] = ((pxi[k] < cam.W) && (pyi[k] < cam.H)) ? LOG2_255 : -3.0e38f;
   }
   float T[4] = {1.f, 1.f, 1.f, 1.f};
   float Cr[4] = {0.f, 0.f, 0.f, 0.f}, Cg[4] = {0.f, 0.f, 0.f, 0.f}, Cb[4] = {0.f, 0.f, 0.f, 0.f};
@@ -153,7 +188,7 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
   for (int base = start; base < end; base += 64) {
     unsigned slot_live = 0u;
 #pragma unroll
-    for (int k = 0; k < 4; k++) slot_live |= (__ballot(live[k]) != 0ull) ? (1u << k) : 0u;
+    for (int k = 0; k < 4; k++) slot_live |= (__ballot(smax[k] > 0.f) != 0ull) ? (1u << k) : 0u;
     if (slot_live == 0u) break;
     __syncthreads();
     if (base + lane < end) {
@@ -176,18 +211,13 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
       for (int k = 0; k < 4; k++) {
         if (m & (1u << k)) {  // wave-uniform
           const float s = eval_s(qa, qb, pc, k);
-          const bool valid = live[k] & (s >= qb.z) & (s <= LOG2_255);
-          float al = fminf(ALPHA_MAX, __builtin_amdgcn_exp2f(-s));
-          al = valid ? al : 0.f;
-          const float Tn = fmaf(-al, T[k], T[k]);
-          const bool stop = valid & (Tn <= T_STOP);
-          float w = al * T[k];
-          w = stop ? 0.f : w;
+          float Tn; bool go;
+          const float al = blend_step(s, T[k], smax[k], Tn, go);
+          const float w = al * T[k];
           Cr[k] = fmaf(w, qc.x, Cr[k]); Cg[k] = fmaf(w, qc.y, Cg[k]);
           Cb[k] = fmaf(w, qc.z, Cb[k]); D[k] = fmaf(w, qb.w, D[k]);
-          T[k] = stop ? T[k] : Tn;
-          last[k] = (valid & !stop) ? pos : last[k];
-          live[k] = live[k] & !stop;
+          T[k] = go ? Tn : T[k];
+          if (WANT_IDX) last[k] = go ? pos : last[k];
         }
       }
     }
@@ -201,7 +231,7 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
       out_rgb[3 * p + 2] = Cb[k] + T[k] * cam.bg[2];
       out_depth[p] = D[k];
       final_T[p] = T[k];
-      final_idx[p] = last[k];
+      if (WANT_IDX) final_idx[p] = last[k];
     }
   }
 }
@@ -251,10 +281,9 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
     CamK cam, int T_total, const float* __restrict__ splats, const int32_t* __restrict__ group_base,
     const int32_t* __restrict__ sorted_gid, const int32_t* __restrict__ tile_start,
     const float* __restrict__ out_rgb, const float* __restrict__ out_depth,
-    const float* __restrict__ final_T, const int32_t* __restrict__ final_idx,
-    const float* __restrict__ v_rgb, const float* __restrict__ v_depth,
-    const float* __restrict__ v_alpha, LossK loss, float* __restrict__ partials,
-    float* __restrict__ tile_loss) {
+    const float* __restrict__ final_T, const float* __restrict__ v_rgb,
+    const float* __restrict__ v_depth, const float* __restrict__ v_alpha, LossK loss,
+    float* __restrict__ partials, float* __restrict__ tile_loss) {
   const int tile = xcd_tile(blockIdx.x, T_total);
   if (tile >= T_total) return;
   const int lane = threadIdx.x;
@@ -266,27 +295,32 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
   const int n = end - start;
   const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
 
-  float T[4], Sv[4] = {0.f, 0.f, 0.f, 0.f}, vCr[4], vCg[4], vCb[4], vD[4], vAT[4];
-  int last[4];
+  // The list is walked FRONT TO BACK exactly like the forward (same blend_step, hence the same
+  // transmittance sequence and the same threshold decisions); the colour accumulated BEHIND a
+  // Gaussian, which B.7 needs, is (final colour - prefix), both projected on the pixel's upstream
+  // gradient:  S.v = Cv_total - Pv.   Per-pixel state: T, Pv, smax.
+  float T[4] = {1.f, 1.f, 1.f, 1.f}, Pv[4] = {0.f, 0.f, 0.f, 0.f};
+  float smax[4], vCr[4], vCg[4], vCb[4], vD[4], X[4];  // X = T_final*(v_A - bg.v_C) - Cv_total
   float l_l1 = 0.f, l_dep = 0.f;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int px = tx * TGS_BLOCK + 8 * (k & 1) + (lane & 7);
     const int py = ty * TGS_BLOCK + 8 * (k >> 1) + (lane >> 3);
-    T[k] = 1.f; vCr[k] = vCg[k] = vCb[k] = vD[k] = vAT[k] = 0.f; last[k] = -1;
+    smax[k] = -3.0e38f; vCr[k] = vCg[k] = vCb[k] = vD[k] = X[k] = 0.f;
     if (px < cam.W && py < cam.H) {
+      smax[k] = LOG2_255;
       const size_t p = (size_t)py * cam.W + px;
       const float Tf = final_T[p];
-      T[k] = Tf;
-      last[k] = final_idx[p];
+      const float o0 = out_rgb[3 * p], o1 = out_rgb[3 * p + 1], o2 = out_rgb[3 * p + 2];
+      const float od = out_depth[p];
       float vA = v_alpha ? v_alpha[p] : 0.f;
       if (v_rgb) { vCr[k] = v_rgb[3 * p]; vCg[k] = v_rgb[3 * p + 1]; vCb[k] = v_rgb[3 * p + 2]; }
       if (v_depth) vD[k] = v_depth[p];
       if (loss.on) {
         if (loss.gt_rgb) {
-          const float d0 = out_rgb[3 * p] - loss.gt_rgb[3 * p];
-          const float d1 = out_rgb[3 * p + 1] - loss.gt_rgb[3 * p + 1];
-          const float d2 = out_rgb[3 * p + 2] - loss.gt_rgb[3 * p + 2];
+          const float d0 = o0 - loss.gt_rgb[3 * p];
+          const float d1 = o1 - loss.gt_rgb[3 * p + 1];
+          const float d2 = o2 - loss.gt_rgb[3 * p + 2];
           vCr[k] += loss.l1w * ((d0 > 0.f) - (d0 < 0.f));
           vCg[k] += loss.l1w * ((d1 > 0.f) - (d1 < 0.f));
           vCb[k] += loss.l1w * ((d2 > 0.f) - (d2 < 0.f));
@@ -297,7 +331,7 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
           if (gd > 0.f) {
             const float alpha = fmaxf(1.f - Tf, 1e-10f);
             const float ia = 1.0f / alpha;
-            const float dhat = out_depth[p] * ia;
+            const float dhat = od * ia;
             const float r = dhat - gd;
             float wgt = loss.dw;
             if (loss.unc) wgt = wgt / (loss.uw * loss.unc[p] + loss.eps);
@@ -310,7 +344,10 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
         }
       }
       const float bgdot = cam.bg[0] * vCr[k] + cam.bg[1] * vCg[k] + cam.bg[2] * vCb[k];
-      vAT[k] = Tf * (vA - bgdot);  // the T_final * (v_A - b.v_C) factor of B.7
+      // colour part of the output without the background term, projected on v
+      const float cvtot = vCr[k] * (o0 - Tf * cam.bg[0]) + vCg[k] * (o1 - Tf * cam.bg[1]) +
+                          vCb[k] * (o2 - Tf * cam.bg[2]) + vD[k] * od;
+      X[k] = Tf * (vA - bgdot) - cvtot;
     }
   }
   if (tile_loss) {
@@ -319,29 +356,21 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
   }
   if (n == 0) return;
 
-  const int maxlast = wave_max_i(max(max(last[0], last[1]), max(last[2], last[3])));
-
-  // list positions past the last contributor of every pixel of the tile: zero partials
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int pos = maxlast + 1 + lane; pos < n; pos += 64) {
-    const int gid = sorted_gid[start + pos];
-    const size_t P = pair_index(group_base, gid, ld4(splats + (size_t)gid * TGS_SPLAT_FLOATS + 8), tx, ty);
-    float* o = partials + P * TGS_PARTIAL_FLOATS;
-    st4(o, z4); st4(o + 4, z4); st4(o + 8, z4);
-  }
-
   __shared__ float4 recs[64 * 3];
   __shared__ float4 sums[64 * 4];  // [Gaussian j][16 slots], slot i < 10 = total of value i
-  for (int base = (maxlast >= 0 ? (maxlast >> 6) << 6 : -1); base >= 0; base -= 64) {
-    const int cnt = min(64, maxlast + 1 - base);
-    size_t P = 0;
-    float4 a0 = z4, a1 = z4;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  int base = start;
+  for (; base < end; base += 64) {
     unsigned slot_live = 0u;
 #pragma unroll
-    for (int k = 0; k < 4; k++) slot_live |= (__ballot(last[k] >= base) != 0ull) ? (1u << k) : 0u;
+    for (int k = 0; k < 4; k++) slot_live |= (__ballot(smax[k] > 0.f) != 0ull) ? (1u << k) : 0u;
+    if (slot_live == 0u) break;
+    const int cnt = min(64, end - base);
+    size_t P = 0;
+    float4 a0 = z4, a1 = z4;
     __syncthreads();
     if (lane < cnt) {
-      const int gid = sorted_gid[start + base + lane];
+      const int gid = sorted_gid[base + lane];
       const float* r = splats + (size_t)gid * TGS_SPLAT_FLOATS;
       a0 = ld4(r); a1 = ld4(r + 4);
       const float4 a2 = ld4(r + 8);
@@ -352,12 +381,11 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
     sums[lane * 4] = z4; sums[lane * 4 + 1] = z4; sums[lane * 4 + 2] = z4;
     __syncthreads();
 
-    for (int j = cnt - 1; j >= 0; j--) {
+    for (int j = 0; j < cnt; j++) {
       const float4 qc = recs[j * 3 + 2];
       const unsigned m = __builtin_amdgcn_readfirstlane(__float_as_uint(qc.w)) & slot_live;
       if (m == 0u) continue;
       const float4 qa = recs[j * 3], qb = recs[j * 3 + 1];
-      const int pos = base + j;
       // acc: 0..2 v_rgb, 3 v_depth, 4 Q0 = sum q, 5 Qu, 6 Qv, 7 Quu, 8 Quv, 9 Qvv
       float acc[10];
 #pragma unroll
@@ -367,27 +395,26 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
       for (int k = 0; k < 4; k++) {
         if (m & (1u << k)) {  // wave-uniform
           const float s = eval_s(qa, qb, pc, k);
-          const bool valid = (pos <= last[k]) & (s >= qb.z) & (s <= LOG2_255);
-          const float e2 = __builtin_amdgcn_exp2f(-s);          // = opacity * exp(-sigma)
-          float al = fminf(ALPHA_MAX, e2);
-          al = valid ? al : 0.f;
+          float Tn; bool go;
+          const float al = blend_step(s, T[k], smax[k], Tn, go);
           const float ra = __builtin_amdgcn_rcpf(1.f - al);
-          const float Tb = T[k] * ra;                            // transmittance in front of g
-          T[k] = Tb;
-          const float w = al * Tb;
+          const float w = al * T[k];
           acc[0] = fmaf(w, vCr[k], acc[0]); acc[1] = fmaf(w, vCg[k], acc[1]);
           acc[2] = fmaf(w, vCb[k], acc[2]); acc[3] = fmaf(w, vD[k], acc[3]);
           float cv = qc.x * vCr[k];
           cv = fmaf(qc.y, vCg[k], cv); cv = fmaf(qc.z, vCb[k], cv); cv = fmaf(qb.w, vD[k], cv);
-          const float va = fmaf(Tb, cv, ra * (vAT[k] - Sv[k]));  // dL/d alpha
-          Sv[k] = fmaf(w, cv, Sv[k]);
-          float q = e2 * va;
-          q = valid ? q : 0.f;
+          Pv[k] = fmaf(w, cv, Pv[k]);
+          // dL/d alpha = T cv + (T_final (v_A - bg.v_C) - S_behind.v) / (1 - alpha)
+          const float va = fmaf(T[k], cv, ra * (X[k] + Pv[k]));
+          T[k] = go ? Tn : T[k];
+          // q = opacity * exp(-sigma) * dL/dalpha  (no special-casing of the 0.999 clamp, B.7)
+          float q = __builtin_amdgcn_exp2f(-s) * va;
+          q = go ? q : 0.f;
           acc[4] += q;
           acc[5] = fmaf(q, pc.u[k & 1], acc[5]); acc[6] = fmaf(q, pc.v[k >> 1], acc[6]);
           acc[7] = fmaf(q, pc.uu[k & 1], acc[7]); acc[8] = fmaf(q, pc.uv[k], acc[8]);
           acc[9] = fmaf(q, pc.vv[k >> 1], acc[9]);
-          any |= valid;
+          any |= go;
         }
       }
       if (__ballot(any) != 0ull) {
@@ -414,6 +441,13 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
       st4(o + 8, make_float4(s0.y, s0.z, 0.f, 0.f));
     }
   }
+  // every pixel of the tile has stopped: the rest of the list received no gradient
+  for (int i = base + lane; i < end; i += 64) {
+    const int gid = sorted_gid[i];
+    const size_t P = pair_index(group_base, gid, ld4(splats + (size_t)gid * TGS_SPLAT_FLOATS + 8), tx, ty);
+    float* o = partials + P * TGS_PARTIAL_FLOATS;
+    st4(o, z4); st4(o + 4, z4); st4(o + 8, z4);
+  }
 }
 
 }  // namespace
@@ -423,13 +457,17 @@ extern "C" int tgs_rasterize_fwd(const TgsCamera* cam, const float* splats,
                                  float* out_rgb, float* out_depth, float* final_T,
                                  int32_t* final_idx, void* stream) {
   TGS_CHECK_ARG(camera_ok(cam), "bad camera");
-  TGS_CHECK_ARG(splats && sorted_gid && tile_start && out_rgb && out_depth && final_T && final_idx,
+  TGS_CHECK_ARG(splats && sorted_gid && tile_start && out_rgb && out_depth && final_T,
                 "null pointer");
   const CamK k = make_camk(cam);
   const int T = k.TW * k.TH;
   const int grid = ((T + 7) / 8) * 8;
-  hipLaunchKernelGGL(k_raster_fwd, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T, splats,
-                     sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx);
+  if (final_idx)
+    hipLaunchKernelGGL(k_raster_fwd<true>, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T,
+                       splats, sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx);
+  else
+    hipLaunchKernelGGL(k_raster_fwd<false>, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T,
+                       splats, sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx);
   TGS_CHECK_LAUNCH();
   return TGS_OK;
 }
@@ -438,18 +476,17 @@ extern "C" int tgs_rasterize_bwd(const TgsCamera* cam, const float* splats,
                                  const int32_t* group_base, const int32_t* sorted_gid,
                                  const int32_t* tile_start, const float* out_rgb,
                                  const float* out_depth, const float* final_T,
-                                 const int32_t* final_idx, const float* v_rgb,
+                                 const float* v_rgb,
                                  const float* v_depth, const float* v_alpha,
                                  const TgsLossSpec* loss, float* partials, float* tile_loss,
                                  void* stream) {
   TGS_CHECK_ARG(camera_ok(cam), "bad camera");
-  TGS_CHECK_ARG(splats && group_base && sorted_gid && tile_start && final_T && final_idx && partials,
-                "null pointer");
+  TGS_CHECK_ARG(splats && group_base && sorted_gid && tile_start && out_rgb && out_depth &&
+                final_T && partials, "null pointer");
   LossK lk;
   lk.on = 0; lk.gt_rgb = nullptr; lk.gt_depth = nullptr; lk.unc = nullptr;
   lk.l1w = lk.dw = lk.uw = 0.f; lk.eps = 1e-6f;
   if (loss) {
-    TGS_CHECK_ARG(out_rgb && out_depth, "fused loss needs out_rgb and out_depth");
     lk.on = 1;
     lk.gt_rgb = (loss->l1_weight != 0.f) ? loss->gt_rgb : nullptr;
     lk.gt_depth = (loss->depth_weight != 0.f) ? loss->gt_depth : nullptr;
@@ -461,7 +498,7 @@ extern "C" int tgs_rasterize_bwd(const TgsCamera* cam, const float* splats,
   const int T = k.TW * k.TH;
   const int grid = ((T + 7) / 8) * 8;
   hipLaunchKernelGGL(k_raster_bwd, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T, splats,
-                     group_base, sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx,
+                     group_base, sorted_gid, tile_start, out_rgb, out_depth, final_T,
                      v_rgb, v_depth, v_alpha, lk, partials, tile_loss);
   TGS_CHECK_LAUNCH();
   return TGS_OK;

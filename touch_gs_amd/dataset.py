@@ -1,0 +1,73 @@
+"""Scene loading for the self-contained trainer: the on-disk contract the reference's plumbing
+produces for ``ns-train depth-gaussian-splatting ... nerfstudio-data``.
+
+``transforms.json``: top-level fl_x, fl_y, cx, cy (, w, h); per frame file_path, transform_matrix
+(4x4 camera->world, OpenGL axes), depth_file_path, uncertainty_file_path
+(reference utils/transforms_utils.py:40-49, utils/add_depth_file_path_to_transforms.py:37-50).
+Depth / uncertainty: 16-bit PNG in millimetres (x 1e-3 -> metres; legacy/dataparser_tactile.py:65-66).
+Seed points: points_touch.npy [M,3], points_colors.npy [M,3] in 0..255
+(utils/create_point_cloud_from_touches.py:243-244).  Poses are centred and scaled by 1/max|t|
+and depths by the same factor (legacy/dataparser_tactile.py:222-235,306,310).
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .camera import Camera
+from .model import View
+from .plumbing import from_uint16_mm, get_train_eval_split_fraction, read_png16
+
+
+def _read_rgb(path: str) -> np.ndarray:
+    from PIL import Image
+    return np.asarray(Image.open(path).convert("RGB"), dtype=np.float32) / 255.0
+
+
+class Scene:
+    def __init__(self, root: str, train_split_fraction: float = 0.9, device="cuda", scale_poses: bool = True,
+                 depth_unit_scale_factor: float = 1e-3):
+        self.root = root
+        with open(os.path.join(root, "transforms.json")) as f:
+            meta = json.load(f)
+        frames = sorted(meta["frames"], key=lambda fr: fr["file_path"])
+        c2ws = np.stack([np.array(fr["transform_matrix"], dtype=np.float64) for fr in frames])
+        self.scale = 1.0
+        if scale_poses:
+            c2ws[:, :3, 3] -= c2ws[:, :3, 3].mean(axis=0)
+            self.scale = 1.0 / float(np.max(np.abs(c2ws[:, :3, 3])))
+            c2ws[:, :3, 3] *= self.scale
+        self.offset = None
+        self.views: List[View] = []
+        for fr, c2w in zip(frames, c2ws):
+            rgb = _read_rgb(os.path.join(root, fr["file_path"]))
+            H, W = rgb.shape[:2]
+            g = lambda k, d=None: fr.get(k, meta.get(k, d))
+            cam = Camera.from_c2w_opengl(c2w, g("fl_x"), g("fl_y"), g("cx", W / 2), g("cy", H / 2), W, H)
+            depth = unc = None
+            if "depth_file_path" in fr:
+                depth = torch.from_numpy(from_uint16_mm(read_png16(os.path.join(root, fr["depth_file_path"])))
+                                         .astype(np.float32) * (depth_unit_scale_factor * 1e3) * self.scale)
+            if "uncertainty_file_path" in fr:
+                unc = torch.from_numpy(from_uint16_mm(read_png16(os.path.join(root, fr["uncertainty_file_path"])))
+                                       .astype(np.float32))
+            self.views.append(View(cam=cam, rgb=torch.from_numpy(rgb).to(device).contiguous(),
+                                   depth=None if depth is None else depth.to(device).contiguous(),
+                                   uncertainty=None if unc is None else unc.to(device).contiguous()))
+        names = [fr["file_path"] for fr in frames]
+        self.i_train, self.i_eval = get_train_eval_split_fraction(names, train_split_fraction)
+        self._centre = np.stack([np.array(fr["transform_matrix"], dtype=np.float64)[:3, 3] for fr in frames]).mean(0) \
+            if scale_poses else np.zeros(3)
+
+    def seed_points(self) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
+        """points_touch.npy / points_colors.npy, moved into the scaled scene frame."""
+        p = os.path.join(self.root, "points_touch.npy")
+        c = os.path.join(self.root, "points_colors.npy")
+        if not (os.path.exists(p) and os.path.exists(c)):
+            return None
+        pts = (np.load(p).astype(np.float64) - self._centre) * self.scale
+        return torch.from_numpy(pts.astype(np.float32)), torch.from_numpy(np.load(c).astype(np.float32))

@@ -188,7 +188,7 @@ class DepthGaussianSplattingModel:
         if c.ssim_lambda > 0:
             ssim_sum, v_img = ops.ssim_fwd_bwd(rgb, view.rgb, weight=-c.ssim_lambda / (3 * H * W))
         partials, tile_loss = ops.rasterize_bwd(cam, splats, group_base, sorted_gid, tile_start, rgb,
-                                                depth_acc, fT, fidx, v_rgb=v_img,
+                                                depth_acc, fT, v_rgb=v_img,
                                                 loss=self.loss_spec(view), want_tile_loss=True)
         out = ops.project_bwd(cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, splats,
                               group_base, partials, out=p.grad_views(), want_v_xy=want_v_xy)

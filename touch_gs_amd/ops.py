@@ -122,22 +122,22 @@ def bin_sort(cam: Camera, splats, budget: Optional[IntersectBudget] = None):
     return group_base, tile_start, sorted_gid, status
 
 
-def rasterize_fwd(cam: Camera, splats, sorted_gid, tile_start):
-    """K6 -> (rgb [H,W,3], depth_acc [H,W], final_T [H,W], final_idx [H,W]).  (tgs_rasterize_fwd)"""
+def rasterize_fwd(cam: Camera, splats, sorted_gid, tile_start, want_idx: bool = False):
+    """K6 -> (rgb [H,W,3], depth_acc [H,W], final_T [H,W], final_idx [H,W] or None).  (tgs_rasterize_fwd)"""
     lib = _lib.load()
     dev = splats.device
     H, W = cam.H, cam.W
     rgb = torch.empty(H, W, 3, dtype=torch.float32, device=dev)
     depth = torch.empty(H, W, dtype=torch.float32, device=dev)
     fT = torch.empty(H, W, dtype=torch.float32, device=dev)
-    fidx = torch.empty(H, W, dtype=torch.int32, device=dev)
+    fidx = torch.empty(H, W, dtype=torch.int32, device=dev) if want_idx else None
     cs = cam.c_struct()
     check(lib.tgs_rasterize_fwd(C.byref(cs), ptr(splats), ptr(sorted_gid), ptr(tile_start), ptr(rgb),
                                 ptr(depth), ptr(fT), ptr(fidx), _stream()), "tgs_rasterize_fwd")
     return rgb, depth, fT, fidx
 
 
-def rasterize_bwd(cam: Camera, splats, group_base, sorted_gid, tile_start, rgb, depth, fT, fidx,
+def rasterize_bwd(cam: Camera, splats, group_base, sorted_gid, tile_start, rgb, depth, fT,
                   v_rgb=None, v_depth=None, v_alpha=None, loss: Optional[dict] = None,
                   want_tile_loss: bool = False):
     """K7 -> (partials [cap,12], tile_loss [T,2] or None).  (tgs_rasterize_bwd)
@@ -163,7 +163,7 @@ def rasterize_bwd(cam: Camera, splats, group_base, sorted_gid, tile_start, rgb, 
         ls.eps = float(loss.get("eps", 1e-6))
     v_rgb, v_depth, v_alpha = _f32c(v_rgb), _f32c(v_depth), _f32c(v_alpha)
     check(lib.tgs_rasterize_bwd(C.byref(cs), ptr(splats), ptr(group_base), ptr(sorted_gid),
-                                ptr(tile_start), ptr(rgb), ptr(depth), ptr(fT), ptr(fidx),
+                                ptr(tile_start), ptr(rgb), ptr(depth), ptr(fT),
                                 ptr(v_rgb), ptr(v_depth), ptr(v_alpha),
                                 C.byref(ls) if ls is not None else None, ptr(partials),
                                 ptr(tile_loss), _stream()), "tgs_rasterize_bwd")
@@ -217,7 +217,7 @@ class _Render(torch.autograd.Function):
         ctx.cam, ctx.sh_deg = cam, sh_deg
         ctx.want_xy = means2d is not None
         ctx.save_for_backward(means, log_scales, quats, opac_logit, sh, splats, group_base,
-                              tile_start, sorted_gid, rgb, depth, fT, fidx)
+                              tile_start, sorted_gid, rgb, depth, fT)
         alpha = 1.0 - fT
         ctx.mark_non_differentiable(radii)
         return rgb, depth, alpha, radii
@@ -225,10 +225,10 @@ class _Render(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_rgb, v_depth, v_alpha, _v_radii):
         (means, log_scales, quats, opac_logit, sh, splats, group_base, tile_start, sorted_gid,
-         rgb, depth, fT, fidx) = ctx.saved_tensors
+         rgb, depth, fT) = ctx.saved_tensors
         cam = ctx.cam
         partials, _ = rasterize_bwd(cam, splats, group_base, sorted_gid, tile_start, rgb, depth, fT,
-                                    fidx, v_rgb, v_depth, v_alpha)
+                                    v_rgb, v_depth, v_alpha)
         v_means, v_ls, v_q, v_ol, v_sh, v_xy = project_bwd(
             cam, means, log_scales, quats, opac_logit, sh, ctx.sh_deg, splats, group_base, partials,
             want_v_xy=ctx.want_xy)
@@ -366,15 +366,15 @@ class _RasterizeGaussians(torch.autograd.Function):
         rgb, depth, fT, fidx = rasterize_fwd(cam, splats, sorted_gid, tile_start)
         ctx.cam = cam
         ctx.opacity_shape = opacity.shape
-        ctx.save_for_backward(splats, group_base, tile_start, sorted_gid, rgb, depth, fT, fidx)
+        ctx.save_for_backward(splats, group_base, tile_start, sorted_gid, rgb, depth, fT)
         return rgb, 1.0 - fT, depth
 
     @staticmethod
     def backward(ctx, v_rgb, v_alpha, v_depth):
-        splats, group_base, tile_start, sorted_gid, rgb, depth, fT, fidx = ctx.saved_tensors
+        splats, group_base, tile_start, sorted_gid, rgb, depth, fT = ctx.saved_tensors
         cam = ctx.cam
         partials, _ = rasterize_bwd(cam, splats, group_base, sorted_gid, tile_start, rgb, depth, fT,
-                                    fidx, v_rgb, v_depth, v_alpha)
+                                    v_rgb, v_depth, v_alpha)
         v = reduce_partials(cam, splats, group_base, partials)
         v_xys, v_depths = v[:, 0:2].contiguous(), v[:, 2].contiguous()
         v_op = v[:, 3].contiguous().reshape(ctx.opacity_shape)

@@ -1,0 +1,144 @@
+"""Self-contained trainer for the ``depth-gaussian-splatting`` method (the build's counterpart of
+``ns-train`` / ``ns-eval``, which never travel to the GPU box).
+
+Flags keep the reference's names (scripts/train_bunny_real.sh:52, train_block_data.sh:50):
+    python -m touch_gs_amd.train --data <scene> --depth-loss-mult 0.2 \
+        --depth-loss-type DEPTH_UNCERTAINTY_WEIGHTED_LOSS --uncertainty-weight 1 \
+        --train-split-fraction 0.8 [--max-num-iterations 30000] [--output-dir outputs]
+    python -m torch.distributed.run --nproc-per-node 8 -m touch_gs_amd.train ...   # data parallel
+    python -m touch_gs_amd.train --synthetic 100000 800 800 ...                    # no data needed
+
+Outputs ``<output-dir>/<scene>/depth-gaussian-splatting/<timestamp>/`` with config.json, checkpoints
+``step-<n>.ckpt`` (every --steps-per-save) and ``eval.json`` whose ``results`` keys are the ones the
+reference aggregates (experiment_utils/get_results.py:35-52: psnr, ssim, depth_mse,
+supervised_depth_mse; lpips is omitted -- it needs pretrained network weights).
+"""
+from __future__ import annotations
+
+import argparse
+import dataclasses
+import json
+import math
+import os
+import time
+
+import torch
+
+from . import ops, parallel
+from .model import DEPTH_LOSS_TYPES, DepthGaussianSplattingModel, ModelConfig, View
+from .optim import GaussianParams
+
+SH_C0 = 0.28209479177387814
+
+
+def init_params(n: int, K: int, device, seed_points=None, extent: float = 1.0, seed: int = 0) -> GaussianParams:
+    """Seed Gaussians from the touch point cloud (+ random fill), Splatfacto-style: scales from the
+    mean distance to the 3 nearest neighbours, identity-ish rotations, opacity 0.1."""
+    g = torch.Generator().manual_seed(seed)
+    pts, cols = [], []
+    if seed_points is not None:
+        pts.append(seed_points[0])
+        cols.append(seed_points[1] / 255.0)
+    n_rand = max(n - sum(len(p) for p in pts), 0)
+    if n_rand:
+        pts.append((torch.rand(n_rand, 3, generator=g) - 0.5) * 2 * extent)
+        cols.append(torch.rand(n_rand, 3, generator=g))
+    means = torch.cat(pts)[:n].float()
+    colors = torch.cat(cols)[:n].float()
+    N = means.shape[0]
+    sub = means[torch.randperm(N, generator=g)[:min(N, 20000)]]
+    d = torch.cdist(means[:min(N, 200000)], sub)
+    knn = d.topk(4, largest=False).values[:, 1:].mean(1).clamp_min(1e-4)
+    scale = torch.full((N,), float(knn.median()))
+    scale[:knn.numel()] = knn
+    sh = torch.zeros(N, K, 3)
+    sh[:, 0] = (colors - 0.5) / SH_C0
+    quats = torch.nn.functional.normalize(torch.randn(N, 4, generator=g), dim=1)
+    return GaussianParams.from_tensors(means.to(device), torch.log(scale)[:, None].repeat(1, 3).to(device),
+                                       quats.to(device), torch.full((N,), math.log(0.1 / 0.9)).to(device),
+                                       sh.to(device))
+
+
+@torch.no_grad()
+def evaluate(model: DepthGaussianSplattingModel, views) -> dict:
+    acc = {}
+    for v in views:
+        out = model.get_outputs(v.cam, sh_degree=model.active_sh_degree())
+        m, _ = model.get_image_metrics_and_images(out, v)
+        for k, x in m.items():
+            acc.setdefault(k, []).append(x)
+    return {k: float(sum(x) / len(x)) for k, x in acc.items()}
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--data", type=str, default=None)
+    ap.add_argument("--synthetic", type=int, nargs=3, metavar=("N", "W", "H"), default=None)
+    ap.add_argument("--depth-loss-mult", type=float, default=0.2)
+    ap.add_argument("--depth-loss-type", type=str, default="DEPTH_UNCERTAINTY_WEIGHTED_LOSS", choices=DEPTH_LOSS_TYPES)
+    ap.add_argument("--uncertainty-weight", "--uncertainty_weight", type=float, default=1.0, dest="uncertainty_weight")
+    ap.add_argument("--train-split-fraction", type=float, default=0.9)
+    ap.add_argument("--max-num-iterations", type=int, default=30000)
+    ap.add_argument("--steps-per-save", type=int, default=2000)
+    ap.add_argument("--steps-per-eval", type=int, default=500)
+    ap.add_argument("--num-gaussians", type=int, default=100000)
+    ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--output-dir", type=str, default="outputs")
+    ap.add_argument("--load-checkpoint", type=str, default=None)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args(argv)
+
+    dp = parallel.init_from_env()
+    dev = torch.device("cuda", dp.local_rank)
+    torch.cuda.set_device(dev)
+    K = (args.sh_degree + 1) ** 2
+    if args.synthetic:
+        from .scene import make_view, synthetic_gaussians
+        N, W, H = args.synthetic
+        views = [make_view(N, W, H, args.sh_degree, 1235, dev, view=v, n_views=8) for v in range(8)]
+        i_train, i_eval = list(range(7)), [7]
+        P, _ = synthetic_gaussians(N, W, H, args.sh_degree, 4321)  # a *different* scene to fit from
+        params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
+        scene_name = f"synthetic_{N}_{W}x{H}"
+    else:
+        from .dataset import Scene
+        scene = Scene(args.data, args.train_split_fraction, dev)
+        views, i_train, i_eval = scene.views, list(scene.i_train), list(scene.i_eval)
+        params = init_params(args.num_gaussians, K, dev, scene.seed_points(), seed=args.seed)
+        scene_name = os.path.basename(os.path.normpath(args.data))
+    cfg = ModelConfig(sh_degree=args.sh_degree, depth_loss_mult=args.depth_loss_mult,
+                      depth_loss_type=args.depth_loss_type, uncertainty_weight=args.uncertainty_weight)
+    model = DepthGaussianSplattingModel(cfg, params)
+    if args.load_checkpoint:
+        model.load_state_dict(torch.load(args.load_checkpoint, map_location=dev))
+    run_dir = os.path.join(args.output_dir, scene_name, "depth-gaussian-splatting", time.strftime("%Y-%m-%d_%H%M%S"))
+    if dp.rank == 0:
+        os.makedirs(run_dir, exist_ok=True)
+        with open(os.path.join(run_dir, "config.json"), "w") as f:
+            json.dump(dict(vars(args), model=dataclasses.asdict(cfg), world_size=dp.world), f, indent=2)
+    train_views = [views[i] for i in i_train]
+    eval_views = [views[i] for i in i_eval] or train_views[:1]
+    t0 = time.time()
+    for step in range(model.step, args.max_num_iterations):
+        view = train_views[dp.views_for_step(step, len(train_views))]
+        model.train_step(view, dp if dp.world > 1 else None)
+        if dp.rank == 0 and (step + 1) % args.steps_per_eval == 0:
+            loss = model.loss_from(model.last["tile_loss"], model.last["ssim_sum"], view)
+            print(f"step {step + 1}: " + " ".join(f"{k}={float(v):.5f}" for k, v in loss.items()) +
+                  f"  {(step + 1 - 0) / (time.time() - t0):.1f} it/s", flush=True)
+        if dp.rank == 0 and ((step + 1) % args.steps_per_save == 0 or step + 1 == args.max_num_iterations):
+            torch.save(model.state_dict(), os.path.join(run_dir, f"step-{step + 1:09d}.ckpt"))
+    if dp.world > 1:
+        dp.assert_replicas_identical(params.flat)
+    if dp.rank == 0:
+        results = evaluate(model, eval_views)
+        with open(os.path.join(run_dir, "eval.json"), "w") as f:
+            json.dump({"experiment_name": scene_name, "method_name": "depth-gaussian-splatting",
+                       "checkpoint": run_dir, "results": results}, f, indent=2)
+        print(json.dumps(results))
+    dp.barrier()
+    return run_dir
+
+
+if __name__ == "__main__":
+    main()
