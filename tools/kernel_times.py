@@ -1,7 +1,7 @@
 """Scratch timing of each kernel on the BASELINE configs (developer tool, not bench.py)."""
 import sys, time, math
 import torch
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, '..')
 from oracle import torch_oracle as O
 from touch_gs_amd import ops, Camera
 

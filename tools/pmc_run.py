@@ -1,6 +1,6 @@
 """Developer tool: run K1..K8 a few times on cfg3 (for rocprofv3 --pmc passes)."""
 import sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, '..')
 from touch_gs_amd import ops
 from touch_gs_amd.scene import synthetic_gaussians, make_camera
 N, W, H, deg = 1_000_000, 1920, 1080, 3

@@ -358,9 +358,20 @@ class _RasterizeGaussians(torch.autograd.Function):
         N = xys.shape[0]
         dev = xys.device
         op = opacity.reshape(N, 1).to(torch.float32)
+        # slot 10 = packed App. B.4 tile rect x0 | y0<<8 | w<<16 | h<<24 (include/tgs.h)
+        tw, th = cam.tiles
+        r = radii.to(torch.float32)
+        xf, yf = xys[:, 0].to(torch.float32), xys[:, 1].to(torch.float32)
+        x0 = torch.clamp(((xf - r) * 0.0625).to(torch.int64), 0, tw)
+        x1 = torch.clamp(((xf + r) * 0.0625).to(torch.int64) + 1, 0, tw)
+        y0 = torch.clamp(((yf - r) * 0.0625).to(torch.int64), 0, th)
+        y1 = torch.clamp(((yf + r) * 0.0625).to(torch.int64) + 1, 0, th)
+        vis = (radii > 0) & (x1 > x0) & (y1 > y0)
+        packed = torch.where(vis, x0 | (y0 << 8) | ((x1 - x0) << 16) | ((y1 - y0) << 24), torch.zeros_like(x0))
+        packed = torch.where(packed >= 2 ** 31, packed - 2 ** 32, packed).to(torch.int32)
         splats = torch.cat([xys.to(torch.float32), depths.reshape(N, 1).to(torch.float32), op,
                             conics.to(torch.float32), colors.to(torch.float32),
-                            radii.to(torch.int32).reshape(N, 1).view(torch.float32),
+                            packed.reshape(N, 1).view(torch.float32),
                             torch.zeros(N, 1, dtype=torch.float32, device=dev)], dim=1).contiguous()
         group_base, tile_start, sorted_gid, _ = bin_sort(cam, splats, budget)
         rgb, depth, fT, fidx = rasterize_fwd(cam, splats, sorted_gid, tile_start)
