@@ -159,10 +159,12 @@ int tgs_project_bwd(const TgsCamera* cam /*[host]*/, int N, const float* means,
                     float* v_means, float* v_log_scales, float* v_quats, float* v_opac_logit,
                     float* v_sh, float* v_xy, void* stream);
 
-/* K9  fused Adam over the flat parameter buffer (torch.optim.Adam semantics, no weight decay). */
+/* K9  fused Adam over the flat parameter buffer (torch.optim.Adam semantics, no weight decay).
+ *     Updates elements [elem_begin, elem_end) of the flat buffers (multiples of 4; pass 0, -1 for
+ *     everything) so that chunks can be stepped as their gradient all-reduce completes. */
 int tgs_adam_step(int N, int sh_stride, float* params, const float* grads, float* exp_avg,
                   float* exp_avg_sq, const TgsAdamSpec* spec /*[host]*/, float grad_scale,
-                  void* stream);
+                  int64_t elem_begin, int64_t elem_end, void* stream);
 
 /* K10 SSIM (11x11 Gaussian window, sigma 1.5, zero padding) forward + gradient image; the
  *     (1-SSIM) term of the Splatfacto-style loss.

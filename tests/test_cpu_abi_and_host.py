@@ -111,6 +111,14 @@ def test_scene_generator_matches_oracle_recipe():
     assert np.allclose(orbit_viewmat(3, 8), O.orbit_viewmat(3, 8).numpy())
 
 
+def test_chunk_ranges():
+    from touch_gs_amd.parallel import GradSync
+    for numel, n in ((59_000_000, 8), (1003, 5), (8, 8), (4, 3), (12, 1)):
+        r = GradSync.chunk_ranges(numel, n)
+        assert r[0][0] == 0 and r[-1][1] == numel and all(b % 4 == 0 for b, _ in r)
+        assert all(r[i][1] == r[i + 1][0] for i in range(len(r) - 1)) and len(r) <= n
+
+
 def test_intersect_budget_logic():
     from touch_gs_amd.ops import IntersectBudget
     b = IntersectBudget()
@@ -145,6 +153,18 @@ for step in range(4):
     params = params - 1e-3 * m / (v.sqrt() + 1e-15)
     dp.assert_replicas_identical(params)
 assert seen == [(s * 2 + dp.rank) % 8 for s in range(4)]
+# pipelined form: chunked all-reduce, optimizer callback per reduced chunk
+gflat = torch.arange(1003, dtype=torch.float32) * (dp.rank + 1)
+calls = []
+def step_range(b, e, scale):
+    calls.append((b, e))
+    gflat[b:e] *= scale
+began = []
+dp.n_chunks = 5
+dp.reduce_and_step(gflat, step_range, lambda: began.append(1))
+assert began == [1] and calls[0][0] == 0 and calls[-1][1] == 1003 and all(b % 4 == 0 for b, _ in calls)
+assert all(calls[i][1] == calls[i + 1][0] for i in range(len(calls) - 1)) and len(calls) == 5
+assert torch.allclose(gflat, torch.arange(1003, dtype=torch.float32) * 1.5)
 assert dp.max_over_ranks(float(dp.rank)) == 1.0
 dp.barrier()
 if dp.rank == 0: print("GLOO_OK", dp.bytes_per_step)
@@ -159,4 +179,4 @@ def test_data_parallel_gloo_world2(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", "29611", str(script), ROOT],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "GLOO_OK 4000" in r.stdout
+    assert "GLOO_OK 4012" in r.stdout  # bytes of the last exchanged buffer (1003 floats)

@@ -13,6 +13,7 @@ namespace {
 
 struct AdamK {
   long long e_means, e_scales, e_quats, e_opac, e_total;  // start of the NEXT segment (elements)
+  long long e_begin, e_end;                               // element range updated by this launch
   unsigned sh_row;                                        // 3*K floats per Gaussian in the SH block
   unsigned row_step;                                      // (4 * grid stride) mod sh_row
   float lr_means, lr_scales, lr_quats, lr_opac, lr_dc, lr_rest;
@@ -34,11 +35,11 @@ __device__ __forceinline__ void adam1(const AdamK& a, float lr, float& p, float 
 __global__ __launch_bounds__(256) void k_adam(AdamK a, float* __restrict__ p,
                                               const float* __restrict__ g, float* __restrict__ m,
                                               float* __restrict__ v) {
-  const long long n4 = a.e_total >> 2;
+  const long long n4 = a.e_end >> 2;
   const long long stride = (long long)gridDim.x * blockDim.x;
   unsigned r = 0;
   bool in_sh = false;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+  for (long long i = (a.e_begin >> 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     const long long e = 4 * i;
     float4 P = ld4(p + e), G = ld4(g + e), M = ld4(m + e), V = ld4(v + e);
     float l0, l1, l2, l3;
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void k_adam(AdamK a, float* __restrict__ p,
 
 extern "C" int tgs_adam_step(int N, int sh_stride, float* params, const float* grads,
                              float* exp_avg, float* exp_avg_sq, const TgsAdamSpec* spec,
-                             float grad_scale, void* stream) {
+                             float grad_scale, int64_t elem_begin, int64_t elem_end, void* stream) {
   TGS_CHECK_ARG(N >= 0 && sh_stride >= 0, "negative size");
   if (N == 0) return TGS_OK;
   TGS_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && spec, "null pointer");
@@ -87,7 +88,12 @@ extern "C" int tgs_adam_step(int N, int sh_stride, float* params, const float* g
   a.ibc1 = 1.0f / spec->bias_corr1;
   a.isq_bc2 = 1.0f / sqrtf(spec->bias_corr2);
   a.gscale = grad_scale;
-  const long long n4 = a.e_total >> 2;
+  if (elem_end < 0 || elem_end > a.e_total) elem_end = a.e_total;
+  if (elem_begin < 0) elem_begin = 0;
+  TGS_CHECK_ARG((elem_begin & 3) == 0 && (elem_end & 3) == 0, "element range must be a multiple of 4");
+  if (elem_end <= elem_begin) return TGS_OK;
+  a.e_begin = elem_begin; a.e_end = elem_end;
+  const long long n4 = (elem_end - elem_begin) >> 2;
   long long blocks = (n4 + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 blocks per CU
   if (blocks < 1) blocks = 1;

@@ -208,10 +208,10 @@ class DepthGaussianSplattingModel:
     def train_step(self, view: View, dp=None) -> None:
         """One optimizer iteration on one view (per rank).  ``dp``: a parallel.GradSync or None."""
         self.forward_backward(view)
-        scale = 1.0
-        if dp is not None:
-            scale = dp.all_reduce_(self.params.grad)
-        self.optimizer.step(grad_scale=scale)
+        if dp is not None and dp.world > 1:
+            dp.reduce_and_step(self.params.grad, self.optimizer.step_range, self.optimizer.begin_step)
+        else:
+            self.optimizer.step()
         self.step += 1
 
     # -- checkpoint -----------------------------------------------------------------------------

@@ -89,19 +89,31 @@ class FusedAdam:
         self.exp_avg_sq = torch.zeros_like(params.flat)
         self.t = 0
 
-    def step(self, grad_scale: float = 1.0):
-        lib = _lib.load()
-        self.t += 1
+    def _spec(self):
         s = _lib.TgsAdamSpec()
         s.lr_means, s.lr_scales, s.lr_quats = self.lrs["means"], self.lrs["log_scales"], self.lrs["quats"]
         s.lr_opac, s.lr_sh_dc, s.lr_sh_rest = self.lrs["opac_logit"], self.lrs["sh_dc"], self.lrs["sh_rest"]
         s.beta1, s.beta2, s.eps = self.betas[0], self.betas[1], self.eps
         s.bias_corr1 = 1.0 - self.betas[0] ** self.t
         s.bias_corr2 = 1.0 - self.betas[1] ** self.t
+        return s
+
+    def begin_step(self):
+        """Advance the step counter once per optimizer iteration (before step_range calls)."""
+        self.t += 1
+
+    def step_range(self, elem_begin: int, elem_end: int, grad_scale: float = 1.0):
+        """Adam on flat elements [elem_begin, elem_end) (multiples of 4) of the current step."""
+        lib = _lib.load()
+        s = self._spec()
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(lib.tgs_adam_step(self.p.N, self.p.K, ptr(self.p.flat), ptr(self.p.grad), ptr(self.exp_avg),
-                                ptr(self.exp_avg_sq), C.byref(s), C.c_float(grad_scale), stream),
-              "tgs_adam_step")
+                                ptr(self.exp_avg_sq), C.byref(s), C.c_float(grad_scale), elem_begin, elem_end,
+                                stream), "tgs_adam_step")
+
+    def step(self, grad_scale: float = 1.0):
+        self.begin_step()
+        self.step_range(0, -1, grad_scale)
 
     def state_dict(self):
         return dict(t=self.t, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lrs=self.lrs)

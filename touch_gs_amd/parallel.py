@@ -33,17 +33,73 @@ def init_from_env(backend: Optional[str] = None) -> "GradSync":
 
 
 class GradSync:
-    """Sum-all-reduce of the flat gradient buffer; returns the scale that turns it into a mean."""
+    """Gradient exchange for data-parallel training.
 
-    def __init__(self, rank: int = 0, world: int = 1, local_rank: int = 0):
+    ``all_reduce_`` is the plain form (one blocking sum all-reduce, returns the 1/world scale).
+    ``reduce_and_step`` is the pipelined form used by the trainer: the flat gradient buffer is cut
+    into ``n_chunks`` contiguous ranges; their all-reduces are enqueued back to back on a side
+    stream and the fused Adam of range c is enqueued on the compute stream behind an event that
+    fires when range c has been reduced -- so the optimizer (0.37 ms at 1 M Gaussians) runs under
+    the shadow of the collective (~1 ms for 236 MB on xGMI) instead of after it.
+    """
+
+    def __init__(self, rank: int = 0, world: int = 1, local_rank: int = 0, n_chunks: int = 8):
         self.rank, self.world, self.local_rank = rank, world, local_rank
+        self.n_chunks = n_chunks
         self.bytes_per_step = 0
+        self._comm_stream = None
 
     def all_reduce_(self, flat_grad: torch.Tensor) -> float:
         if self.world > 1:
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
             self.bytes_per_step = flat_grad.numel() * flat_grad.element_size()
         return 1.0 / self.world
+
+    @staticmethod
+    def chunk_ranges(numel: int, n_chunks: int, align: int = 4):
+        """Contiguous [begin, end) ranges covering [0, numel), every boundary a multiple of `align`."""
+        n_chunks = max(1, min(n_chunks, max(numel // align, 1)))
+        per = -(-numel // n_chunks)
+        per = -(-per // align) * align
+        out, b = [], 0
+        while b < numel:
+            e = min(b + per, numel)
+            out.append((b, e))
+            b = e
+        return out
+
+    def reduce_and_step(self, flat_grad: torch.Tensor, step_range, begin_step=None) -> None:
+        """Sum-all-reduce ``flat_grad`` chunk by chunk and call ``step_range(begin, end, scale)`` for
+        every chunk once it is reduced (scale = 1/world turns the sum into a mean)."""
+        scale = 1.0 / self.world
+        if begin_step is not None:
+            begin_step()
+        if self.world == 1:
+            step_range(0, flat_grad.numel(), 1.0)
+            return
+        ranges = self.chunk_ranges(flat_grad.numel(), self.n_chunks)
+        self.bytes_per_step = flat_grad.numel() * flat_grad.element_size()
+        if not flat_grad.is_cuda:  # CPU / gloo (tests): no streams, same order of operations
+            for b, e in ranges:
+                dist.all_reduce(flat_grad[b:e], op=dist.ReduceOp.SUM)
+                step_range(b, e, scale)
+            return
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=flat_grad.device)
+        comp = torch.cuda.current_stream(flat_grad.device)
+        ready = torch.cuda.Event()
+        ready.record(comp)                     # gradients complete on the compute stream
+        self._comm_stream.wait_event(ready)
+        events = []
+        with torch.cuda.stream(self._comm_stream):
+            for b, e in ranges:
+                dist.all_reduce(flat_grad[b:e], op=dist.ReduceOp.SUM)
+                ev = torch.cuda.Event()
+                ev.record(self._comm_stream)
+                events.append(ev)
+        for (b, e), ev in zip(ranges, events):
+            comp.wait_event(ev)
+            step_range(b, e, scale)
 
     def barrier(self):
         if self.world > 1:
