@@ -159,6 +159,17 @@ int tgs_project_bwd(const TgsCamera* cam /*[host]*/, int N, const float* means,
                     float* v_means, float* v_log_scales, float* v_quats, float* v_opac_logit,
                     float* v_sh, float* v_xy, void* stream);
 
+/* K8+K9 fused (single-process training): projection/SH backward whose gradients go straight
+ *     through the Adam update of the flat parameter buffer `params` (layout of TgsAdamSpec) and
+ *     its moment buffers -- the 59-float gradient of a Gaussian never touches HBM.  Requires a
+ *     dense SH tensor evaluated at its full degree (sh_stride == (sh_deg+1)^2, sh_deg 1 or 3).
+ *     Not usable when gradients must first be all-reduced across ranks. */
+int tgs_project_bwd_adam(const TgsCamera* cam /*[host]*/, int N, int sh_stride, int sh_deg,
+                         float* params, float* exp_avg, float* exp_avg_sq,
+                         const TgsAdamSpec* spec /*[host]*/, const float* splats,
+                         const int32_t* group_base, const float* partials, float* v_xy,
+                         void* stream);
+
 /* K9  fused Adam over the flat parameter buffer (torch.optim.Adam semantics, no weight decay).
  *     Updates elements [elem_begin, elem_end) of the flat buffers (multiples of 4; pass 0, -1 for
  *     everything) so that chunks can be stepped as their gradient all-reduce completes. */

@@ -216,3 +216,28 @@ def test_data_parallel_train_step_two_ranks_one_gpu(dev, tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", "29633", str(script), root],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("deg", [3, 1])
+def test_fused_backward_adam_equals_separate_kernels(dev, deg):
+    """tgs_project_bwd_adam == tgs_project_bwd followed by tgs_adam_step (same Adam arithmetic)."""
+    from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
+    from touch_gs_amd.optim import GaussianParams
+    from touch_gs_amd.scene import make_view, synthetic_gaussians
+    N, W, H = 4100, 160, 96   # N not a multiple of 256: exercises the ragged last group
+    views = [make_view(N, W, H, deg, 7, dev, view=v, n_views=4) for v in range(2)]
+    P, _ = synthetic_gaussians(N, W, H, deg, 99)
+    models = []
+    for fuse in (True, False):
+        params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
+        m = DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=0), params)
+        m.fuse_adam = fuse
+        for step in range(3):
+            m.train_step(views[step % 2])
+        models.append(m)
+    a, b = models
+    assert a.optimizer.t == b.optimizer.t == 3
+    for x, y, name in ((a.params.flat, b.params.flat, "params"), (a.optimizer.exp_avg, b.optimizer.exp_avg, "m"),
+                       (a.optimizer.exp_avg_sq, b.optimizer.exp_avg_sq, "v")):
+        scale = y.abs().max().item()
+        assert (x - y).abs().max().item() < 1e-5 * scale + 1e-9, name

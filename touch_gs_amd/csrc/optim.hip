@@ -7,26 +7,9 @@
 // (every segment starts at a multiple of 4 floats so that all views are 16-byte aligned; pad
 // elements carry zero gradient and stay zero)
 // Roofline: HBM; 28 B of traffic per parameter (read p,g,m,v; write p,m,v).
-#include "tgs_common.h"
+#include "tgs_adam.h"
 
 namespace {
-
-struct AdamK {
-  long long e_means, e_scales, e_quats, e_opac, e_total;  // start of the NEXT segment (elements)
-  long long e_begin, e_end;                               // element range updated by this launch
-  unsigned sh_row;                                        // 3*K floats per Gaussian in the SH block
-  unsigned row_step;                                      // (4 * grid stride) mod sh_row
-  float lr_means, lr_scales, lr_quats, lr_opac, lr_dc, lr_rest;
-  float b1, b2, eps, ibc1, isq_bc2, gscale;
-};
-
-__device__ __forceinline__ void adam1(const AdamK& a, float lr, float& p, float g, float& m, float& v) {
-  g *= a.gscale;
-  m = a.b1 * m + (1.f - a.b1) * g;
-  v = a.b2 * v + (1.f - a.b2) * g * g;
-  const float denom = sqrtf(v) * a.isq_bc2 + a.eps;
-  p -= lr * (m * a.ibc1) / denom;
-}
 
 // One float4 per thread per grid-stride iteration.  Segment starts are multiples of 4 floats, so
 // a float4 never straddles two parameter groups; inside the SH block the DC/rest split needs the
@@ -74,20 +57,7 @@ extern "C" int tgs_adam_step(int N, int sh_stride, float* params, const float* g
   TGS_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && spec, "null pointer");
   TGS_CHECK_ARG(((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0,
                 "buffers must be 16-byte aligned");
-  AdamK a;
-  auto al4 = [](long long x) { return (x + 3) & ~3ll; };
-  a.e_means = al4(3ll * N);                 // log_scales start
-  a.e_scales = al4(a.e_means + 3ll * N);    // quats start
-  a.e_quats = a.e_scales + 4ll * N;         // opac_logit start
-  a.e_opac = al4(a.e_quats + N);            // sh start
-  a.sh_row = sh_stride > 0 ? 3u * (unsigned)sh_stride : 4u;
-  a.e_total = al4(a.e_opac + (long long)N * sh_stride * 3);
-  a.lr_means = spec->lr_means; a.lr_scales = spec->lr_scales; a.lr_quats = spec->lr_quats;
-  a.lr_opac = spec->lr_opac; a.lr_dc = spec->lr_sh_dc; a.lr_rest = spec->lr_sh_rest;
-  a.b1 = spec->beta1; a.b2 = spec->beta2; a.eps = spec->eps;
-  a.ibc1 = 1.0f / spec->bias_corr1;
-  a.isq_bc2 = 1.0f / sqrtf(spec->bias_corr2);
-  a.gscale = grad_scale;
+  AdamK a = make_adamk(N, sh_stride, spec, grad_scale);
   if (elem_end < 0 || elem_end > a.e_total) elem_end = a.e_total;
   if (elem_begin < 0) elem_begin = 0;
   TGS_CHECK_ARG((elem_begin & 3) == 0 && (elem_end & 3) == 0, "element range must be a multiple of 4");

@@ -7,7 +7,7 @@
 //
 // Roofline: pure streaming, HBM bound.  Forward reads 44+12K B and writes 48 B per Gaussian;
 // backward reads 44+12K+48 (+48*tiles_hit of partials) and writes 44+12K (+8) B per Gaussian.
-#include "tgs_common.h"
+#include "tgs_adam.h"
 
 namespace {
 
@@ -231,12 +231,27 @@ __device__ __forceinline__ void sum_partials(const CamK& cam, const float* __res
   if (hits == 0) return;
   const size_t off = (size_t)group_base[g / TGS_GROUP] + (size_t)__float_as_int(r2.w);
   const float* p = partials + off * TGS_PARTIAL_FLOATS;
-  for (int k = 0; k < hits; k++, p += TGS_PARTIAL_FLOATS) {
-    const float4 a = ld4(p), b = ld4(p + 4);
-    const float2 c = *reinterpret_cast<const float2*>(p + 8);
-    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
-    v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
-    v[8] += c.x; v[9] += c.y;
+  // 4 records (12 independent 16-B loads) in flight per round: the loop is latency-bound
+  // otherwise.  Accumulation order is still k = 0, 1, 2, ... (bit-identical to a serial loop).
+  for (int k0 = 0; k0 < hits; k0 += 4, p += 4 * TGS_PARTIAL_FLOATS) {
+    float4 a[4], b[4];
+    float2 c[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (k0 + u < hits) {
+        a[u] = ld4(p + u * TGS_PARTIAL_FLOATS);
+        b[u] = ld4(p + u * TGS_PARTIAL_FLOATS + 4);
+        c[u] = *reinterpret_cast<const float2*>(p + u * TGS_PARTIAL_FLOATS + 8);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (k0 + u < hits) {
+        v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w;
+        v[4] += b[u].x; v[5] += b[u].y; v[6] += b[u].z; v[7] += b[u].w;
+        v[8] += c[u].x; v[9] += c[u].y;
+      }
+    }
   }
 }
 
@@ -251,6 +266,84 @@ __global__ __launch_bounds__(256) void k_reduce_partials(
   st4(o, make_float4(v[0], v[1], v[2], v[3]));
   st4(o + 4, make_float4(v[4], v[5], v[6], v[7]));
   st4(o + 8, make_float4(v[8], v[9], 0.f, 0.f));
+}
+
+// B.8 geometry backward for one visible Gaussian: v = {v_x, v_y, v_depth, -, v_a, v_b, v_c, ...}
+// -> accumulates into vm (means), writes vls (log-scales) and vq (quaternion).
+__device__ __forceinline__ void geom_bwd(const CamK& cam, const float* m, const float* ls, const float* q,
+                                         const float* v, float* vm, float* vls, float* vq) {
+    Geom G;
+    geom_eval(cam, m, ls, q, G);
+    const float id = 1.0f / G.det;
+    const float a = G.c11 * id, b = -G.c01 * id, c = G.c00 * id;
+    const float va = v[4], vb = v[5], vc = v[6];
+    // gradient w.r.t. the 2x2 covariance as a full symmetric matrix [[G00,G01],[G01,G11]]
+    const float G00 = -(a * a * va + a * b * vb + b * b * vc);
+    const float G11 = -(b * b * va + b * c * vb + c * c * vc);
+    const float G01 = -0.5f * (2.f * a * b * va + (a * c + b * b) * vb + 2.f * b * c * vc);
+    // GT = Gm * Tm (2x3)
+    float GT[6];
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) {
+      GT[cc] = G00 * G.Tm[cc] + G01 * G.Tm[3 + cc];
+      GT[3 + cc] = G01 * G.Tm[cc] + G11 * G.Tm[3 + cc];
+    }
+    // v_Sigma = Tm^T * GT (3x3 symmetric)
+    float vS[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int cc = 0; cc < 3; cc++) vS[3 * r + cc] = G.Tm[r] * GT[cc] + G.Tm[3 + r] * GT[3 + cc];
+    // v_Tm = 2 * GT * Sigma
+    const float S9[9] = {G.Sig[0], G.Sig[1], G.Sig[2], G.Sig[1], G.Sig[3], G.Sig[4],
+                         G.Sig[2], G.Sig[4], G.Sig[5]};
+    float vTm[6];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+      for (int cc = 0; cc < 3; cc++)
+        vTm[3 * r + cc] = 2.f * (GT[3 * r] * S9[cc] + GT[3 * r + 1] * S9[3 + cc] + GT[3 * r + 2] * S9[6 + cc]);
+    // v_J = v_Tm * R_world^T; only J00, J02, J11, J12 are non-constant
+    const float* R = cam.R;
+    const float vJ00 = vTm[0] * R[0] + vTm[1] * R[1] + vTm[2] * R[2];
+    const float vJ02 = vTm[0] * R[6] + vTm[1] * R[7] + vTm[2] * R[8];
+    const float vJ11 = vTm[3] * R[3] + vTm[4] * R[4] + vTm[5] * R[5];
+    const float vJ12 = vTm[3] * R[6] + vTm[4] * R[7] + vTm[5] * R[8];
+    const float rz = 1.0f / G.tz, rz2 = rz * rz;
+    float vt[3] = {0.f, 0.f, 0.f};
+    vt[2] += -(vJ00 * cam.fx + vJ11 * cam.fy) * rz2;
+    if (G.inx) { vt[0] += -vJ02 * cam.fx * rz2; vt[2] += 2.f * vJ02 * cam.fx * G.tx * rz2 * rz; }
+    else vt[2] += vJ02 * cam.fx * G.ucx * rz2;
+    if (G.iny) { vt[1] += -vJ12 * cam.fy * rz2; vt[2] += 2.f * vJ12 * cam.fy * G.ty * rz2 * rz; }
+    else vt[2] += vJ12 * cam.fy * G.ucy * rz2;
+    // mean2d and depth
+    vt[0] += v[0] * cam.fx * rz; vt[2] += -v[0] * cam.fx * G.tx * rz2;
+    vt[1] += v[1] * cam.fy * rz; vt[2] += -v[1] * cam.fy * G.ty * rz2;
+    vt[2] += v[2];
+#pragma unroll
+    for (int j = 0; j < 3; j++) vm[j] += R[j] * vt[0] + R[3 + j] * vt[1] + R[6 + j] * vt[2];
+    // Sigma = M M^T  ->  v_M = 2 v_Sigma M,  M = Rq diag(s)
+    float vR[9];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      float vMj[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+        vMj[r] = 2.f * (vS[3 * r] * G.Rq[j] + vS[3 * r + 1] * G.Rq[3 + j] + vS[3 * r + 2] * G.Rq[6 + j]) * G.s[j];
+      const float vs = G.Rq[j] * vMj[0] + G.Rq[3 + j] * vMj[1] + G.Rq[6 + j] * vMj[2];
+      vls[j] = vs * G.s[j];
+      vR[j] = vMj[0] * G.s[j]; vR[3 + j] = vMj[1] * G.s[j]; vR[6 + j] = vMj[2] * G.s[j];
+    }
+    const float w = G.qn[0], x = G.qn[1], y = G.qn[2], z = G.qn[3];
+    float vqn[4];
+    vqn[0] = 2.f * (x * (vR[7] - vR[5]) + y * (vR[2] - vR[6]) + z * (vR[3] - vR[1]));
+    vqn[1] = 2.f * (-2.f * x * (vR[4] + vR[8]) + y * (vR[1] + vR[3]) + z * (vR[2] + vR[6]) + w * (vR[7] - vR[5]));
+    vqn[2] = 2.f * (x * (vR[1] + vR[3]) - 2.f * y * (vR[0] + vR[8]) + z * (vR[5] + vR[7]) + w * (vR[2] - vR[6]));
+    vqn[3] = 2.f * (x * (vR[2] + vR[6]) + y * (vR[5] + vR[7]) - 2.f * z * (vR[0] + vR[4]) + w * (vR[3] - vR[1]));
+    const float dot = w * vqn[0] + x * vqn[1] + y * vqn[2] + z * vqn[3];
+    const float iq = 1.0f / G.qnorm;
+#pragma unroll
+    for (int j = 0; j < 4; j++) vq[j] = (vqn[j] - G.qn[j] * dot) * iq;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -338,84 +431,201 @@ __global__ __launch_bounds__(256) void k_project_bwd(
     const float ls[3] = {log_scales[3 * g], log_scales[3 * g + 1], log_scales[3 * g + 2]};
     const float4 q4 = ld4(quats + 4 * (size_t)g);
     const float q[4] = {q4.x, q4.y, q4.z, q4.w};
-    Geom G;
-    geom_eval(cam, m, ls, q, G);
-    const float id = 1.0f / G.det;
-    const float a = G.c11 * id, b = -G.c01 * id, c = G.c00 * id;
-    const float va = v[4], vb = v[5], vc = v[6];
-    // gradient w.r.t. the 2x2 covariance as a full symmetric matrix [[G00,G01],[G01,G11]]
-    const float G00 = -(a * a * va + a * b * vb + b * b * vc);
-    const float G11 = -(b * b * va + b * c * vb + c * c * vc);
-    const float G01 = -0.5f * (2.f * a * b * va + (a * c + b * b) * vb + 2.f * b * c * vc);
-    // GT = Gm * Tm (2x3)
-    float GT[6];
-#pragma unroll
-    for (int cc = 0; cc < 3; cc++) {
-      GT[cc] = G00 * G.Tm[cc] + G01 * G.Tm[3 + cc];
-      GT[3 + cc] = G01 * G.Tm[cc] + G11 * G.Tm[3 + cc];
-    }
-    // v_Sigma = Tm^T * GT (3x3 symmetric)
-    float vS[9];
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int cc = 0; cc < 3; cc++) vS[3 * r + cc] = G.Tm[r] * GT[cc] + G.Tm[3 + r] * GT[3 + cc];
-    // v_Tm = 2 * GT * Sigma
-    const float S9[9] = {G.Sig[0], G.Sig[1], G.Sig[2], G.Sig[1], G.Sig[3], G.Sig[4],
-                         G.Sig[2], G.Sig[4], G.Sig[5]};
-    float vTm[6];
-#pragma unroll
-    for (int r = 0; r < 2; r++)
-#pragma unroll
-      for (int cc = 0; cc < 3; cc++)
-        vTm[3 * r + cc] = 2.f * (GT[3 * r] * S9[cc] + GT[3 * r + 1] * S9[3 + cc] + GT[3 * r + 2] * S9[6 + cc]);
-    // v_J = v_Tm * R_world^T; only J00, J02, J11, J12 are non-constant
-    const float* R = cam.R;
-    const float vJ00 = vTm[0] * R[0] + vTm[1] * R[1] + vTm[2] * R[2];
-    const float vJ02 = vTm[0] * R[6] + vTm[1] * R[7] + vTm[2] * R[8];
-    const float vJ11 = vTm[3] * R[3] + vTm[4] * R[4] + vTm[5] * R[5];
-    const float vJ12 = vTm[3] * R[6] + vTm[4] * R[7] + vTm[5] * R[8];
-    const float rz = 1.0f / G.tz, rz2 = rz * rz;
-    float vt[3] = {0.f, 0.f, 0.f};
-    vt[2] += -(vJ00 * cam.fx + vJ11 * cam.fy) * rz2;
-    if (G.inx) { vt[0] += -vJ02 * cam.fx * rz2; vt[2] += 2.f * vJ02 * cam.fx * G.tx * rz2 * rz; }
-    else vt[2] += vJ02 * cam.fx * G.ucx * rz2;
-    if (G.iny) { vt[1] += -vJ12 * cam.fy * rz2; vt[2] += 2.f * vJ12 * cam.fy * G.ty * rz2 * rz; }
-    else vt[2] += vJ12 * cam.fy * G.ucy * rz2;
-    // mean2d and depth
-    vt[0] += v[0] * cam.fx * rz; vt[2] += -v[0] * cam.fx * G.tx * rz2;
-    vt[1] += v[1] * cam.fy * rz; vt[2] += -v[1] * cam.fy * G.ty * rz2;
-    vt[2] += v[2];
-#pragma unroll
-    for (int j = 0; j < 3; j++) vm[j] += R[j] * vt[0] + R[3 + j] * vt[1] + R[6 + j] * vt[2];
-    // Sigma = M M^T  ->  v_M = 2 v_Sigma M,  M = Rq diag(s)
-    float vR[9];
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      float vMj[3];
-#pragma unroll
-      for (int r = 0; r < 3; r++)
-        vMj[r] = 2.f * (vS[3 * r] * G.Rq[j] + vS[3 * r + 1] * G.Rq[3 + j] + vS[3 * r + 2] * G.Rq[6 + j]) * G.s[j];
-      const float vs = G.Rq[j] * vMj[0] + G.Rq[3 + j] * vMj[1] + G.Rq[6 + j] * vMj[2];
-      vls[j] = vs * G.s[j];
-      vR[j] = vMj[0] * G.s[j]; vR[3 + j] = vMj[1] * G.s[j]; vR[6 + j] = vMj[2] * G.s[j];
-    }
-    const float w = G.qn[0], x = G.qn[1], y = G.qn[2], z = G.qn[3];
-    float vqn[4];
-    vqn[0] = 2.f * (x * (vR[7] - vR[5]) + y * (vR[2] - vR[6]) + z * (vR[3] - vR[1]));
-    vqn[1] = 2.f * (-2.f * x * (vR[4] + vR[8]) + y * (vR[1] + vR[3]) + z * (vR[2] + vR[6]) + w * (vR[7] - vR[5]));
-    vqn[2] = 2.f * (x * (vR[1] + vR[3]) - 2.f * y * (vR[0] + vR[8]) + z * (vR[5] + vR[7]) + w * (vR[2] - vR[6]));
-    vqn[3] = 2.f * (x * (vR[2] + vR[6]) + y * (vR[5] + vR[7]) - 2.f * z * (vR[0] + vR[4]) + w * (vR[3] - vR[1]));
-    const float dot = w * vqn[0] + x * vqn[1] + y * vqn[2] + z * vqn[3];
-    const float iq = 1.0f / G.qnorm;
-#pragma unroll
-    for (int j = 0; j < 4; j++) vq[j] = (vqn[j] - G.qn[j] * dot) * iq;
+    geom_bwd(cam, m, ls, q, v, vm, vls, vq);
   }
   v_means[3 * g] = vm[0]; v_means[3 * g + 1] = vm[1]; v_means[3 * g + 2] = vm[2];
   v_log_scales[3 * g] = vls[0]; v_log_scales[3 * g + 1] = vls[1]; v_log_scales[3 * g + 2] = vls[2];
   st4(v_quats + 4 * (size_t)g, make_float4(vq[0], vq[1], vq[2], vq[3]));
   if (v_xy) {
     v_xy[2 * g] = v[0]; v_xy[2 * g + 1] = v[1];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K8 with LDS-staged SH rows (and optionally Adam fused in)
+// ---------------------------------------------------------------------------------------------
+// A workgroup owns 256 consecutive Gaussians whose SH rows are one contiguous 256*3K-float block.
+// It is moved with fully coalesced 16-B accesses into an LDS image [256][3K+4] (the +4 pad makes
+// the per-thread ds_read_b128 of a row conflict-free), each thread reads its own row from LDS,
+// writes its SH gradient row back into the same LDS image, and the block then streams the image
+// out coalesced -- either as v_sh, or (FUSE_ADAM) straight through the Adam update of sh/m/v, so
+// that the 12K-float SH gradient never touches HBM.  The 11 non-SH parameters per Gaussian are
+// updated by their owner thread.
+template <int DEG, bool FUSE_ADAM>
+__global__ __launch_bounds__(256) void k_project_bwd_lds(
+    CamK cam, int N, float* __restrict__ means, float* __restrict__ log_scales,
+    float* __restrict__ quats, float* __restrict__ opac_logit, float* __restrict__ sh,
+    const float* __restrict__ splats, const int32_t* __restrict__ group_base,
+    const float* __restrict__ partials, float* __restrict__ v_means,
+    float* __restrict__ v_log_scales, float* __restrict__ v_quats,
+    float* __restrict__ v_opac_logit, float* __restrict__ v_sh, float* __restrict__ v_xy,
+    AdamK ad, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq) {
+  constexpr int K = (DEG + 1) * (DEG + 1);   // requires sh_stride == K here (3K % 4 == 0)
+  constexpr int ROW = 3 * K, RS = ROW + 4, F4 = ROW / 4;
+  extern __shared__ float4 lds4[];
+  float* lds = reinterpret_cast<float*>(lds4);
+  const int tid = threadIdx.x;
+  const int g0 = blockIdx.x * 256;
+  const int g = g0 + tid;
+  const int nrows = min(256, N - g0);
+  const size_t blk = (size_t)g0 * ROW;
+
+  {
+    const int nf = nrows * F4;
+    for (int f0 = tid; f0 < nf; f0 += 256 * 4) {
+      float4 t[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) if (f0 + 256 * u < nf) t[u] = ld4(sh + blk + 4 * (size_t)(f0 + 256 * u));
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int f = f0 + 256 * u;
+        if (f < nf) { const int row = f / F4, c4 = f - row * F4; st4(lds + row * RS + 4 * c4, t[u]); }
+      }
+    }
+  }
+  __syncthreads();
+
+  float vm[3] = {0.f, 0.f, 0.f}, vls[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f};
+  float m[3] = {0.f, 0.f, 0.f}, ls[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f};
+  float ol = 0.f, vol = 0.f;
+  if (g < N) {
+    float v[10];
+    sum_partials(cam, splats, group_base, partials, g, v);
+    m[0] = means[3 * g]; m[1] = means[3 * g + 1]; m[2] = means[3 * g + 2];
+    ol = opac_logit[g];
+    const float o = 1.0f / (1.0f + expf(-ol));
+    vol = v[3] * o * (1.0f - o);
+    // ---- SH colour backward (B.5), coefficients from / gradients to the LDS row ----
+    float dx = m[0] - cam.campos[0], dy = m[1] - cam.campos[1], dz = m[2] - cam.campos[2];
+    const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    const float d[3] = {dx * inv, dy * inv, dz * inv};
+    float Y[16];
+    sh_basis<DEG>(d[0], d[1], d[2], Y);
+    float* row = lds + tid * RS;
+    float ck[ROW];
+#pragma unroll
+    for (int i = 0; i < F4; i++) {
+      const float4 t = ld4(row + 4 * i);
+      ck[4 * i] = t.x; ck[4 * i + 1] = t.y; ck[4 * i + 2] = t.z; ck[4 * i + 3] = t.w;
+    }
+    float col[3] = {0.5f, 0.5f, 0.5f};
+#pragma unroll
+    for (int k = 0; k < K; k++)
+#pragma unroll
+      for (int ch = 0; ch < 3; ch++) col[ch] += Y[k] * ck[3 * k + ch];
+    float vr[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) vr[ch] = (col[ch] > 0.f) ? v[7 + ch] : 0.f;  // clamp gate
+    if constexpr (DEG >= 1) {
+      float dY[K][3];
+      sh_basis_grad<DEG>(d[0], d[1], d[2], dY);
+      float vd[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 1; k < K; k++) {
+        const float s = ck[3 * k] * vr[0] + ck[3 * k + 1] * vr[1] + ck[3 * k + 2] * vr[2];
+        vd[0] += dY[k][0] * s; vd[1] += dY[k][1] * s; vd[2] += dY[k][2] * s;
+      }
+      const float dot = d[0] * vd[0] + d[1] * vd[1] + d[2] * vd[2];
+#pragma unroll
+      for (int j = 0; j < 3; j++) vm[j] += (vd[j] - d[j] * dot) * inv;
+    }
+    // own row <- SH gradient (only this thread ever touches this row before the barrier)
+#pragma unroll
+    for (int i = 0; i < F4; i++) {
+      float4 t;
+      t.x = Y[(4 * i) / 3] * vr[(4 * i) % 3];
+      t.y = Y[(4 * i + 1) / 3] * vr[(4 * i + 1) % 3];
+      t.z = Y[(4 * i + 2) / 3] * vr[(4 * i + 2) % 3];
+      t.w = Y[(4 * i + 3) / 3] * vr[(4 * i + 3) % 3];
+      st4(row + 4 * i, t);
+    }
+    // ---- geometry backward (B.8) ----
+    if (splats[(size_t)g * TGS_SPLAT_FLOATS + 4] > 0.f) {
+      ls[0] = log_scales[3 * g]; ls[1] = log_scales[3 * g + 1]; ls[2] = log_scales[3 * g + 2];
+      const float4 q4 = ld4(quats + 4 * (size_t)g);
+      q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+      geom_bwd(cam, m, ls, q, v, vm, vls, vq);
+    } else if (FUSE_ADAM) {
+      ls[0] = log_scales[3 * g]; ls[1] = log_scales[3 * g + 1]; ls[2] = log_scales[3 * g + 2];
+      const float4 q4 = ld4(quats + 4 * (size_t)g);
+      q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+    }
+    if (v_xy) { v_xy[2 * g] = v[0]; v_xy[2 * g + 1] = v[1]; }
+    if constexpr (!FUSE_ADAM) {
+      v_means[3 * g] = vm[0]; v_means[3 * g + 1] = vm[1]; v_means[3 * g + 2] = vm[2];
+      v_log_scales[3 * g] = vls[0]; v_log_scales[3 * g + 1] = vls[1]; v_log_scales[3 * g + 2] = vls[2];
+      st4(v_quats + 4 * (size_t)g, make_float4(vq[0], vq[1], vq[2], vq[3]));
+      v_opac_logit[g] = vol;
+    } else {
+      // Adam on the 11 non-SH parameters of this Gaussian (flat-buffer offsets from the layout)
+      float* ea = exp_avg; float* es = exp_avg_sq;
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const long long e = 3ll * g + j;
+        float pm = m[j], M = ea[e], V = es[e];
+        adam1(ad, ad.lr_means, pm, vm[j], M, V);
+        means[3 * g + j] = pm; ea[e] = M; es[e] = V;
+      }
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const long long e = ad.e_means + 3ll * g + j;
+        float pl = ls[j], M = ea[e], V = es[e];
+        adam1(ad, ad.lr_scales, pl, vls[j], M, V);
+        log_scales[3 * g + j] = pl; ea[e] = M; es[e] = V;
+      }
+      {
+        const long long e = ad.e_scales + 4ll * g;
+        float4 M = ld4(ea + e), V = ld4(es + e);
+        float4 Q = make_float4(q[0], q[1], q[2], q[3]);
+        adam1(ad, ad.lr_quats, Q.x, vq[0], M.x, V.x); adam1(ad, ad.lr_quats, Q.y, vq[1], M.y, V.y);
+        adam1(ad, ad.lr_quats, Q.z, vq[2], M.z, V.z); adam1(ad, ad.lr_quats, Q.w, vq[3], M.w, V.w);
+        st4(quats + 4 * (size_t)g, Q); st4(ea + e, M); st4(es + e, V);
+      }
+      {
+        const long long e = ad.e_quats + g;
+        float po = ol, M = ea[e], V = es[e];
+        adam1(ad, ad.lr_opac, po, vol, M, V);
+        opac_logit[g] = po; ea[e] = M; es[e] = V;
+      }
+    }
+  }
+  __syncthreads();
+  // coalesced stream of the block's SH gradient image (2 float4 columns per thread per round so
+  // that 6 independent loads are in flight)
+  const int nf = nrows * F4;
+  for (int f0 = tid; f0 < nf; f0 += 256 * 2) {
+    if constexpr (!FUSE_ADAM) {
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int f = f0 + 256 * u;
+        if (f < nf) { const int row = f / F4, c4 = f - row * F4; st4(v_sh + blk + 4 * (size_t)f, ld4(lds + row * RS + 4 * c4)); }
+      }
+    } else {
+      float4 P[2], M[2], V[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int f = f0 + 256 * u;
+        if (f < nf) {
+          const size_t e = blk + 4 * (size_t)f;
+          P[u] = ld4(sh + e); M[u] = ld4(exp_avg + ad.e_opac + e); V[u] = ld4(exp_avg_sq + ad.e_opac + e);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int f = f0 + 256 * u;
+        if (f < nf) {
+          const int row = f / F4, c4 = f - row * F4;
+          const float4 G = ld4(lds + row * RS + 4 * c4);
+          const size_t e = blk + 4 * (size_t)f;
+          const int c = 4 * c4;  // column of the first element inside the 3K-float row; DC = columns 0..2
+          adam1(ad, c < 3 ? ad.lr_dc : ad.lr_rest, P[u].x, G.x, M[u].x, V[u].x);
+          adam1(ad, c + 1 < 3 ? ad.lr_dc : ad.lr_rest, P[u].y, G.y, M[u].y, V[u].y);
+          adam1(ad, c + 2 < 3 ? ad.lr_dc : ad.lr_rest, P[u].z, G.z, M[u].z, V[u].z);
+          adam1(ad, ad.lr_rest, P[u].w, G.w, M[u].w, V[u].w);
+          st4(sh + e, P[u]); st4(exp_avg + ad.e_opac + e, M[u]); st4(exp_avg_sq + ad.e_opac + e, V[u]);
+        }
+      }
+    }
   }
 }
 
@@ -486,6 +696,22 @@ extern "C" int tgs_project_bwd(const TgsCamera* cam, int N, const float* means,
   const CamK k = make_camk(cam);
   const dim3 grid((N + 255) / 256), block(256);
   hipStream_t s = (hipStream_t)stream;
+  // fast path: SH rows staged through LDS (needs a dense [N,K,3] tensor with 3K % 4 == 0)
+  if (partials && sh && v_sh && sh_deg >= 1 && sh_stride == (sh_deg + 1) * (sh_deg + 1) &&
+      (3 * sh_stride) % 4 == 0) {
+    AdamK none{};
+    const size_t lds_bytes = 256 * (size_t)(3 * sh_stride + 4) * sizeof(float);
+#define LAUNCH_LDS(D)                                                                            \
+  hipLaunchKernelGGL((k_project_bwd_lds<D, false>), grid, block, lds_bytes, s, k, N,             \
+                     const_cast<float*>(means), const_cast<float*>(log_scales),                  \
+                     const_cast<float*>(quats), const_cast<float*>(opac_logit),                  \
+                     const_cast<float*>(sh), splats, group_base, partials, v_means, v_log_scales,\
+                     v_quats, v_opac_logit, v_sh, v_xy, none, (float*)nullptr, (float*)nullptr)
+    if (sh_deg == 3) LAUNCH_LDS(3); else LAUNCH_LDS(1);
+#undef LAUNCH_LDS
+    TGS_CHECK_LAUNCH();
+    return TGS_OK;
+  }
 #define LAUNCH(D)                                                                                \
   hipLaunchKernelGGL(k_project_bwd<D>, grid, block, 0, s, k, N, means, log_scales, quats,        \
                      opac_logit, sh, sh_stride, splats, group_base, partials, v_splats, v_means, \
@@ -498,6 +724,37 @@ extern "C" int tgs_project_bwd(const TgsCamera* cam, int N, const float* means,
     default: LAUNCH(-1); break;
   }
 #undef LAUNCH
+  TGS_CHECK_LAUNCH();
+  return TGS_OK;
+}
+
+extern "C" int tgs_project_bwd_adam(const TgsCamera* cam, int N, int sh_stride, int sh_deg,
+                                    float* params, float* exp_avg, float* exp_avg_sq,
+                                    const TgsAdamSpec* spec, const float* splats,
+                                    const int32_t* group_base, const float* partials, float* v_xy,
+                                    void* stream) {
+  TGS_CHECK_ARG(camera_ok(cam), "bad camera");
+  if (N <= 0) return TGS_OK;
+  TGS_CHECK_ARG(params && exp_avg && exp_avg_sq && spec && splats && group_base && partials, "null pointer");
+  TGS_CHECK_ARG((sh_deg == 3 || sh_deg == 1) && sh_stride == (sh_deg + 1) * (sh_deg + 1),
+                "fused K8+Adam needs a dense SH tensor at its full degree (1 or 3)");
+  const CamK k = make_camk(cam);
+  const AdamK a = make_adamk(N, sh_stride, spec, 1.0f);
+  float* means = params;
+  float* log_scales = params + a.e_means;
+  float* quats = params + a.e_scales;
+  float* opac = params + a.e_quats;
+  float* sh = params + a.e_opac;
+  const dim3 grid((N + 255) / 256), block(256);
+  const size_t lds_bytes = 256 * (size_t)(3 * sh_stride + 4) * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_F(D)                                                                              \
+  hipLaunchKernelGGL((k_project_bwd_lds<D, true>), grid, block, lds_bytes, s, k, N, means,       \
+                     log_scales, quats, opac, sh, splats, group_base, partials, (float*)nullptr, \
+                     (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, v_xy, a,\
+                     exp_avg, exp_avg_sq)
+  if (sh_deg == 3) LAUNCH_F(3); else LAUNCH_F(1);
+#undef LAUNCH_F
   TGS_CHECK_LAUNCH();
   return TGS_OK;
 }

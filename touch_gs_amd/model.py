@@ -87,6 +87,7 @@ class DepthGaussianSplattingModel:
     def populate_modules(self):
         self.optimizer = FusedAdam(self.params, self.config.lrs())
         self.budget = ops.IntersectBudget()
+        self.fuse_adam = True   # single-process steps use the fused K8+K9 kernel when it applies
         self.last = {}
 
     @property
@@ -175,9 +176,10 @@ class DepthGaussianSplattingModel:
                         uncertainty_weight=c.uncertainty_weight, eps=c.depth_eps)
         return spec
 
-    def forward_backward(self, view: View, want_v_xy: bool = False):
-        """Forward + loss + backward of one view into ``params.grad`` (overwritten).  No host sync
-        unless ``budget.sync``.  Returns device tensors (l1+depth tile losses, ssim sum)."""
+    def forward_backward(self, view: View, want_v_xy: bool = False, fuse_adam: bool = False):
+        """Forward + loss + backward of one view into ``params.grad`` (overwritten) -- or, with
+        ``fuse_adam``, straight through the optimizer update (K8+K9 fused, ``params.grad`` untouched).
+        No host sync unless ``budget.sync``.  Returns device tensors (l1+depth tile losses, ssim sum)."""
         p, c, cam = self.params, self.config, view.cam
         deg = self.active_sh_degree()
         H, W = cam.H, cam.W
@@ -190,9 +192,12 @@ class DepthGaussianSplattingModel:
         partials, tile_loss = ops.rasterize_bwd(cam, splats, group_base, sorted_gid, tile_start, rgb,
                                                 depth_acc, fT, v_rgb=v_img,
                                                 loss=self.loss_spec(view), want_tile_loss=True)
-        out = ops.project_bwd(cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, splats,
-                              group_base, partials, out=p.grad_views(), want_v_xy=want_v_xy)
-        self.last = dict(rgb=rgb, depth_acc=depth_acc, final_T=fT, splats=splats, v_xy=out[5],
+        if fuse_adam:
+            v_xy = self.optimizer.backward_and_step(cam, deg, splats, group_base, partials, want_v_xy)
+        else:
+            v_xy = ops.project_bwd(cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, splats,
+                                   group_base, partials, out=p.grad_views(), want_v_xy=want_v_xy)[5]
+        self.last = dict(rgb=rgb, depth_acc=depth_acc, final_T=fT, splats=splats, v_xy=v_xy,
                          tile_loss=tile_loss, ssim_sum=ssim_sum)
         return tile_loss, ssim_sum
 
@@ -207,10 +212,12 @@ class DepthGaussianSplattingModel:
 
     def train_step(self, view: View, dp=None) -> None:
         """One optimizer iteration on one view (per rank).  ``dp``: a parallel.GradSync or None."""
-        self.forward_backward(view)
-        if dp is not None and dp.world > 1:
+        distributed = dp is not None and dp.world > 1
+        fuse = (not distributed) and self.fuse_adam and self.optimizer.can_fuse_with_backward(self.active_sh_degree())
+        self.forward_backward(view, fuse_adam=fuse)
+        if distributed:
             dp.reduce_and_step(self.params.grad, self.optimizer.step_range, self.optimizer.begin_step)
-        else:
+        elif not fuse:
             self.optimizer.step()
         self.step += 1
 

@@ -115,6 +115,23 @@ class FusedAdam:
         self.begin_step()
         self.step_range(0, -1, grad_scale)
 
+    def can_fuse_with_backward(self, sh_deg: int) -> bool:
+        """tgs_project_bwd_adam needs the SH tensor evaluated at its full (dense) degree 1 or 3."""
+        return sh_deg in (1, 3) and self.p.K == (sh_deg + 1) ** 2
+
+    def backward_and_step(self, cam, sh_deg: int, splats, group_base, partials, want_v_xy: bool = False):
+        """K8 + K9 in one launch (single-process training): gradients never reach HBM."""
+        lib = _lib.load()
+        self.begin_step()
+        s = self._spec()
+        cs = cam.c_struct()
+        v_xy = torch.empty(self.p.N, 2, dtype=torch.float32, device=self.p.flat.device) if want_v_xy else None
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.tgs_project_bwd_adam(C.byref(cs), self.p.N, self.p.K, sh_deg, ptr(self.p.flat), ptr(self.exp_avg),
+                                       ptr(self.exp_avg_sq), C.byref(s), ptr(splats), ptr(group_base),
+                                       ptr(partials), ptr(v_xy), stream), "tgs_project_bwd_adam")
+        return v_xy
+
     def state_dict(self):
         return dict(t=self.t, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lrs=self.lrs)
 
