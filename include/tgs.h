@@ -179,7 +179,7 @@ int tgs_adam_step(int N, int sh_stride, float* params, const float* grads, float
 
 /* K10 SSIM (11x11 Gaussian window, sigma 1.5, zero padding) forward + gradient image; the
  *     (1-SSIM) term of the Splatfacto-style loss.
- * out: block_partials[3*ceil(H/16)*ceil(W/16)] per-block sums of the SSIM map (deterministic;
+ * out: block_partials[ceil(H/16)*ceil(W/16)] per-tile sums of the SSIM map (deterministic;
  *      mean SSIM = sum / (3*H*W)),
  *      v_img[H,W,3] = weight * d(sum of SSIM map)/d(img)   (NULL => forward only)
  * tmp: scratch[9*H*W] floats (needed when v_img != NULL). */

@@ -5,16 +5,30 @@ sys.path.insert(0, '.'); sys.path.insert(0, '..')
 from oracle import torch_oracle as O
 from touch_gs_amd import ops, Camera
 
-def run(N, W, H, deg, seed, iters=10):
+def morton_order(means, bits=10):
+    m = means.double()
+    lo, hi = m.min(0).values, m.max(0).values
+    q = ((m - lo) / (hi - lo + 1e-12) * (2 ** bits - 1)).long()
+    code = torch.zeros(len(m), dtype=torch.long)
+    for b in range(bits):
+        for a in range(3):
+            code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+    return torch.argsort(code)
+
+
+def run(N, W, H, deg, seed, iters=10, morton=False):
     dev = torch.device('cuda:0')
     P, c = O.synthetic_scene(N, W, H, deg, seed, dtype=torch.float32)
+    if morton:
+        order = morton_order(P['means'])
+        P = {k: v[order] for k, v in P.items()}
     D = {k: v.to(dev).contiguous() for k, v in P.items()}
     cam = Camera(O.orbit_viewmat(0, 8).numpy(), c['fx'], c['fy'], c['cx'], c['cy'], W, H)
     budget = ops.IntersectBudget()
     sp = ops.project_fwd(cam, D['means'], D['log_scales'], D['quats'], D['opac_logit'], D['sh'], deg)
     gb, ts, sg, st = ops.bin_sort(cam, sp, budget)
     n = st.tolist()[0]
-    print(f'N={N} {W}x{H} I={n} tiles={cam.num_tiles} per-tile={n/cam.num_tiles:.0f} max-tile={int((ts[1:]-ts[:-1]).max())} visible={int((sp[:,4]>0).sum())}')
+    print(f'morton={morton} N={N} {W}x{H} I={n} tiles={cam.num_tiles} per-tile={n/cam.num_tiles:.0f} max-tile={int((ts[1:]-ts[:-1]).max())} visible={int((sp[:,4]>0).sum())}')
     budget.sync = False
     budget.capacity = int(n * 1.2)
     gt = torch.rand(H, W, 3, device=dev); dgt = torch.rand(H, W, device=dev) * 5; unc = torch.rand(H, W, device=dev)
@@ -37,5 +51,5 @@ def run(N, W, H, deg, seed, iters=10):
     print('  alpha mean', float((1-fT).mean()), 'mean last idx', float(fidx.float().mean()))
 
 if __name__ == '__main__':
-    run(100_000, 800, 800, 3, 1235)
     run(1_000_000, 1920, 1080, 3, 1236)
+    run(1_000_000, 1920, 1080, 3, 1236, morton=True)

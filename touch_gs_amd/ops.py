@@ -432,7 +432,7 @@ def ssim_fwd_bwd(img, gt, weight: float = 1.0, want_grad: bool = True):
     img, gt = _f32c(img), _f32c(gt)
     H, W = img.shape[0], img.shape[1]
     dev = img.device
-    nb = 3 * ((H + 15) // 16) * ((W + 15) // 16)
+    nb = ((H + 15) // 16) * ((W + 15) // 16)
     bp = torch.empty(nb, dtype=torch.float32, device=dev)
     v_img = torch.empty_like(img) if want_grad else None
     scratch = torch.empty(9 * H * W, dtype=torch.float32, device=dev) if want_grad else None
