@@ -245,3 +245,30 @@ def test_fused_backward_adam_equals_separate_kernels(dev, deg):
     assert a.optimizer.t == b.optimizer.t == 3
     d = (a.params.flat - b.params.flat).abs()
     assert torch.quantile(d[::7].float(), 0.999).item() < 1e-5 * b.params.flat.abs().max().item()
+
+
+def test_densification_clone_split_cull(dev):
+    from touch_gs_amd.densify import DensifyConfig
+    from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
+    from touch_gs_amd.optim import GaussianParams
+    from touch_gs_amd.scene import make_view, synthetic_gaussians
+    N, W, H, deg = 4000, 160, 96, 1
+    views = [make_view(N, W, H, deg, 7, dev, view=v, n_views=4) for v in range(4)]
+    P, _ = synthetic_gaussians(N, W, H, deg, 99)
+    P["opac_logit"][:200] = -6.0   # nearly transparent -> must be culled
+    params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
+    model = DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=0), params)
+    model.enable_densification(DensifyConfig(warmup_length=4, refine_every=8, densify_grad_thresh=1e-5,
+                                            densify_size_thresh=0.02, cull_alpha_thresh=0.01, reset_alpha_every=0))
+    for step in range(8):
+        model.train_step(views[step % 4])
+    info = model.last_refine
+    assert info["before"] == N and info["culled"] >= 200 and info["cloned"] + info["split"] > 0
+    assert model.params.N == info["after"] and info["after"] != N
+    assert model.optimizer.exp_avg.shape == model.params.flat.shape and model.optimizer.t == 8
+    n1 = model.params.N
+    for step in range(8, 12):   # training continues on the refined set (fused and unfused paths)
+        model.train_step(views[step % 4])
+    assert torch.isfinite(model.params.flat).all() and model.params.N == n1
+    out = model.get_outputs(views[0].cam)
+    assert out["rgb"].shape == (H, W, 3) and torch.isfinite(out["rgb"]).all()

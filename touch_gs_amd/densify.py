@@ -1,0 +1,152 @@
+"""Adaptive density control for the Gaussian model.
+
+Splatfacto-style refinement (defaults of SURVEY App. A.3 -- the reference's own values live in the
+absent nerfstudio fork): every ``refine_every`` steps Gaussians whose average screen-space mean
+gradient exceeds ``densify_grad_thresh`` are cloned (small) or split into ``n_split_samples``
+(large); Gaussians that are nearly transparent or too large are culled; every
+``reset_alpha_every * refine_every`` steps opacities are clamped down.  The parameter buffer is the
+flat SoA store of ``optim.GaussianParams``, so refinement = one gather of the surviving rows + one
+append, and the Adam moments move with their rows (new rows start at zero).
+
+Data-parallel: the three per-Gaussian statistics are reduced across ranks (sum, sum, max -- the C2
+collective of SURVEY 2.2) and the split sampler is seeded from the step, so every replica takes
+identical decisions and the replicas stay bit-identical.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import Optional
+
+import torch
+
+from .optim import FusedAdam, GaussianParams
+
+
+@dataclasses.dataclass
+class DensifyConfig:
+    warmup_length: int = 500
+    refine_every: int = 100
+    densify_grad_thresh: float = 0.0002
+    densify_size_thresh: float = 0.01
+    n_split_samples: int = 2
+    cull_alpha_thresh: float = 0.1
+    cull_scale_thresh: float = 0.5
+    reset_alpha_every: int = 30
+    stop_split_at: int = 15000
+    max_gaussians: int = 5_000_000
+
+
+def quat_to_rotmat(q: torch.Tensor) -> torch.Tensor:
+    q = q / q.norm(dim=-1, keepdim=True)
+    w, x, y, z = q.unbind(-1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                        2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                        2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1).view(-1, 3, 3)
+
+
+class DensityController:
+    def __init__(self, cfg: DensifyConfig, n: int, device):
+        self.cfg = cfg
+        self.reset_stats(n, device)
+
+    def reset_stats(self, n: int, device):
+        self.grad_norm_sum = torch.zeros(n, device=device)
+        self.vis_count = torch.zeros(n, device=device)
+        self.max_radius = torch.zeros(n, device=device)
+
+    @torch.no_grad()
+    def accumulate(self, v_xy: torch.Tensor, radii: torch.Tensor, W: int, H: int):
+        """Per-step statistics: |screen gradient| in NDC-like units (x 0.5 max(W,H), as Splatfacto
+        does), visibility count and the largest normalised screen radius."""
+        vis = radii > 0
+        g = v_xy.norm(dim=-1) * (0.5 * max(W, H))
+        self.grad_norm_sum += torch.where(vis, g, torch.zeros_like(g))
+        self.vis_count += vis.float()
+        self.max_radius = torch.maximum(self.max_radius, radii.float() / float(max(W, H)))
+
+    @torch.no_grad()
+    def sync(self, dp) -> None:
+        """C2: make the statistics identical on all ranks (sum, sum, max)."""
+        if dp is None or dp.world == 1:
+            return
+        import torch.distributed as dist
+        dist.all_reduce(self.grad_norm_sum, op=dist.ReduceOp.SUM)
+        dist.all_reduce(self.vis_count, op=dist.ReduceOp.SUM)
+        dist.all_reduce(self.max_radius, op=dist.ReduceOp.MAX)
+
+    @torch.no_grad()
+    def refine(self, params: GaussianParams, optimizer: FusedAdam, step: int, dp=None):
+        """Clone / split / cull.  Returns (new GaussianParams, new FusedAdam, info dict)."""
+        c = self.cfg
+        self.sync(dp)
+        N, K, dev = params.N, params.K, params.flat.device
+        avg_grad = self.grad_norm_sum / self.vis_count.clamp_min(1)
+        scale_max = torch.exp(params.log_scales).max(dim=-1).values
+        hot = (avg_grad > c.densify_grad_thresh) & (self.vis_count > 0)
+        do_densify = step < c.stop_split_at
+        split = hot & (scale_max > c.densify_size_thresh) & do_densify
+        clone = hot & (scale_max <= c.densify_size_thresh) & do_densify
+        budget = c.max_gaussians - N
+        if budget <= 0:
+            split &= False
+            clone &= False
+        opac = torch.sigmoid(params.opac_logit)
+        cull = (opac < c.cull_alpha_thresh) | (scale_max > c.cull_scale_thresh)
+        keep = ~cull & ~split  # split parents are replaced by their samples
+        names = GaussianParams.NAMES
+        cur = {k: getattr(params, k) for k in names}
+        mom = {k: (GaussianParams.views_of(optimizer.exp_avg, N, K)[k], GaussianParams.views_of(optimizer.exp_avg_sq, N, K)[k])
+               for k in names}
+
+        parts = {k: [cur[k][keep]] for k in names}
+        m_parts = {k: [mom[k][0][keep]] for k in names}
+        v_parts = {k: [mom[k][1][keep]] for k in names}
+
+        def append(rows, overrides=None):
+            n_new = int(rows.shape[0])
+            if n_new == 0:
+                return
+            for k in names:
+                val = cur[k][rows] if overrides is None or k not in overrides else overrides[k]
+                parts[k].append(val)
+                m_parts[k].append(torch.zeros_like(val))
+                v_parts[k].append(torch.zeros_like(val))
+
+        clone_idx = torch.nonzero(clone & ~cull).squeeze(1)
+        append(clone_idx)
+        split_idx = torch.nonzero(split & ~cull).squeeze(1)
+        if split_idx.numel():
+            g = torch.Generator(device="cpu").manual_seed(1_000_003 * (step + 1))
+            S = c.n_split_samples
+            idx = split_idx.repeat(S)
+            noise = torch.randn(idx.shape[0], 3, generator=g).to(dev)
+            R = quat_to_rotmat(cur["quats"][idx])
+            sc = torch.exp(cur["log_scales"][idx])
+            offs = torch.einsum("nij,nj->ni", R, noise * sc)
+            append(idx, dict(means=cur["means"][idx] + offs,
+                             log_scales=cur["log_scales"][idx] - math.log(1.6)))
+        new = {k: torch.cat(parts[k]) for k in names}
+        n_new = new["means"].shape[0]
+        new_params = GaussianParams.from_tensors(*[new[k] for k in names])
+        new_opt = FusedAdam(new_params, optimizer.lrs, optimizer.betas, optimizer.eps)
+        new_opt.t = optimizer.t
+        mv = GaussianParams.views_of(new_opt.exp_avg, n_new, K)
+        vv = GaussianParams.views_of(new_opt.exp_avg_sq, n_new, K)
+        for k in names:
+            mv[k].copy_(torch.cat(m_parts[k]))
+            vv[k].copy_(torch.cat(v_parts[k]))
+        # opacity reset
+        reset = c.reset_alpha_every > 0 and (step // c.refine_every) % c.reset_alpha_every == 0 and step > 0
+        if reset:
+            cap = math.log(2 * c.cull_alpha_thresh / (1 - 2 * c.cull_alpha_thresh))
+            new_params.opac_logit.clamp_(max=cap)
+            mv["opac_logit"].zero_()
+            vv["opac_logit"].zero_()
+        self.reset_stats(n_new, dev)
+        info = dict(before=N, after=n_new, cloned=int(clone_idx.numel()), split=int(split_idx.numel()),
+                    culled=int(cull.sum()), opacity_reset=bool(reset))
+        return new_params, new_opt, info
+
+    def due(self, step: int) -> bool:
+        return step >= self.cfg.warmup_length and step % self.cfg.refine_every == 0 and step > 0

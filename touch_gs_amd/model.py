@@ -183,7 +183,11 @@ class DepthGaussianSplattingModel:
         p, c, cam = self.params, self.config, view.cam
         deg = self.active_sh_degree()
         H, W = cam.H, cam.W
-        splats = ops.project_fwd(cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg)
+        radii = None
+        if want_v_xy:
+            splats, radii = ops.project_fwd(cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, want_radii=True)
+        else:
+            splats = ops.project_fwd(cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg)
         group_base, tile_start, sorted_gid, _ = ops.bin_sort(cam, splats, self.budget)
         rgb, depth_acc, fT, fidx = ops.rasterize_fwd(cam, splats, sorted_gid, tile_start)
         v_img, ssim_sum = None, None
@@ -197,7 +201,7 @@ class DepthGaussianSplattingModel:
         else:
             v_xy = ops.project_bwd(cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, splats,
                                    group_base, partials, out=p.grad_views(), want_v_xy=want_v_xy)[5]
-        self.last = dict(rgb=rgb, depth_acc=depth_acc, final_T=fT, splats=splats, v_xy=v_xy,
+        self.last = dict(rgb=rgb, depth_acc=depth_acc, final_T=fT, splats=splats, v_xy=v_xy, radii=radii,
                          tile_loss=tile_loss, ssim_sum=ssim_sum)
         return tile_loss, ssim_sum
 
@@ -210,16 +214,27 @@ class DepthGaussianSplattingModel:
             main = main + c.ssim_lambda * (1 - ssim_sum / (3 * H * W))
         return {"main_loss": main, "depth_loss": t[1]}
 
+    def enable_densification(self, cfg=None):
+        """Turn on Splatfacto-style clone / split / cull refinement (touch_gs_amd.densify)."""
+        from .densify import DensifyConfig, DensityController
+        self.density = DensityController(cfg or DensifyConfig(), self.params.N, self.params.flat.device)
+
     def train_step(self, view: View, dp=None) -> None:
         """One optimizer iteration on one view (per rank).  ``dp``: a parallel.GradSync or None."""
         distributed = dp is not None and dp.world > 1
         fuse = (not distributed) and self.fuse_adam and self.optimizer.can_fuse_with_backward(self.active_sh_degree())
-        self.forward_backward(view, fuse_adam=fuse)
+        density = getattr(self, "density", None)
+        self.forward_backward(view, want_v_xy=density is not None, fuse_adam=fuse)
+        if density is not None:
+            density.accumulate(self.last["v_xy"], self.last["radii"], view.cam.W, view.cam.H)
         if distributed:
             dp.reduce_and_step(self.params.grad, self.optimizer.step_range, self.optimizer.begin_step)
         elif not fuse:
             self.optimizer.step()
         self.step += 1
+        if density is not None and density.due(self.step):
+            self.params, self.optimizer, self.last_refine = density.refine(self.params, self.optimizer, self.step, dp)
+            self.budget = ops.IntersectBudget()  # the intersection count changes with N
 
     # -- checkpoint -----------------------------------------------------------------------------
     def state_dict(self):

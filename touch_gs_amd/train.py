@@ -86,6 +86,9 @@ def main(argv=None):
     ap.add_argument("--output-dir", type=str, default="outputs")
     ap.add_argument("--load-checkpoint", type=str, default=None)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--densify", action="store_true", help="Splatfacto-style clone/split/cull refinement")
+    ap.add_argument("--refine-every", type=int, default=100)
+    ap.add_argument("--warmup-length", type=int, default=500)
     args = ap.parse_args(argv)
 
     dp = parallel.init_from_env()
@@ -109,6 +112,9 @@ def main(argv=None):
     cfg = ModelConfig(sh_degree=args.sh_degree, depth_loss_mult=args.depth_loss_mult,
                       depth_loss_type=args.depth_loss_type, uncertainty_weight=args.uncertainty_weight)
     model = DepthGaussianSplattingModel(cfg, params)
+    if args.densify:
+        from .densify import DensifyConfig
+        model.enable_densification(DensifyConfig(refine_every=args.refine_every, warmup_length=args.warmup_length))
     if args.load_checkpoint:
         model.load_state_dict(torch.load(args.load_checkpoint, map_location=dev))
     run_dir = os.path.join(args.output_dir, scene_name, "depth-gaussian-splatting", time.strftime("%Y-%m-%d_%H%M%S"))
@@ -129,7 +135,7 @@ def main(argv=None):
         if dp.rank == 0 and ((step + 1) % args.steps_per_save == 0 or step + 1 == args.max_num_iterations):
             torch.save(model.state_dict(), os.path.join(run_dir, f"step-{step + 1:09d}.ckpt"))
     if dp.world > 1:
-        dp.assert_replicas_identical(params.flat)
+        dp.assert_replicas_identical(model.params.flat)
     if dp.rank == 0:
         results = evaluate(model, eval_views)
         with open(os.path.join(run_dir, "eval.json"), "w") as f:
