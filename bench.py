@@ -31,8 +31,8 @@ def algorithmic_bytes(N, I, P, T, K):
     """Compulsory-traffic model of THIS build's data layout, bytes/step."""
     A = 44 + 12 * K                      # parameter bytes per Gaussian
     b = {}
-    b["project_fwd"] = N * (A + 48)
-    b["bin_sort"] = N * (16 + 4) + I * (4 + 4 + 8 + 8 + 4) + 12 * T   # rect read, rank w/r, pair w/r, id w
+    # K1 (+ fused tile count): params in, record out; rank w/r, pair w/r, sorted id w, rect re-read by fill
+    b["project_bin_sort"] = N * (A + 48) + N * 16 + I * (4 + 4 + 8 + 8 + 4) + 12 * T
     b["raster_fwd"] = I * (4 + 48) + P * 24 + 8 * T
     b["ssim"] = P * (24 + 36 + 36 + 12 + 24)
     b["raster_bwd"] = I * (4 + 48 + 48) + P * (24 + 12 + 28) + 8 * T
@@ -153,43 +153,42 @@ def main():
         view = views[0]
         I = n_isect[0]
         ev = lambda: torch.cuda.Event(enable_timing=True)
-        names = ["project_fwd", "bin_sort", "raster_fwd", "ssim", "raster_bwd", "project_bwd", "adam"]
+        names = ["project_bin_sort", "raster_fwd", "ssim", "raster_bwd", "project_bwd", "adam"]
         acc = {k: 0.0 for k in names}
         reps = min(args.steps, 20)
         p = params
         for _ in range(reps):
-            e = [ev() for _ in range(8)]
+            e = [ev() for _ in range(7)]
             e[0].record()
-            sp = ops.project_fwd(view.cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg)
+            sp, _, gb, ts, sg, _ = ops.project_bin_sort(view.cam, p.means, p.log_scales, p.quats, p.opac_logit,
+                                                        p.sh, deg, model.budget)
             e[1].record()
-            gb, ts, sg, _ = ops.bin_sort(view.cam, sp, model.budget)
-            e[2].record()
             rgb, dacc, fT, fidx = ops.rasterize_fwd(view.cam, sp, sg, ts)
-            e[3].record()
+            e[2].record()
             ssim_sum, v_img = ops.ssim_fwd_bwd(rgb, view.rgb, weight=-cfg.ssim_lambda / (3 * H * W))
-            e[4].record()
+            e[3].record()
             partials, tl = ops.rasterize_bwd(view.cam, sp, gb, sg, ts, rgb, dacc, fT, v_rgb=v_img,
                                              loss=model.loss_spec(view), want_tile_loss=True)
-            e[5].record()
+            e[4].record()
             ops.project_bwd(view.cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, sp, gb, partials,
                             out=p.grad_views())
-            e[6].record()
+            e[5].record()
             p.grad.zero_()  # keep the scene fixed while profiling
-            e[7].record()
+            e[6].record()
             model.optimizer.step()
             e7b = ev(); e7b.record()
             torch.cuda.synchronize()
-            for j, k in enumerate(names[:6]):
+            for j, k in enumerate(names[:5]):
                 acc[k] += e[j].elapsed_time(e[j + 1])
-            acc["adam"] += e[7].elapsed_time(e7b)
+            acc["adam"] += e[6].elapsed_time(e7b)
         kern_ms = {k: v / reps for k, v in acc.items()}
         # render-only throughput (K1..K6)
         torch.cuda.synchronize()
         r0 = time.perf_counter()
         rr = 20
         for _ in range(rr):
-            sp = ops.project_fwd(view.cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg)
-            gb, ts, sg, _ = ops.bin_sort(view.cam, sp, model.budget)
+            sp, _, gb, ts, sg, _ = ops.project_bin_sort(view.cam, p.means, p.log_scales, p.quats, p.opac_logit,
+                                                        p.sh, deg, model.budget)
             ops.rasterize_fwd(view.cam, sp, sg, ts)
         torch.cuda.synchronize()
         render_ms = (time.perf_counter() - r0) / rr * 1e3
@@ -218,7 +217,7 @@ def main():
             "step_roofline": {"algorithmic_bytes": step_bytes,
                               "achieved_GBs": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                               "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                              "fwd_bwd_ms": round(sum(kern_ms[k] for k in names[:6] if k != "ssim"), 4)},
+                              "fwd_bwd_ms": round(sum(kern_ms[k] for k in names[:5] if k != "ssim"), 4)},
         }
         if dp.world == 1 and not args.no_cpu_baseline:
             try:

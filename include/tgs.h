@@ -113,6 +113,17 @@ int tgs_bin_sort(const TgsCamera* cam /*[host]*/, int N, float* splats, int32_t*
                  int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
                  int64_t capacity, void* scratch, int32_t* status, void* stream);
 
+/* K1 + K2-K5 in one call (the fast path): the projection workgroup IS the 256-Gaussian binning
+ *     group, so it also builds the group scan and counts its tile intersections -- the records are
+ *     not re-read and the pair offset is stored with the record.  Arguments as in tgs_project_fwd
+ *     (without colors_in) followed by those of tgs_bin_sort. */
+int tgs_project_bin_sort(const TgsCamera* cam /*[host]*/, int N, const float* means,
+                         const float* log_scales, const float* quats, const float* opac_logit,
+                         const float* sh, int sh_stride, int sh_deg, float* splats, int32_t* radii,
+                         int32_t* group_base, int32_t* tile_start, int32_t* tile_cursor,
+                         int32_t* sorted_gid, int64_t capacity, void* scratch, int32_t* status,
+                         void* stream);
+
 /* K6  per-tile front-to-back compositing of RGB + depth in ONE pass  (stands behind gsplat
  *     `rasterize_gaussians` fwd, called twice by Splatfacto for rgb and depth; spec App. B.6).
  * out: out_rgb[H,W,3] (incl. background)  out_depth[H,W] (= sum w*depth, NOT divided by alpha)

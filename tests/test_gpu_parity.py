@@ -378,3 +378,20 @@ def test_selforacle_fixtures_gpu(dev):
             got = D[k].grad.cpu().double().numpy()
             cos = (ref * got).sum() / max(np.sqrt((ref * ref).sum() * (got * got).sum()), 1e-30)
             assert cos > 0.9999, (name, k, cos)
+
+
+def test_fused_project_bin_sort_equals_separate_calls(dev):
+    """tgs_project_bin_sort (K1 fused with the tile count) == tgs_project_fwd + tgs_bin_sort."""
+    from touch_gs_amd import ops
+    for N, W, H, deg, seed in ((5000, 200, 120, 3, 201), (777, 70, 50, 1, 202), (300, 64, 48, 0, 203)):
+        P, cam = scene(N, W, H, deg, seed)
+        acam = amd_cam(cam)
+        D = to_dev(P, dev)
+        sp1, r1 = ops.project_fwd(acam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], deg, want_radii=True)
+        gb1, ts1, sg1, st1 = ops.bin_sort(acam, sp1)
+        sp2, r2, gb2, ts2, sg2, st2 = ops.project_bin_sort(acam, D["means"], D["log_scales"], D["quats"], D["opac_logit"],
+                                                            D["sh"], deg, want_radii=True)
+        n = st1.tolist()[0]
+        assert st2.tolist() == [n, 0] and torch.equal(r1, r2) and torch.equal(ts1, ts2)
+        assert torch.equal(sg1[:n], sg2[:n])
+        assert torch.equal(sp1.view(torch.int32), sp2.view(torch.int32))  # records incl. rect + in-group offset

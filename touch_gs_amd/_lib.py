@@ -44,6 +44,8 @@ SIGNATURES = {
     "tgs_sort_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "tgs_project_fwd": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "tgs_bin_sort": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P]),
+    "tgs_project_bin_sort": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P,
+                                       C.c_int64, _P, _P, _P]),
     "tgs_rasterize_fwd": (C.c_int, [C.POINTER(TgsCamera), _P, _P, _P, _P, _P, _P, _P, _P]),
     "tgs_rasterize_bwd": (C.c_int, [C.POINTER(TgsCamera)] + [_P] * 10 + [C.POINTER(TgsLossSpec), _P, _P, _P]),
     "tgs_reduce_partials": (C.c_int, [_I, _P, _P, C.POINTER(TgsCamera), _P, _P, _P]),

@@ -14,24 +14,15 @@
 // contiguous range [group_base, group_base+total) of the pair index space, so every pass is
 // balanced (one thread per intersection, found by binary search in the group's LDS-resident scan)
 // no matter how many tiles a single Gaussian covers.
-#include "tgs_common.h"
+#include "tgs_binning.h"
 
 namespace {
 
-struct GroupScan {
-  int off[TGS_GROUP + 1];  // exclusive scan of tiles_hit inside the group
-  int x0[TGS_GROUP], y0[TGS_GROUP], w[TGS_GROUP];
-  unsigned depth_bits[TGS_GROUP];
-  int wave_tot[TGS_GROUP / TGS_WAVE];
-  int base;
-};
-
-// Loads the group's rects, builds the in-group exclusive scan.  Returns the group total.
+// Loads the group's rects from the splat records and builds the in-group scan.
 __device__ __forceinline__ int group_load_scan(const CamK& cam, int N,
                                                const float* __restrict__ splats, GroupScan& S,
                                                int& my_off) {
-  const int tid = threadIdx.x;
-  const int g = blockIdx.x * TGS_GROUP + tid;
+  const int g = blockIdx.x * TGS_GROUP + threadIdx.x;
   int hits = 0, x0 = 0, y0 = 0, w = 0;
   unsigned dbits = 0;
   if (g < N) {
@@ -41,42 +32,7 @@ __device__ __forceinline__ int group_load_scan(const CamK& cam, int N,
     hits = w * h;
     dbits = __float_as_uint(rec[2]);
   }
-  // wave-level inclusive scan, then across the 4 waves
-  int incl = hits;
-#pragma unroll
-  for (int o = 1; o < TGS_WAVE; o <<= 1) {
-    const int t = __shfl_up(incl, o);
-    if ((tid & (TGS_WAVE - 1)) >= o) incl += t;
-  }
-  if ((tid & (TGS_WAVE - 1)) == TGS_WAVE - 1) S.wave_tot[tid / TGS_WAVE] = incl;
-  __syncthreads();
-  int wbase = 0, total = 0;
-#pragma unroll
-  for (int i = 0; i < TGS_GROUP / TGS_WAVE; i++) {
-    if (i < tid / TGS_WAVE) wbase += S.wave_tot[i];
-    total += S.wave_tot[i];
-  }
-  my_off = wbase + incl - hits;
-  S.off[tid] = my_off;
-  S.x0[tid] = x0; S.y0[tid] = y0; S.w[tid] = max(w, 1);
-  S.depth_bits[tid] = dbits;
-  if (tid == 0) S.off[TGS_GROUP] = total;
-  return total;
-}
-
-// pair i of the group -> (local Gaussian j, tile id)
-__device__ __forceinline__ void group_pair(const GroupScan& S, int TW, int i, int& j, int& tile) {
-  int lo = 0, hi = TGS_GROUP;
-#pragma unroll
-  for (int it = 0; it < 8; it++) {
-    const int mid = (lo + hi) >> 1;
-    if (S.off[mid] <= i) lo = mid; else hi = mid;
-  }
-  j = lo;
-  const int k = i - S.off[lo];
-  const int w = S.w[lo];
-  const int ky = k / w;
-  tile = (S.y0[lo] + ky) * TW + S.x0[lo] + (k - ky * w);
+  return group_scan_store(S, hits, x0, y0, w, dbits, my_off);
 }
 
 // K3a: count intersections per tile; allocate the group's pair range; remember every pair's
@@ -88,24 +44,9 @@ __global__ __launch_bounds__(TGS_GROUP) void k_tile_count(
   __shared__ GroupScan S;
   int my_off;
   const int total = group_load_scan(cam, N, splats, S, my_off);
-  const int tid = threadIdx.x;
-  const int g = blockIdx.x * TGS_GROUP + tid;
+  const int g = blockIdx.x * TGS_GROUP + threadIdx.x;
   if (g < N) splats[(size_t)g * TGS_SPLAT_FLOATS + 11] = __int_as_float(my_off);
-  if (tid == 0) {
-    const int base = total ? atomicAdd(&status[0], total) : 0;
-    S.base = base;
-    group_base[blockIdx.x] = base;
-    if ((long long)base + total > capacity) status[1] = 1;
-  }
-  __syncthreads();
-  const long long base = S.base;
-  const bool fits = base + total <= capacity;
-  for (int i = tid; i < total; i += TGS_GROUP) {
-    int j, tile;
-    group_pair(S, cam.TW, i, j, tile);
-    const int r = atomicAdd(&tile_count[tile], 1);
-    if (fits) rank[base + i] = r;
-  }
+  group_count_tiles(S, cam.TW, total, group_base, tile_count, rank, status, capacity);
 }
 
 // K4: exclusive scan of tile counts -> tile_start[T+1] (single workgroup; T is a few 10^4).
@@ -256,6 +197,32 @@ extern "C" size_t tgs_sort_scratch_bytes(int64_t capacity) {
   return (size_t)capacity * (8 + 16 + 4) + 64;
 }
 
+int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* group_base,
+                   int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid, int64_t capacity,
+                   void* scratch, int32_t* status, hipStream_t s) {
+  const int T = k.TW * k.TH;
+  const int G = tgs_num_groups(N);
+  const BinScratch sc = carve_scratch(scratch, capacity);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, T, tile_cursor, tile_start, status);
+  TGS_CHECK_LAUNCH();
+  if (G > 0) {
+    hipLaunchKernelGGL(k_fill_bins, dim3(G), dim3(TGS_GROUP), 0, s, k, N, splats, group_base,
+                       tile_start, sc.rank, (uint2*)sc.pairs, status);
+    TGS_CHECK_LAUNCH();
+    const int small_grid = T < 256 ? T : 256;
+    hipLaunchKernelGGL((k_sort_tiles_lds<SORT_CAP_A, 256, 0>), dim3(T), dim3(256), 0, s, T,
+                       tile_start, sc.pairs, sorted_gid);
+    TGS_CHECK_LAUNCH();
+    hipLaunchKernelGGL((k_sort_tiles_lds<SORT_CAP_B, 1024, SORT_CAP_A>), dim3(small_grid),
+                       dim3(1024), 0, s, T, tile_start, sc.pairs, sorted_gid);
+    TGS_CHECK_LAUNCH();
+    hipLaunchKernelGGL((k_sort_tiles_global<SORT_CAP_B>), dim3(small_grid), dim3(1024), 0, s, T,
+                       tile_start, sc.pairs, sc.fb, sorted_gid);
+    TGS_CHECK_LAUNCH();
+  }
+  return TGS_OK;
+}
+
 extern "C" int tgs_bin_sort(const TgsCamera* cam, int N, float* splats, int32_t* group_base,
                             int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
                             int64_t capacity, void* scratch, int32_t* status, void* stream) {
@@ -269,32 +236,14 @@ extern "C" int tgs_bin_sort(const TgsCamera* cam, int N, float* splats, int32_t*
   const int T = k.TW * k.TH;
   const int G = tgs_num_groups(N);
   hipStream_t s = (hipStream_t)stream;
-  unsigned long long* pairs = (unsigned long long*)scratch;
-  unsigned long long* fb = pairs + capacity;
-  int32_t* rank = (int32_t*)(fb + 2 * capacity);
+  const BinScratch sc = carve_scratch(scratch, capacity);
   TGS_HIP(hipMemsetAsync(tile_cursor, 0, sizeof(int32_t) * (size_t)T, s));
   TGS_HIP(hipMemsetAsync(status, 0, sizeof(int32_t) * 2, s));
   if (G > 0) {
     hipLaunchKernelGGL(k_tile_count, dim3(G), dim3(TGS_GROUP), 0, s, k, N, splats, group_base,
-                       tile_cursor, rank, status, (long long)capacity);
+                       tile_cursor, sc.rank, status, (long long)capacity);
     TGS_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, T, tile_cursor, tile_start, status);
-  TGS_CHECK_LAUNCH();
-  if (G > 0) {
-    hipLaunchKernelGGL(k_fill_bins, dim3(G), dim3(TGS_GROUP), 0, s, k, N, splats, group_base,
-                       tile_start, rank, (uint2*)pairs, status);
-    TGS_CHECK_LAUNCH();
-    const int small_grid = T < 256 ? T : 256;
-    hipLaunchKernelGGL((k_sort_tiles_lds<SORT_CAP_A, 256, 0>), dim3(T), dim3(256), 0, s, T,
-                       tile_start, pairs, sorted_gid);
-    TGS_CHECK_LAUNCH();
-    hipLaunchKernelGGL((k_sort_tiles_lds<SORT_CAP_B, 1024, SORT_CAP_A>), dim3(small_grid),
-                       dim3(1024), 0, s, T, tile_start, pairs, sorted_gid);
-    TGS_CHECK_LAUNCH();
-    hipLaunchKernelGGL((k_sort_tiles_global<SORT_CAP_B>), dim3(small_grid), dim3(1024), 0, s, T,
-                       tile_start, pairs, fb, sorted_gid);
-    TGS_CHECK_LAUNCH();
-  }
-  return TGS_OK;
+  return tgs_bin_finish(k, N, splats, group_base, tile_start, tile_cursor, sorted_gid, capacity,
+                        scratch, status, s);
 }

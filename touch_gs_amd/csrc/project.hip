@@ -8,6 +8,7 @@
 // Roofline: pure streaming, HBM bound.  Forward reads 44+12K B and writes 48 B per Gaussian;
 // backward reads 44+12K+48 (+48*tiles_hit of partials) and writes 44+12K (+8) B per Gaussian.
 #include "tgs_adam.h"
+#include "tgs_binning.h"
 
 namespace {
 
@@ -141,14 +142,22 @@ __device__ __forceinline__ void geom_eval(const CamK& cam, const float* m, const
 // ---------------------------------------------------------------------------------------------
 // K1 forward
 // ---------------------------------------------------------------------------------------------
-template <int DEG>  // DEG = -1: no SH (colours from colors_in or zero)
+// FUSED: the workgroup (= one 256-Gaussian binning group) also builds the group scan, allocates the
+// group's pair range and counts its (tile, Gaussian) intersections (K3a), so the records are not
+// re-read and the pair offset is stored with the record instead of patched into it afterwards.
+template <int DEG, bool FUSED>  // DEG = -1: no SH (colours from colors_in or zero)
 __global__ __launch_bounds__(256) void k_project_fwd(
     CamK cam, int N, const float* __restrict__ means, const float* __restrict__ log_scales,
     const float* __restrict__ quats, const float* __restrict__ opac_logit,
     const float* __restrict__ sh, int sh_stride, const float* __restrict__ colors_in,
-    float* __restrict__ splats, int32_t* __restrict__ radii) {
+    float* __restrict__ splats, int32_t* __restrict__ radii, int32_t* __restrict__ group_base,
+    int32_t* __restrict__ tile_count, int32_t* __restrict__ rank, int32_t* __restrict__ status,
+    long long capacity) {
   const int g = blockIdx.x * 256 + threadIdx.x;
-  if (g >= N) return;
+  if constexpr (!FUSED) { if (g >= N) return; }
+  unsigned rect = 0u;
+  float tz = 0.f, c1 = 0.f, c2 = 0.f;
+  if (g < N) {
   const float m[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
   const float ls[3] = {log_scales[3 * g], log_scales[3 * g + 1], log_scales[3 * g + 2]};
   const float4 q4 = ld4(quats + 4 * (size_t)g);
@@ -177,7 +186,6 @@ __global__ __launch_bounds__(256) void k_project_fwd(
   geom_eval(cam, m, ls, q, G);
   float x2 = 0.f, y2 = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
   int radius = 0;
-  unsigned rect = 0u;
   if (G.tz > cam.near_plane) {
     const float rz = 1.0f / G.tz;
     x2 = cam.fx * G.tx * rz + cam.cx;
@@ -208,11 +216,25 @@ __global__ __launch_bounds__(256) void k_project_fwd(
     }
   }
   if (radius == 0) { ca = 0.f; cb = 0.f; cc = 0.f; }  // conic != 0  <=>  passed the App. B culls
+  tz = G.tz;
   float* o = splats + (size_t)g * TGS_SPLAT_FLOATS;
   st4(o, make_float4(x2, y2, G.tz, opac));
   st4(o + 4, make_float4(ca, cb, cc, rgb[0]));
-  st4(o + 8, make_float4(rgb[1], rgb[2], __uint_as_float(rect), 0.f));
+  if constexpr (!FUSED) st4(o + 8, make_float4(rgb[1], rgb[2], __uint_as_float(rect), 0.f));
+  else { c1 = rgb[1]; c2 = rgb[2]; }   // third 16-B store follows once the group scan is known
   if (radii) radii[g] = radius;
+  }  // g < N
+  if constexpr (FUSED) {
+    __shared__ GroupScan S;
+    int x0, y0, w, h, my_off;
+    unpack_rect(rect, x0, y0, w, h);
+    const int total = group_scan_store(S, w * h, x0, y0, w, __float_as_uint(tz), my_off);
+    if (g < N) {
+      float* o = splats + (size_t)g * TGS_SPLAT_FLOATS;
+      st4(o + 8, make_float4(c1, c2, __uint_as_float(rect), __int_as_float(my_off)));
+    }
+    group_count_tiles(S, cam.TW, total, group_base, tile_count, rank, status, capacity);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -651,8 +673,9 @@ extern "C" int tgs_project_fwd(const TgsCamera* cam, int N, const float* means,
   const dim3 grid((N + 255) / 256), block(256);
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(D)                                                                              \
-  hipLaunchKernelGGL(k_project_fwd<D>, grid, block, 0, s, k, N, means, log_scales, quats,      \
-                     opac_logit, sh, sh_stride, colors_in, splats, radii)
+  hipLaunchKernelGGL((k_project_fwd<D, false>), grid, block, 0, s, k, N, means, log_scales, quats, \
+                     opac_logit, sh, sh_stride, colors_in, splats, radii, (int32_t*)nullptr,       \
+                     (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, 0ll)
   switch (sh_deg) {
     case 0: LAUNCH(0); break;
     case 1: LAUNCH(1); break;
@@ -757,4 +780,45 @@ extern "C" int tgs_project_bwd_adam(const TgsCamera* cam, int N, int sh_stride, 
 #undef LAUNCH_F
   TGS_CHECK_LAUNCH();
   return TGS_OK;
+}
+
+// K1 + K3a fused, then scan / fill / sort: the whole front half of a frame in one call.
+extern "C" int tgs_project_bin_sort(const TgsCamera* cam, int N, const float* means,
+                                    const float* log_scales, const float* quats,
+                                    const float* opac_logit, const float* sh, int sh_stride,
+                                    int sh_deg, float* splats, int32_t* radii, int32_t* group_base,
+                                    int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
+                                    int64_t capacity, void* scratch, int32_t* status, void* stream) {
+  TGS_CHECK_ARG(camera_ok(cam), "bad camera");
+  TGS_CHECK_ARG(N >= 0 && capacity >= 0 && capacity < (1ll << 31), "bad size");
+  TGS_CHECK_ARG(cam->W <= 4080 && cam->H <= 4080, "image side > 4080 px (255 tiles)");
+  TGS_CHECK_ARG(group_base && tile_start && tile_cursor && sorted_gid && scratch && status, "null pointer");
+  TGS_CHECK_ARG(N == 0 || (means && log_scales && quats && opac_logit && splats), "null pointer");
+  if (!sh) sh_deg = -1;
+  TGS_CHECK_ARG(sh_deg <= 3, "sh_deg > 3");
+  TGS_CHECK_ARG(sh_deg < 0 || sh_stride >= (sh_deg + 1) * (sh_deg + 1), "sh_stride too small");
+  const CamK k = make_camk(cam);
+  const int T = k.TW * k.TH;
+  hipStream_t s = (hipStream_t)stream;
+  const BinScratch sc = carve_scratch(scratch, capacity);
+  TGS_HIP(hipMemsetAsync(tile_cursor, 0, sizeof(int32_t) * (size_t)T, s));
+  TGS_HIP(hipMemsetAsync(status, 0, sizeof(int32_t) * 2, s));
+  if (N > 0) {
+    const dim3 grid((N + 255) / 256), block(256);
+#define LAUNCH(D)                                                                                  \
+  hipLaunchKernelGGL((k_project_fwd<D, true>), grid, block, 0, s, k, N, means, log_scales, quats,  \
+                     opac_logit, sh, sh_stride, (const float*)nullptr, splats, radii, group_base,   \
+                     tile_cursor, sc.rank, status, (long long)capacity)
+    switch (sh_deg) {
+      case 0: LAUNCH(0); break;
+      case 1: LAUNCH(1); break;
+      case 2: LAUNCH(2); break;
+      case 3: LAUNCH(3); break;
+      default: LAUNCH(-1); break;
+    }
+#undef LAUNCH
+    TGS_CHECK_LAUNCH();
+  }
+  return tgs_bin_finish(k, N, splats, group_base, tile_start, tile_cursor, sorted_gid, capacity,
+                        scratch, status, s);
 }

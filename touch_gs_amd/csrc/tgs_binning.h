@@ -1,0 +1,101 @@
+// tgs_binning.h -- pieces of the tile-binning pass shared by binning.hip and the fused
+// projection+count kernel in project.hip.
+#pragma once
+#include "tgs_common.h"
+
+// scratch layout of tgs_bin_sort: pairs u64[cap] | fallback u64[2*cap] | rank i32[cap]
+struct BinScratch {
+  unsigned long long* pairs;
+  unsigned long long* fb;
+  int32_t* rank;
+};
+static inline BinScratch carve_scratch(void* scratch, int64_t capacity) {
+  BinScratch b;
+  b.pairs = (unsigned long long*)scratch;
+  b.fb = b.pairs + capacity;
+  b.rank = (int32_t*)(b.fb + 2 * capacity);
+  return b;
+}
+
+// scan + fill + sort (everything after the per-tile counts exist); defined in binning.hip
+int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* group_base,
+                   int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid, int64_t capacity,
+                   void* scratch, int32_t* status, hipStream_t s);
+
+#ifdef __HIPCC__
+struct GroupScan {
+  int off[TGS_GROUP + 1];  // exclusive scan of tiles_hit inside the group
+  int x0[TGS_GROUP], y0[TGS_GROUP], w[TGS_GROUP];
+  unsigned depth_bits[TGS_GROUP];
+  int wave_tot[TGS_GROUP / TGS_WAVE];
+  int base;
+};
+
+// Builds the in-group exclusive scan from each thread's (rect, depth).  Returns the group total.
+// Must be called by all 256 threads; the caller synchronises before reading S.
+__device__ __forceinline__ int group_scan_store(GroupScan& S, int hits, int x0, int y0, int w,
+                                                unsigned dbits, int& my_off) {
+  const int tid = threadIdx.x;
+  int incl = hits;
+#pragma unroll
+  for (int o = 1; o < TGS_WAVE; o <<= 1) {
+    const int t = __shfl_up(incl, o);
+    if ((tid & (TGS_WAVE - 1)) >= o) incl += t;
+  }
+  if ((tid & (TGS_WAVE - 1)) == TGS_WAVE - 1) S.wave_tot[tid / TGS_WAVE] = incl;
+  __syncthreads();
+  int wbase = 0, total = 0;
+#pragma unroll
+  for (int i = 0; i < TGS_GROUP / TGS_WAVE; i++) {
+    if (i < tid / TGS_WAVE) wbase += S.wave_tot[i];
+    total += S.wave_tot[i];
+  }
+  my_off = wbase + incl - hits;
+  S.off[tid] = my_off;
+  S.x0[tid] = x0; S.y0[tid] = y0; S.w[tid] = max(w, 1);
+  S.depth_bits[tid] = dbits;
+  if (tid == 0) S.off[TGS_GROUP] = total;
+  return total;
+}
+
+// pair i of the group -> (local Gaussian j, tile id)
+__device__ __forceinline__ void group_pair(const GroupScan& S, int TW, int i, int& j, int& tile) {
+  int lo = 0, hi = TGS_GROUP;
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    const int mid = (lo + hi) >> 1;
+    if (S.off[mid] <= i) lo = mid; else hi = mid;
+  }
+  j = lo;
+  const int k = i - S.off[lo];
+  const int w = S.w[lo];
+  const int ky = k / w;
+  tile = (S.y0[lo] + ky) * TW + S.x0[lo] + (k - ky * w);
+}
+
+// Allocates the group's contiguous pair range and counts its intersections per tile; every pair
+// remembers its arrival rank inside its tile.  Call after group_scan_store + __syncthreads-free
+// (this function synchronises internally).
+__device__ __forceinline__ void group_count_tiles(GroupScan& S, int TW, int total,
+                                                  int32_t* __restrict__ group_base,
+                                                  int32_t* __restrict__ tile_count,
+                                                  int32_t* __restrict__ rank,
+                                                  int32_t* __restrict__ status, long long capacity) {
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    const int base = total ? atomicAdd(&status[0], total) : 0;
+    S.base = base;
+    group_base[blockIdx.x] = base;
+    if ((long long)base + total > capacity) status[1] = 1;
+  }
+  __syncthreads();
+  const long long base = S.base;
+  const bool fits = base + total <= capacity;
+  for (int i = tid; i < total; i += TGS_GROUP) {
+    int j, tile;
+    group_pair(S, TW, i, j, tile);
+    const int r = atomicAdd(&tile_count[tile], 1);
+    if (fits) rank[base + i] = r;
+  }
+}
+#endif  // __HIPCC__

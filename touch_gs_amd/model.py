@@ -183,12 +183,8 @@ class DepthGaussianSplattingModel:
         p, c, cam = self.params, self.config, view.cam
         deg = self.active_sh_degree()
         H, W = cam.H, cam.W
-        radii = None
-        if want_v_xy:
-            splats, radii = ops.project_fwd(cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, want_radii=True)
-        else:
-            splats = ops.project_fwd(cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg)
-        group_base, tile_start, sorted_gid, _ = ops.bin_sort(cam, splats, self.budget)
+        splats, radii, group_base, tile_start, sorted_gid, _ = ops.project_bin_sort(
+            cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, self.budget, want_radii=want_v_xy)
         rgb, depth_acc, fT, fidx = ops.rasterize_fwd(cam, splats, sorted_gid, tile_start)
         v_img, ssim_sum = None, None
         if c.ssim_lambda > 0:

@@ -122,6 +122,45 @@ def bin_sort(cam: Camera, splats, budget: Optional[IntersectBudget] = None):
     return group_base, tile_start, sorted_gid, status
 
 
+def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_deg: int,
+                     budget: Optional[IntersectBudget] = None, want_radii: bool = False):
+    """K1 fused with the tile counting, then scan / fill / sort: the front half of a frame in ONE C
+    call -> (splats, radii or None, group_base, tile_start, sorted_gid, status).  (tgs_project_bin_sort)"""
+    lib = _lib.load()
+    budget = budget or _default_budget
+    N = means.shape[0]
+    dev = means.device
+    T = cam.num_tiles
+    G = lib.tgs_num_groups(N)
+    cs = cam.c_struct()
+    splats = torch.empty(N, SPLAT_FLOATS, dtype=torch.float32, device=dev)
+    radii = torch.empty(N, dtype=torch.int32, device=dev) if want_radii else None
+    group_base = torch.empty(max(G, 1), dtype=torch.int32, device=dev)
+    tile_start = torch.empty(T + 1, dtype=torch.int32, device=dev)
+    tile_cursor = torch.empty(max(T, 1), dtype=torch.int32, device=dev)
+    status = torch.empty(2, dtype=torch.int32, device=dev)
+    sh_stride = sh.shape[1] if sh is not None else 0
+    cap = budget.initial(N)
+    while True:
+        sorted_gid = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+        scratch = torch.empty(lib.tgs_sort_scratch_bytes(cap), dtype=torch.uint8, device=dev)
+        check(lib.tgs_project_bin_sort(C.byref(cs), N, ptr(means), ptr(log_scales), ptr(quats), ptr(opac_logit),
+                                       ptr(sh), sh_stride, sh_deg if sh is not None else -1, ptr(splats),
+                                       ptr(radii), ptr(group_base), ptr(tile_start), ptr(tile_cursor),
+                                       ptr(sorted_gid), cap, ptr(scratch), ptr(status), _stream()),
+              "tgs_project_bin_sort")
+        budget.last_status = status
+        if not budget.sync:
+            break
+        n, ovf = status.tolist()
+        budget.last_n = n
+        if not ovf:
+            break
+        cap = int(n * budget.growth) + 1024
+        budget.capacity = cap
+    return splats, radii, group_base, tile_start, sorted_gid, status
+
+
 def rasterize_fwd(cam: Camera, splats, sorted_gid, tile_start, want_idx: bool = False):
     """K6 -> (rgb [H,W,3], depth_acc [H,W], final_T [H,W], final_idx [H,W] or None).  (tgs_rasterize_fwd)"""
     lib = _lib.load()
@@ -211,8 +250,8 @@ class _Render(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, log_scales, quats, opac_logit, sh, means2d, cam, sh_deg, budget):
         means, log_scales, quats, opac_logit, sh = map(_f32c, (means, log_scales, quats, opac_logit, sh))
-        splats, radii = project_fwd(cam, means, log_scales, quats, opac_logit, sh, sh_deg, want_radii=True)
-        group_base, tile_start, sorted_gid, _ = bin_sort(cam, splats, budget)
+        splats, radii, group_base, tile_start, sorted_gid, _ = project_bin_sort(
+            cam, means, log_scales, quats, opac_logit, sh, sh_deg, budget, want_radii=True)
         rgb, depth, fT, fidx = rasterize_fwd(cam, splats, sorted_gid, tile_start)
         ctx.cam, ctx.sh_deg = cam, sh_deg
         ctx.want_xy = means2d is not None
