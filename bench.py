@@ -41,6 +41,24 @@ def algorithmic_bytes(N, I, P, T, K):
     return b
 
 
+def measured_traffic(kernel_key, N, W, H, deg):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*pmc_step_cfg3.json: FETCH_SIZE / WRITE_SIZE collected in separate --pmc passes on this
+    same workload and corrected as MI355X_MICROARCH.md prescribes).  None if no profile matches."""
+    if (N, W, H, deg) != (1_000_000, 1920, 1080, 3):
+        return None
+    import glob
+    names = {"raster_bwd": "k_raster_bwd", "raster_fwd": "k_raster_fwd<false>", "adam": "k_adam"}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_step_cfg3.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            return int(d["hbm_bytes_per_launch_corrected"][names[kernel_key]]["total_bytes"])
+        except Exception:
+            continue
+    return None
+
+
 def cpu_baseline(N, W, H, deg, seed, frac=None):
     """Build's own scalar C restatement (oracle/ref_raster.c, fp32, OpenMP over tiles) timed on the
     host cores: full projection / binning / projection-backward, compositing fwd+bwd on the first
@@ -212,7 +230,8 @@ def main():
                        "depth_loss_type": cfg.depth_loss_type},
             "kernel_ms": {k: round(v, 4) for k, v in kern_ms.items()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": measured_traffic(dom, N, W, H, deg),
                          "algorithmic_bytes": ab[dom]},
             "step_roofline": {"algorithmic_bytes": step_bytes,
                               "achieved_GBs": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
