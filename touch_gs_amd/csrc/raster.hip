@@ -191,21 +191,31 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
     for (int k = 0; k < 4; k++) slot_live |= (__ballot(smax[k] > 0.f) != 0ull) ? (1u << k) : 0u;
     if (slot_live == 0u) break;
     __syncthreads();
+    unsigned my_mask = 0u;
     if (base + lane < end) {
       const TileRec t = make_tile_rec(n0, n1, n2, tcx, tcy);
       recs[lane * 3] = t.a; recs[lane * 3 + 1] = t.b; recs[lane * 3 + 2] = t.c;
+      my_mask = __float_as_uint(t.c.w);
     }
     __syncthreads();
     if (base + 64 + lane < end) {
       const float* r = splats + (size_t)sorted_gid[base + 64 + lane] * TGS_SPLAT_FLOATS;
       n0 = ld4(r); n1 = ld4(r + 4); n2 = ld4(r + 8);
     }
-    const int cnt = min(64, end - base);
-    for (int j = 0; j < cnt; j++) {
-      const float4 qc = recs[j * 3 + 2];
-      const unsigned m = __builtin_amdgcn_readfirstlane(__float_as_uint(qc.w)) & slot_live;
-      if (m == 0u) continue;
-      const float4 qa = recs[j * 3], qb = recs[j * 3 + 1];
+    // quadrant masks of the whole batch as four wave-uniform 64-bit ballots (bit j = Gaussian j
+    // reaches quadrant k): Gaussians that reach no live quadrant are skipped by scalar bit
+    // scanning, without touching LDS or the VALU
+    unsigned long long qm[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      qm[k] = ((slot_live >> k) & 1u) ? __ballot((my_mask >> k) & 1u) : 0ull;
+    unsigned long long rem = qm[0] | qm[1] | qm[2] | qm[3];
+    while (rem) {
+      const int j = __builtin_ctzll(rem);
+      rem &= rem - 1;
+      const unsigned m = (unsigned)((qm[0] >> j) & 1ull) | ((unsigned)((qm[1] >> j) & 1ull) << 1) |
+                         ((unsigned)((qm[2] >> j) & 1ull) << 2) | ((unsigned)((qm[3] >> j) & 1ull) << 3);
+      const float4 qa = recs[j * 3], qb = recs[j * 3 + 1], qc = recs[j * 3 + 2];
       const int pos = base - start + j;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -368,6 +378,7 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
     const int cnt = min(64, end - base);
     size_t P = 0;
     float4 a0 = z4, a1 = z4;
+    unsigned my_mask = 0u;
     __syncthreads();
     if (lane < cnt) {
       const int gid = sorted_gid[base + lane];
@@ -376,16 +387,23 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
       const float4 a2 = ld4(r + 8);
       const TileRec t = make_tile_rec(a0, a1, a2, tcx, tcy);
       recs[lane * 3] = t.a; recs[lane * 3 + 1] = t.b; recs[lane * 3 + 2] = t.c;
+      my_mask = __float_as_uint(t.c.w);
       P = pair_index(group_base, gid, a2, tx, ty);
     }
     sums[lane * 4] = z4; sums[lane * 4 + 1] = z4; sums[lane * 4 + 2] = z4;
     __syncthreads();
 
-    for (int j = 0; j < cnt; j++) {
-      const float4 qc = recs[j * 3 + 2];
-      const unsigned m = __builtin_amdgcn_readfirstlane(__float_as_uint(qc.w)) & slot_live;
-      if (m == 0u) continue;
-      const float4 qa = recs[j * 3], qb = recs[j * 3 + 1];
+    unsigned long long qm[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      qm[k] = ((slot_live >> k) & 1u) ? __ballot((my_mask >> k) & 1u) : 0ull;
+    unsigned long long rem = qm[0] | qm[1] | qm[2] | qm[3];
+    while (rem) {
+      const int j = __builtin_ctzll(rem);
+      rem &= rem - 1;
+      const unsigned m = (unsigned)((qm[0] >> j) & 1ull) | ((unsigned)((qm[1] >> j) & 1ull) << 1) |
+                         ((unsigned)((qm[2] >> j) & 1ull) << 2) | ((unsigned)((qm[3] >> j) & 1ull) << 3);
+      const float4 qa = recs[j * 3], qb = recs[j * 3 + 1], qc = recs[j * 3 + 2];
       // acc: 0..2 v_rgb, 3 v_depth, 4 Q0 = sum q, 5 Qu, 6 Qv, 7 Quu, 8 Quv, 9 Qvv
       float acc[10];
 #pragma unroll
@@ -396,20 +414,22 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
         if (m & (1u << k)) {  // wave-uniform
           const float s = eval_s(qa, qb, pc, k);
           float Tn; bool go;
-          const float al = blend_step(s, T[k], smax[k], Tn, go);
+          const float al = blend_step(s, T[k], smax[k], Tn, go);   // 0 unless this Gaussian contributes
           const float ra = __builtin_amdgcn_rcpf(1.f - al);
           const float w = al * T[k];
           acc[0] = fmaf(w, vCr[k], acc[0]); acc[1] = fmaf(w, vCg[k], acc[1]);
           acc[2] = fmaf(w, vCb[k], acc[2]); acc[3] = fmaf(w, vD[k], acc[3]);
           float cv = qc.x * vCr[k];
           cv = fmaf(qc.y, vCg[k], cv); cv = fmaf(qc.z, vCb[k], cv); cv = fmaf(qb.w, vD[k], cv);
-          Pv[k] = fmaf(w, cv, Pv[k]);
-          // dL/d alpha = T cv + (T_final (v_A - bg.v_C) - S_behind.v) / (1 - alpha)
-          const float va = fmaf(T[k], cv, ra * (X[k] + Pv[k]));
-          T[k] = go ? Tn : T[k];
-          // q = opacity * exp(-sigma) * dL/dalpha  (no special-casing of the 0.999 clamp, B.7)
-          float q = __builtin_amdgcn_exp2f(-s) * va;
-          q = go ? q : 0.f;
+          // q = opacity e^-sigma dL/dalpha, dL/dalpha = T cv + (X + Pv)/(1 - alpha)   (B.7).  With
+          // z = w cv:  q = z + alpha/(1-alpha) (X + Pv + z)  -- exact when alpha is not clamped;
+          // under the 0.999 clamp (opacity > 0.999 and sigma ~ 0) q is rescaled by e^-s / 0.999.
+          const float z = w * cv;
+          Pv[k] += z;
+          float q = fmaf(al * ra, X[k] + Pv[k], z);    // = 0 automatically when al == 0
+          const float e2 = __builtin_amdgcn_exp2f(-s);
+          q = (e2 > ALPHA_MAX) ? q * (e2 * (1.0f / ALPHA_MAX)) : q;
+          T[k] = fmaf(-al, T[k], T[k]);                // unchanged when al == 0
           acc[4] += q;
           acc[5] = fmaf(q, pc.u[k & 1], acc[5]); acc[6] = fmaf(q, pc.v[k >> 1], acc[6]);
           acc[7] = fmaf(q, pc.uu[k & 1], acc[7]); acc[8] = fmaf(q, pc.uv[k], acc[8]);
