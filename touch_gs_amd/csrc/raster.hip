@@ -178,13 +178,6 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
   __shared__ float4 recs[64 * 3];
   const int start = tile_start[tile], end = tile_start[tile + 1];
 
-  // software pipeline: the next batch's records are gathered while the current one is blended
-  float4 n0, n1, n2;
-  n0 = n1 = n2 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (start + lane < end) {
-    const float* r = splats + (size_t)sorted_gid[start + lane] * TGS_SPLAT_FLOATS;
-    n0 = ld4(r); n1 = ld4(r + 4); n2 = ld4(r + 8);
-  }
   for (int base = start; base < end; base += 64) {
     unsigned slot_live = 0u;
 #pragma unroll
@@ -193,15 +186,14 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
     __syncthreads();
     unsigned my_mask = 0u;
     if (base + lane < end) {
-      const TileRec t = make_tile_rec(n0, n1, n2, tcx, tcy);
+      // no register prefetch of the next batch: 12 fewer VGPRs buy two more resident waves per
+      // SIMD, which hide the gather latency (and the long dependent chains of the blend) better
+      const float* r = splats + (size_t)sorted_gid[base + lane] * TGS_SPLAT_FLOATS;
+      const TileRec t = make_tile_rec(ld4(r), ld4(r + 4), ld4(r + 8), tcx, tcy);
       recs[lane * 3] = t.a; recs[lane * 3 + 1] = t.b; recs[lane * 3 + 2] = t.c;
       my_mask = __float_as_uint(t.c.w);
     }
     __syncthreads();
-    if (base + 64 + lane < end) {
-      const float* r = splats + (size_t)sorted_gid[base + 64 + lane] * TGS_SPLAT_FLOATS;
-      n0 = ld4(r); n1 = ld4(r + 4); n2 = ld4(r + 8);
-    }
     // quadrant masks of the whole batch as four wave-uniform 64-bit ballots (bit j = Gaussian j
     // reaches quadrant k): Gaussians that reach no live quadrant are skipped by scalar bit
     // scanning, without touching LDS or the VALU
