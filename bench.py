@@ -59,6 +59,29 @@ def measured_traffic(kernel_key, N, W, H, deg):
     return None
 
 
+def valu_utilisation(kern_ms, N, W, H, deg):
+    """Second roofline for the two compositing kernels, which are VALU- not HBM-bound: VALU
+    wave-instructions per launch (SQ_INSTS_VALU from the committed PMC pass on this workload)
+    divided by the measured time, against the issue limit of 1024 SIMD32s at one wave64 FMA per
+    2.57 cycles @ 2.4 GHz (tools/ubench/pk_fma.hip: 122 TFLOP/s plain v_fma_f32)."""
+    if (N, W, H, deg) != (1_000_000, 1920, 1080, 3):
+        return None
+    import glob
+    peak = 1024 * 2.4e9 / 2.57
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_step_cfg3.json")), reverse=True):
+        try:
+            with open(path) as f:
+                c = json.load(f)["counters"]
+            out = {"peak_wave_instr_per_s": round(peak, -9)}
+            for key, name in (("raster_fwd", "k_raster_fwd<false>"), ("raster_bwd", "k_raster_bwd")):
+                n = c[name]["SQ_INSTS_VALU"]
+                out[key] = {"valu_wave_instr": int(n), "frac_of_issue_peak": round(n / (kern_ms[key] * 1e-3) / peak, 3)}
+            return out
+        except Exception:
+            continue
+    return None
+
+
 def cpu_baseline(N, W, H, deg, seed, frac=None):
     """Build's own scalar C restatement (oracle/ref_raster.c, fp32, OpenMP over tiles) timed on the
     host cores: full projection / binning / projection-backward, compositing fwd+bwd on the first
@@ -238,6 +261,7 @@ def main():
                               "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                               "fwd_bwd_ms": round(sum(kern_ms[k] for k in names[:5] if k != "ssim"), 4)},
         }
+        out["valu_roofline"] = valu_utilisation(kern_ms, N, W, H, deg)
         if dp.world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(N, W, H, deg, args.seed)
