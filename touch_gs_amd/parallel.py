@@ -25,8 +25,11 @@ def init_from_env(backend: Optional[str] = None) -> "GradSync":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" IS RCCL on ROCm
-        if backend == "nccl":
+            # "nccl" IS RCCL on ROCm.  TGS_DIST_BACKEND=gloo lets the multi-rank code path be
+            # exercised with several ranks on ONE GPU (RCCL refuses duplicate devices).
+            backend = os.environ.get("TGS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            local = local % torch.cuda.device_count()
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return GradSync(rank, world, local)
@@ -108,7 +111,7 @@ class GradSync:
     def max_over_ranks(self, value: float) -> float:
         if self.world == 1:
             return value
-        dev = torch.device("cuda", self.local_rank) if dist.get_backend() == "nccl" else torch.device("cpu")
+        dev = torch.device("cuda", self.local_rank) if (dist.get_backend() == "nccl") else torch.device("cpu")
         t = torch.tensor([value], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
