@@ -78,6 +78,8 @@ __device__ __forceinline__ TileRec make_tile_rec(float4 r0, float4 r1, float4 r2
   const float slack = LOG2_255 + 1e-3f;
   if (L < LOG2_255) {
     const float c0 = t.a.x, c1 = t.a.y, c2 = t.a.z, c3 = t.a.w, c4 = t.b.x, c5 = t.b.y;
+    // approximate reciprocals suffice: the test carries a 1e-3 slack and only decides skipping
+    const float ic3 = __builtin_amdgcn_rcpf(c3), ic5 = __builtin_amdgcn_rcpf(c5);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const float u0 = (k & 1) ? 0.5f : -7.5f, u1 = u0 + 7.f;
@@ -92,11 +94,11 @@ __device__ __forceinline__ TileRec make_tile_rec(float4 r0, float4 r1, float4 r2
         for (int e = 0; e < 2; e++) {
           const float v = e ? v1 : v0;
           const float lin = fmaf(c4, v, c1);
-          const float us = fminf(fmaxf(-0.5f * lin / c3, u0), u1);
+          const float us = fminf(fmaxf(-0.5f * lin * ic3, u0), u1);
           best = fminf(best, fmaf(us, fmaf(c3, us, lin), fmaf(v, fmaf(c5, v, c2), c0)));
           const float u = e ? u1 : u0;
           const float lin2 = fmaf(c4, u, c2);
-          const float vs = fminf(fmaxf(-0.5f * lin2 / c5, v0), v1);
+          const float vs = fminf(fmaxf(-0.5f * lin2 * ic5, v0), v1);
           best = fminf(best, fmaf(vs, fmaf(c5, vs, lin2), fmaf(u, fmaf(c3, u, c1), c0)));
         }
       }
@@ -419,8 +421,7 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
           const float z = w * cv;
           Pv[k] += z;
           float q = fmaf(al * ra, X[k] + Pv[k], z);    // = 0 automatically when al == 0
-          const float e2 = __builtin_amdgcn_exp2f(-s);
-          q = (e2 > ALPHA_MAX) ? q * (e2 * (1.0f / ALPHA_MAX)) : q;
+          q *= fmaxf(__builtin_amdgcn_exp2f(-s) * (1.0f / ALPHA_MAX), 1.0f);
           T[k] = fmaf(-al, T[k], T[k]);                // unchanged when al == 0
           acc[4] += q;
           acc[5] = fmaf(q, pc.u[k & 1], acc[5]); acc[6] = fmaf(q, pc.v[k >> 1], acc[6]);
