@@ -395,3 +395,61 @@ def test_fused_project_bin_sort_equals_separate_calls(dev):
         assert st2.tolist() == [n, 0] and torch.equal(r1, r2) and torch.equal(ts1, ts2)
         assert torch.equal(sg1[:n], sg2[:n])
         assert torch.equal(sp1.view(torch.int32), sp2.view(torch.int32))  # records incl. rect + in-group offset
+
+
+@pytest.mark.parametrize("active_deg", [0, 1, 2])
+def test_partial_sh_degree_with_full_storage(dev, active_deg):
+    """SH tensor stored at degree 3 (K = 16) but evaluated at a lower active degree, as during
+    the sh_degree_interval warm-up: forward colours and all gradients vs the oracle; the unused
+    coefficient gradients must be exactly zero."""
+    from touch_gs_amd import ops
+    N, W, H = 2500, 144, 96
+    P, cam = scene(N, W, H, 3, 300 + active_deg)
+    D = {k: v.requires_grad_(True) for k, v in to_dev(P, dev).items()}
+    rgb, depth, alpha, _ = ops.render(D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"],
+                                      amd_cam(cam), active_deg)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    out, *_ = O.render(Pg["means"], Pg["log_scales"], Pg["quats"], Pg["opac_logit"], Pg["sh"], cam, active_deg)
+    e = relerr(rgb.detach().cpu().numpy(), out["rgb"].detach().numpy(), floor=1e-2)
+    assert np.quantile(e, 0.99) < TOL
+    g = torch.Generator().manual_seed(9)
+    w = torch.randn(H, W, 3, generator=g, dtype=torch.float64)
+    wd = torch.randn(H, W, generator=g, dtype=torch.float64)
+    ((out["rgb"] * w).sum() + (out["depth_acc"] * wd).sum()).backward()
+    ((rgb * w.float().to(dev)).sum() + (depth * wd.float().to(dev)).sum()).backward()
+    K = (active_deg + 1) ** 2
+    assert float(D["sh"].grad[:, K:].abs().max()) == 0.0
+    for k in D:
+        ref, got = Pg[k].grad.numpy(), D[k].grad.cpu().double().numpy()
+        cos = (ref * got).sum() / np.sqrt((ref * ref).sum() * (got * got).sum())
+        assert cos > 0.9999, (k, cos)
+
+
+def test_degenerate_sizes(dev):
+    from touch_gs_amd import Camera, ops
+    # N = 0: background only
+    cam = Camera(np.eye(4), 50.0, 50.0, 8.0, 8.0, 16, 16, bg=(0.5, 0.25, 0.125))
+    z = lambda *s: torch.zeros(*s, device=dev)
+    sp, _, gb, ts, sg, st = ops.project_bin_sort(cam, z(0, 3), z(0, 3), z(0, 4), z(0), z(0, 16, 3), 3)
+    assert st.tolist() == [0, 0]
+    rgb, depth, fT, _ = ops.rasterize_fwd(cam, sp, sg, ts)
+    assert torch.allclose(rgb, torch.tensor([0.5, 0.25, 0.125], device=dev).expand(16, 16, 3)) and float(fT.min()) == 1.0
+    # a 1x1 and a 17x5 image (partial tiles in both directions), one Gaussian in front of the camera
+    for W, H in ((1, 1), (17, 5)):
+        cam = Camera(np.eye(4), 20.0, 20.0, W / 2, H / 2, W, H)
+        means = torch.tensor([[0.0, 0.0, 2.0]], device=dev)
+        ls = torch.full((1, 3), -1.0, device=dev)
+        q = torch.tensor([[1.0, 0.0, 0.0, 0.0]], device=dev)
+        op = torch.tensor([2.0], device=dev)
+        sh = torch.zeros(1, 1, 3, device=dev)
+        sh[0, 0] = torch.tensor([1.0, 0.0, -1.0])
+        for t in (means, ls, q, op, sh):
+            t.requires_grad_(True)
+        rgb, depth, alpha, radii = ops.render(means, ls, q, op, sh, cam, 0)
+        assert rgb.shape == (H, W, 3) and int(radii[0]) > 0 and float(alpha.max()) > 0.5
+        (rgb.sum() + depth.sum()).backward()
+        assert all(torch.isfinite(t.grad).all() for t in (means, ls, q, op, sh))
+        ocam = O.Camera(viewmat=torch.eye(4, dtype=torch.float64), fx=20.0, fy=20.0, cx=W / 2, cy=H / 2, W=W, H=H)
+        o, *_ = O.render(means.detach().cpu().double(), ls.detach().cpu().double(), q.detach().cpu().double(),
+                         op.detach().cpu().double(), sh.detach().cpu().double(), ocam, 0)
+        assert np.abs(rgb.detach().cpu().numpy() - o["rgb"].numpy()).max() < 1e-5

@@ -90,4 +90,17 @@ def ptr(t):
         raise RuntimeError("touch_gs_amd ops need device (HIP) tensors; there is no CPU path")
     if not t.is_contiguous():
         raise RuntimeError("touch_gs_amd ops need contiguous tensors")
+    if t.numel() == 0:  # empty tensors have a NULL data pointer; the C ABI wants a valid (unused) one
+        return _dummy(t.device).data_ptr()
     return t.data_ptr()
+
+
+_DUMMY = {}
+
+
+def _dummy(device):
+    import torch
+    key = str(device)
+    if key not in _DUMMY:
+        _DUMMY[key] = torch.zeros(64, dtype=torch.float32, device=device)
+    return _DUMMY[key]

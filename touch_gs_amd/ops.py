@@ -80,7 +80,7 @@ def project_fwd(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_deg: i
     """K1 -> splats [N,12] (, radii int32 [N]).  (tgs_project_fwd)"""
     lib = _lib.load()
     N = means.shape[0]
-    splats = torch.empty(N, SPLAT_FLOATS, dtype=torch.float32, device=means.device)
+    splats = torch.empty(max(N, 1), SPLAT_FLOATS, dtype=torch.float32, device=means.device)[:N]
     radii = torch.empty(N, dtype=torch.int32, device=means.device) if want_radii else None
     cs = cam.c_struct()
     sh_stride = sh.shape[1] if sh is not None else 0
@@ -133,7 +133,7 @@ def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_d
     T = cam.num_tiles
     G = lib.tgs_num_groups(N)
     cs = cam.c_struct()
-    splats = torch.empty(N, SPLAT_FLOATS, dtype=torch.float32, device=dev)
+    splats = torch.empty(max(N, 1), SPLAT_FLOATS, dtype=torch.float32, device=dev)[:N]  # non-null even for N = 0
     radii = torch.empty(N, dtype=torch.int32, device=dev) if want_radii else None
     group_base = torch.empty(max(G, 1), dtype=torch.int32, device=dev)
     tile_start = torch.empty(T + 1, dtype=torch.int32, device=dev)
