@@ -99,6 +99,14 @@ int tgs_project_fwd(const TgsCamera* cam /*[host]*/, int N, const float* means,
                     const float* sh, int sh_stride, int sh_deg, const float* colors_in,
                     float* splats, int32_t* radii, void* stream);
 
+/* Stand-alone SH evaluation (stands behind gsplat `spherical_harmonics`):
+ *   colors[N,3] = sum_k Y_k(dirs / |dirs|) coeffs[N,k,:]  (no +0.5, no clamp);  backward w.r.t. the
+ *   coefficients only (v_coeffs[N,sh_stride,3], rows k >= (sh_deg+1)^2 are zeroed). */
+int tgs_sh_fwd(int N, int sh_deg, int sh_stride, const float* dirs, const float* coeffs,
+               float* colors, void* stream);
+int tgs_sh_bwd(int N, int sh_deg, int sh_stride, const float* dirs, const float* v_colors,
+               float* v_coeffs, void* stream);
+
 /* K2-K5  tile binning + per-tile depth sort  (stands behind gsplat `map_gaussian_to_intersects`,
  *     the CUB radix sort and `get_tile_bin_edges` inside `rasterize_gaussians`; spec App. B.4, B.6).
  * in : splats[N,12] (slot 11 is overwritten with the in-group intersection offset)

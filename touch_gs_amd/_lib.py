@@ -43,6 +43,8 @@ SIGNATURES = {
     "tgs_num_tiles": (C.c_int, [_I, _I]),
     "tgs_sort_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "tgs_project_fwd": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "tgs_sh_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P]),
+    "tgs_sh_bwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P]),
     "tgs_bin_sort": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P]),
     "tgs_project_bin_sort": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P,
                                        C.c_int64, _P, _P, _P]),

@@ -651,6 +651,36 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// stand-alone SH evaluation (gsplat `spherical_harmonics` op: no +0.5, no clamp; coefficients only
+// receive gradient, view directions are treated as constants)
+// ---------------------------------------------------------------------------------------------
+template <int DEG, bool BWD>
+__global__ __launch_bounds__(256) void k_sh_op(int N, int sh_stride, const float* __restrict__ dirs,
+                                               const float* __restrict__ coeffs_or_vout,
+                                               float* __restrict__ out) {
+  constexpr int K = (DEG + 1) * (DEG + 1);
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= N) return;
+  float dx = dirs[3 * g], dy = dirs[3 * g + 1], dz = dirs[3 * g + 2];
+  const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+  float Y[16];
+  sh_basis<DEG>(dx * inv, dy * inv, dz * inv, Y);
+  if constexpr (!BWD) {
+    const float* c = coeffs_or_vout + (size_t)g * sh_stride * 3;
+    float r = 0.f, gg = 0.f, b = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; k++) { r += Y[k] * c[3 * k]; gg += Y[k] * c[3 * k + 1]; b += Y[k] * c[3 * k + 2]; }
+    out[3 * g] = r; out[3 * g + 1] = gg; out[3 * g + 2] = b;
+  } else {
+    const float v0 = coeffs_or_vout[3 * g], v1 = coeffs_or_vout[3 * g + 1], v2 = coeffs_or_vout[3 * g + 2];
+    float* o = out + (size_t)g * sh_stride * 3;
+#pragma unroll
+    for (int k = 0; k < K; k++) { o[3 * k] = Y[k] * v0; o[3 * k + 1] = Y[k] * v1; o[3 * k + 2] = Y[k] * v2; }
+    for (int k = K; k < sh_stride; k++) { o[3 * k] = 0.f; o[3 * k + 1] = 0.f; o[3 * k + 2] = 0.f; }
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -821,4 +851,40 @@ extern "C" int tgs_project_bin_sort(const TgsCamera* cam, int N, const float* me
   }
   return tgs_bin_finish(k, N, splats, group_base, tile_start, tile_cursor, sorted_gid, capacity,
                         scratch, status, s);
+}
+
+extern "C" int tgs_sh_fwd(int N, int sh_deg, int sh_stride, const float* dirs, const float* coeffs,
+                          float* colors, void* stream) {
+  TGS_CHECK_ARG(N >= 0 && sh_deg >= 0 && sh_deg <= 3, "bad size / degree");
+  TGS_CHECK_ARG(sh_stride >= (sh_deg + 1) * (sh_deg + 1), "sh_stride too small");
+  if (N == 0) return TGS_OK;
+  TGS_CHECK_ARG(dirs && coeffs && colors, "null pointer");
+  const dim3 grid((N + 255) / 256), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (sh_deg) {
+    case 0: hipLaunchKernelGGL((k_sh_op<0, false>), grid, block, 0, s, N, sh_stride, dirs, coeffs, colors); break;
+    case 1: hipLaunchKernelGGL((k_sh_op<1, false>), grid, block, 0, s, N, sh_stride, dirs, coeffs, colors); break;
+    case 2: hipLaunchKernelGGL((k_sh_op<2, false>), grid, block, 0, s, N, sh_stride, dirs, coeffs, colors); break;
+    default: hipLaunchKernelGGL((k_sh_op<3, false>), grid, block, 0, s, N, sh_stride, dirs, coeffs, colors); break;
+  }
+  TGS_CHECK_LAUNCH();
+  return TGS_OK;
+}
+
+extern "C" int tgs_sh_bwd(int N, int sh_deg, int sh_stride, const float* dirs, const float* v_colors,
+                          float* v_coeffs, void* stream) {
+  TGS_CHECK_ARG(N >= 0 && sh_deg >= 0 && sh_deg <= 3, "bad size / degree");
+  TGS_CHECK_ARG(sh_stride >= (sh_deg + 1) * (sh_deg + 1), "sh_stride too small");
+  if (N == 0) return TGS_OK;
+  TGS_CHECK_ARG(dirs && v_colors && v_coeffs, "null pointer");
+  const dim3 grid((N + 255) / 256), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (sh_deg) {
+    case 0: hipLaunchKernelGGL((k_sh_op<0, true>), grid, block, 0, s, N, sh_stride, dirs, v_colors, v_coeffs); break;
+    case 1: hipLaunchKernelGGL((k_sh_op<1, true>), grid, block, 0, s, N, sh_stride, dirs, v_colors, v_coeffs); break;
+    case 2: hipLaunchKernelGGL((k_sh_op<2, true>), grid, block, 0, s, N, sh_stride, dirs, v_colors, v_coeffs); break;
+    default: hipLaunchKernelGGL((k_sh_op<3, true>), grid, block, 0, s, N, sh_stride, dirs, v_colors, v_coeffs); break;
+  }
+  TGS_CHECK_LAUNCH();
+  return TGS_OK;
 }

@@ -310,18 +310,34 @@ def _sh_basis_torch(deg: int, d: torch.Tensor) -> torch.Tensor:
     return torch.stack(out, dim=-1)
 
 
-def spherical_harmonics(degrees_to_use: int, viewdirs: torch.Tensor, coeffs: torch.Tensor):
-    """gsplat-shaped SH evaluation: coeffs [N,K,3], viewdirs [N,3] (normalised here) -> [N,3].
+class _SphericalHarmonics(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, degrees_to_use, viewdirs, coeffs):
+        lib = _lib.load()
+        dirs, coeffs = _f32c(viewdirs.detach()), _f32c(coeffs)
+        N = coeffs.shape[0]
+        out = torch.empty(N, 3, dtype=torch.float32, device=coeffs.device)
+        check(lib.tgs_sh_fwd(N, degrees_to_use, coeffs.shape[1], ptr(dirs), ptr(coeffs), ptr(out), _stream()), "tgs_sh_fwd")
+        ctx.deg, ctx.shape = degrees_to_use, coeffs.shape
+        ctx.save_for_backward(dirs)
+        return out
 
-    Stand-alone compatibility op built from device torch ops (differentiable); the training hot
-    path does not use it -- K1/K8 evaluate SH inside the projection kernels.
-    """
-    if not coeffs.is_cuda:
-        raise RuntimeError("touch_gs_amd ops need device (HIP) tensors; there is no CPU path")
-    d = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
-    K = (degrees_to_use + 1) ** 2
-    Y = _sh_basis_torch(degrees_to_use, d)
-    return (Y[..., :, None] * coeffs[..., :K, :]).sum(-2)
+    @staticmethod
+    def backward(ctx, v_colors):
+        lib = _lib.load()
+        (dirs,) = ctx.saved_tensors
+        v = torch.empty(ctx.shape, dtype=torch.float32, device=dirs.device)
+        check(lib.tgs_sh_bwd(ctx.shape[0], ctx.deg, ctx.shape[1], ptr(dirs), ptr(_f32c(v_colors)), ptr(v), _stream()),
+              "tgs_sh_bwd")
+        return None, None, v
+
+
+def spherical_harmonics(degrees_to_use: int, viewdirs: torch.Tensor, coeffs: torch.Tensor):
+    """gsplat-shaped SH evaluation: coeffs [N,K,3], viewdirs [N,3] (normalised in-kernel) -> [N,3]
+    (no +0.5 / clamp: the caller applies them, as Splatfacto does).  Gradient flows to ``coeffs``
+    only, as in gsplat 0.1.  (tgs_sh_fwd / tgs_sh_bwd; the fused training path evaluates SH inside
+    K1/K8 instead.)"""
+    return _SphericalHarmonics.apply(degrees_to_use, viewdirs, coeffs)
 
 
 class _ProjectGaussians(torch.autograd.Function):
