@@ -262,6 +262,11 @@ def main():
                               "fwd_bwd_ms": round(sum(kern_ms[k] for k in names[:5] if k != "ssim"), 4)},
         }
         out["valu_roofline"] = valu_utilisation(kern_ms, N, W, H, deg)
+        if dp.world > 1:
+            out["dp_exchange"] = {"form": "all-gather colour gradients + all-reduce geometry gradients"
+                                  if model._color_all is not None else "all-reduce flat gradient buffer",
+                                  "payload_bytes_per_rank_per_step": int(dp.bytes_per_step),
+                                  "dense_all_reduce_bytes": int(model.params.grad.numel() * 4)}
         if dp.world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(N, W, H, deg, args.seed)

@@ -189,6 +189,28 @@ int tgs_project_bwd_adam(const TgsCamera* cam /*[host]*/, int N, int sh_stride, 
                          const int32_t* group_base, const float* partials, float* v_xy,
                          void* stream);
 
+/* Data-parallel step (one view per rank, SURVEY section 8 row e).  The SH gradient of a rank is the
+ *     outer product Y_k(dir(g)) x v_color[g,:], so the ranks exchange v_color (all-gather, 3 floats
+ *     per Gaussian and rank) instead of all-reducing 3*sh_stride floats per Gaussian:
+ *   tgs_project_bwd_color      = tgs_project_bwd (partials path) that writes, instead of v_sh, the
+ *                                block v_color[3N+4] = clamp-gated colour gradients [N,3] followed
+ *                                by this camera's position [3] and one zero pad;
+ *   tgs_adam_step_sh_gathered  = Adam on the SH segment of `params` with the gradient
+ *                                grad_scale * sum_r Y_k(dir_r(g)) * v_color_r[g,:], rebuilt in rank
+ *                                order from v_color_all[world][3N+4] (the all-gathered blocks).
+ *                                The means inside `params` must still be the ones the forward
+ *                                pass used (step the geometry segments with tgs_adam_step
+ *                                afterwards).  Requires 3*sh_stride % 4 == 0. */
+int tgs_project_bwd_color(const TgsCamera* cam /*[host]*/, int N, const float* means,
+                          const float* log_scales, const float* quats, const float* opac_logit,
+                          const float* sh, int sh_stride, int sh_deg, const float* splats,
+                          const int32_t* group_base, const float* partials, float* v_means,
+                          float* v_log_scales, float* v_quats, float* v_opac_logit, float* v_color,
+                          float* v_xy, void* stream);
+int tgs_adam_step_sh_gathered(int world, int N, int sh_stride, int sh_deg, float* params,
+                              const float* v_color_all, float* exp_avg, float* exp_avg_sq,
+                              const TgsAdamSpec* spec /*[host]*/, float grad_scale, void* stream);
+
 /* K9  fused Adam over the flat parameter buffer (torch.optim.Adam semantics, no weight decay).
  *     Updates elements [elem_begin, elem_end) of the flat buffers (multiples of 4; pass 0, -1 for
  *     everything) so that chunks can be stepped as their gradient all-reduce completes. */

@@ -166,8 +166,26 @@ assert began == [1] and calls[0][0] == 0 and calls[-1][1] == 1003 and all(b % 4 
 assert all(calls[i][1] == calls[i + 1][0] for i in range(len(calls) - 1)) and len(calls) == 5
 assert torch.allclose(gflat, torch.arange(1003, dtype=torch.float32) * 1.5)
 assert dp.max_over_ranks(float(dp.rank)) == 1.0
+bytes_dense = dp.bytes_per_step
+# factored form: all-gather of the colour-gradient blocks, all-reduce of the geometry gradients
+Ng = 37
+block = torch.full((3 * Ng + 4,), float(dp.rank + 1)); block[3 * Ng:] = torch.tensor([10. * dp.rank, 1., 2., 0.])
+allc = torch.zeros(2, 3 * Ng + 4)
+geom = torch.arange(44, dtype=torch.float32) * (dp.rank + 1)
+order = []
+def step_sh(c, scale):
+    order.append("sh")
+    assert scale == 0.5 and c.shape == (2, 3 * Ng + 4)
+    assert torch.all(c[0, :3 * Ng] == 1) and torch.all(c[1, :3 * Ng] == 2)          # rank-major blocks
+    assert c[0, 3 * Ng].item() == 0.0 and c[1, 3 * Ng].item() == 10.0              # camera trailers
+def step_geom(b, e, scale):
+    order.append("geom")
+    assert (b, e, scale) == (0, 44, 0.5)
+    assert torch.allclose(geom, torch.arange(44, dtype=torch.float32) * 3.0)
+dp.gather_color_reduce_geom_and_step(geom, block, allc, step_sh, step_geom, lambda: order.append("begin"))
+assert order == ["begin", "sh", "geom"] and dp.bytes_per_step == 4 * (2 * (3 * Ng + 4) + 44)
 dp.barrier()
-if dp.rank == 0: print("GLOO_OK", dp.bytes_per_step)
+if dp.rank == 0: print("GLOO_OK", bytes_dense)
 '''
 
 

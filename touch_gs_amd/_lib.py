@@ -53,6 +53,8 @@ SIGNATURES = {
     "tgs_reduce_partials": (C.c_int, [_I, _P, _P, C.POINTER(TgsCamera), _P, _P, _P]),
     "tgs_project_bwd": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I] + [_P] * 11),
     "tgs_project_bwd_adam": (C.c_int, [C.POINTER(TgsCamera), _I, _I, _I, _P, _P, _P, C.POINTER(TgsAdamSpec), _P, _P, _P, _P, _P]),
+    "tgs_project_bwd_color": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I] + [_P] * 10),
+    "tgs_adam_step_sh_gathered": (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _P, C.POINTER(TgsAdamSpec), C.c_float, _P]),
     "tgs_adam_step": (C.c_int, [_I, _I, _P, _P, _P, _P, C.POINTER(TgsAdamSpec), C.c_float, C.c_int64, C.c_int64, _P]),
     "tgs_ssim_fwd_bwd": (C.c_int, [_I, _I, _P, _P, C.c_float, _P, _P, _P, _P]),
 }

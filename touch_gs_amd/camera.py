@@ -50,6 +50,11 @@ class Camera:
         tw, th = self.tiles
         return tw * th
 
+    def position(self) -> np.ndarray:
+        """Camera centre in world coordinates, -R^T t."""
+        R, t = self.viewmat[:3, :3], self.viewmat[:3, 3]
+        return -(R.T @ t)
+
     def c_struct(self):
         from ._lib import TgsCamera
         c = TgsCamera()

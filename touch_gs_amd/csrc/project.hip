@@ -379,9 +379,14 @@ __global__ __launch_bounds__(256) void k_project_bwd(
     const int32_t* __restrict__ group_base, const float* __restrict__ partials,
     const float* __restrict__ v_splats, float* __restrict__ v_means,
     float* __restrict__ v_log_scales, float* __restrict__ v_quats,
-    float* __restrict__ v_opac_logit, float* __restrict__ v_sh, float* __restrict__ v_xy) {
+    float* __restrict__ v_opac_logit, float* __restrict__ v_sh, float* __restrict__ v_color,
+    float* __restrict__ v_xy) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= N) return;
+  if (v_color && g == 0) {  // trailer of the colour-gradient block: this view's camera position
+    v_color[3 * (size_t)N] = cam.campos[0]; v_color[3 * (size_t)N + 1] = cam.campos[1];
+    v_color[3 * (size_t)N + 2] = cam.campos[2]; v_color[3 * (size_t)N + 3] = 0.f;
+  }
   // per-Gaussian upstream gradient: {v_x, v_y, v_depth, v_opac, v_a, v_b, v_c, v_r, v_g, v_b}
   float v[10];
   if (partials) {
@@ -418,6 +423,7 @@ __global__ __launch_bounds__(256) void k_project_bwd(
     float vr[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) vr[ch] = (col[ch] > 0.f) ? v[7 + ch] : 0.f;  // clamp gate
+    if (v_color) { v_color[3 * g] = vr[0]; v_color[3 * g + 1] = vr[1]; v_color[3 * g + 2] = vr[2]; }
     if (v_sh) {
       float* o_sh = v_sh + (size_t)g * sh_stride * 3;
 #pragma unroll
@@ -439,9 +445,12 @@ __global__ __launch_bounds__(256) void k_project_bwd(
 #pragma unroll
       for (int j = 0; j < 3; j++) vm[j] += (vd[j] - d[j] * dot) * inv;
     }
-  } else if (v_sh) {
-    float* o_sh = v_sh + (size_t)g * sh_stride * 3;
-    for (int k = 0; k < sh_stride * 3; k++) o_sh[k] = 0.f;
+  } else {
+    if (v_sh) {
+      float* o_sh = v_sh + (size_t)g * sh_stride * 3;
+      for (int k = 0; k < sh_stride * 3; k++) o_sh[k] = 0.f;
+    }
+    if (v_color) { v_color[3 * g] = 0.f; v_color[3 * g + 1] = 0.f; v_color[3 * g + 2] = 0.f; }
   }
 
   // ---- geometry backward (B.8) ----
@@ -473,7 +482,9 @@ __global__ __launch_bounds__(256) void k_project_bwd(
 // out coalesced -- either as v_sh, or (FUSE_ADAM) straight through the Adam update of sh/m/v, so
 // that the 12K-float SH gradient never touches HBM.  The 11 non-SH parameters per Gaussian are
 // updated by their owner thread.
-template <int DEG, bool FUSE_ADAM>
+// COLOR_ONLY (data-parallel training): `v_sh` receives the clamp-gated colour gradient [N,3] instead
+// of the SH gradient image; nothing is streamed out at the end.
+template <int DEG, bool FUSE_ADAM, bool COLOR_ONLY = false>
 __global__ __launch_bounds__(256) void k_project_bwd_lds(
     CamK cam, int N, float* __restrict__ means, float* __restrict__ log_scales,
     float* __restrict__ quats, float* __restrict__ opac_logit, float* __restrict__ sh,
@@ -510,6 +521,12 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
   float vm[3] = {0.f, 0.f, 0.f}, vls[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f};
   float m[3] = {0.f, 0.f, 0.f}, ls[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f};
   float ol = 0.f, vol = 0.f;
+  if constexpr (COLOR_ONLY) {
+    if (g == 0) {  // trailer of the colour-gradient block: this view's camera position
+      v_sh[3 * (size_t)N] = cam.campos[0]; v_sh[3 * (size_t)N + 1] = cam.campos[1];
+      v_sh[3 * (size_t)N + 2] = cam.campos[2]; v_sh[3 * (size_t)N + 3] = 0.f;
+    }
+  }
   if (g < N) {
     float v[10];
     sum_partials(cam, splats, group_base, partials, g, v);
@@ -551,9 +568,10 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
 #pragma unroll
       for (int j = 0; j < 3; j++) vm[j] += (vd[j] - d[j] * dot) * inv;
     }
+    if constexpr (COLOR_ONLY) { v_sh[3 * g] = vr[0]; v_sh[3 * g + 1] = vr[1]; v_sh[3 * g + 2] = vr[2]; }
     // own row <- SH gradient (only this thread ever touches this row before the barrier)
 #pragma unroll
-    for (int i = 0; i < F4; i++) {
+    for (int i = 0; i < (COLOR_ONLY ? 0 : F4); i++) {
       float4 t;
       t.x = Y[(4 * i) / 3] * vr[(4 * i) % 3];
       t.y = Y[(4 * i + 1) / 3] * vr[(4 * i + 1) % 3];
@@ -611,6 +629,7 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
       }
     }
   }
+  if constexpr (COLOR_ONLY) return;
   __syncthreads();
   // coalesced stream of the block's SH gradient image (2 float4 columns per thread per round so
   // that 6 independent loads are in flight)
@@ -646,6 +665,94 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
           adam1(ad, ad.lr_rest, P[u].w, G.w, M[u].w, V[u].w);
           st4(sh + e, P[u]); st4(exp_avg + ad.e_opac + e, M[u]); st4(exp_avg_sq + ad.e_opac + e, V[u]);
         }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam on the SH block from all-gathered colour gradients (data-parallel step)
+// ---------------------------------------------------------------------------------------------
+// The SH gradient of rank r is the outer product Y_k(dir_r(g)) * v_color_r[g,:] -- 3 numbers per
+// Gaussian and rank plus a basis every rank can evaluate itself (means are replicated, the cameras
+// of all ranks are known).  Exchanging v_color (all-gather, 12 B per Gaussian and rank) instead of
+// the 12K-float gradient rows (all-reduce) cuts the bytes crossing xGMI ~2.5x at 8 ranks and ~4x
+// at 2; the sum over ranks is rebuilt here in rank order (identical on every rank), written into an
+// LDS image of the block's rows and streamed through the Adam update fully coalesced, exactly like
+// the fused K8+Adam tail.  `means` must still hold the values the forward pass used.  Each rank's
+// block carries its camera position behind the N colour gradients (written by K8), so no host data
+// is needed.
+template <int DEG>
+__global__ __launch_bounds__(256) void k_adam_sh_gathered(
+    int world, int N, int sh_stride, const float* __restrict__ means,
+    float* __restrict__ sh, const float* __restrict__ v_color_all, AdamK ad,
+    float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq) {
+  constexpr int K = (DEG + 1) * (DEG + 1);
+  const int ROW = 3 * sh_stride, RS = ROW + 4, F4 = ROW / 4;
+  extern __shared__ float4 lds4[];
+  float* lds = reinterpret_cast<float*>(lds4);
+  const int tid = threadIdx.x;
+  const int g0 = blockIdx.x * 256;
+  const int g = g0 + tid;
+  const int nrows = min(256, N - g0);
+  const size_t blk = (size_t)g0 * ROW;
+  if (g < N) {
+    const float m0 = means[3 * g], m1 = means[3 * g + 1], m2 = means[3 * g + 2];
+    float acc[3 * K];
+#pragma unroll
+    for (int i = 0; i < 3 * K; i++) acc[i] = 0.f;
+    const size_t blk_r = 3 * (size_t)N + 4;   // one rank's block: v_color[N,3] | campos[3] | pad
+    for (int r = 0; r < world; r++) {
+      const float* vc = v_color_all + r * blk_r + 3 * (size_t)g;
+      const float* cp = v_color_all + r * blk_r + 3 * (size_t)N;
+      const float v0 = vc[0], v1 = vc[1], v2 = vc[2];
+      const float dx = m0 - cp[0], dy = m1 - cp[1], dz = m2 - cp[2];
+      const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+      float Y[16];
+      sh_basis<DEG>(dx * inv, dy * inv, dz * inv, Y);
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        acc[3 * k] = fmaf(Y[k], v0, acc[3 * k]);
+        acc[3 * k + 1] = fmaf(Y[k], v1, acc[3 * k + 1]);
+        acc[3 * k + 2] = fmaf(Y[k], v2, acc[3 * k + 2]);
+      }
+    }
+    float* row = lds + tid * RS;
+#pragma unroll
+    for (int i = 0; i < 3 * K / 4; i++) st4(row + 4 * i, make_float4(acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]));
+    if constexpr ((3 * K) % 4 != 0) {   // K = 1 or 9: finish the last partial float4 with zeros
+      float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < (3 * K) % 4; i++) t[i] = acc[(3 * K / 4) * 4 + i];
+      st4(row + (3 * K / 4) * 4, make_float4(t[0], t[1], t[2], t[3]));
+    }
+    for (int i = (3 * K + 3) / 4; i < F4; i++) st4(row + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
+  }
+  __syncthreads();
+  const int nf = nrows * F4;
+  for (int f0 = tid; f0 < nf; f0 += 256 * 2) {
+    float4 P[2], M[2], V[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int f = f0 + 256 * u;
+      if (f < nf) {
+        const size_t e = blk + 4 * (size_t)f;
+        P[u] = ld4(sh + e); M[u] = ld4(exp_avg + ad.e_opac + e); V[u] = ld4(exp_avg_sq + ad.e_opac + e);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int f = f0 + 256 * u;
+      if (f < nf) {
+        const int row = f / F4, c4 = f - row * F4;
+        const float4 G = ld4(lds + row * RS + 4 * c4);
+        const size_t e = blk + 4 * (size_t)f;
+        const int c = 4 * c4;  // column inside the 3K-float row; DC = columns 0..2
+        adam1(ad, c < 3 ? ad.lr_dc : ad.lr_rest, P[u].x, G.x, M[u].x, V[u].x);
+        adam1(ad, c + 1 < 3 ? ad.lr_dc : ad.lr_rest, P[u].y, G.y, M[u].y, V[u].y);
+        adam1(ad, c + 2 < 3 ? ad.lr_dc : ad.lr_rest, P[u].z, G.z, M[u].z, V[u].z);
+        adam1(ad, ad.lr_rest, P[u].w, G.w, M[u].w, V[u].w);
+        st4(sh + e, P[u]); st4(exp_avg + ad.e_opac + e, M[u]); st4(exp_avg_sq + ad.e_opac + e, V[u]);
       }
     }
   }
@@ -768,7 +875,7 @@ extern "C" int tgs_project_bwd(const TgsCamera* cam, int N, const float* means,
 #define LAUNCH(D)                                                                                \
   hipLaunchKernelGGL(k_project_bwd<D>, grid, block, 0, s, k, N, means, log_scales, quats,        \
                      opac_logit, sh, sh_stride, splats, group_base, partials, v_splats, v_means, \
-                     v_log_scales, v_quats, v_opac_logit, v_sh, v_xy)
+                     v_log_scales, v_quats, v_opac_logit, v_sh, (float*)nullptr, v_xy)
   switch (sh_deg) {
     case 0: LAUNCH(0); break;
     case 1: LAUNCH(1); break;
@@ -885,6 +992,81 @@ extern "C" int tgs_sh_bwd(int N, int sh_deg, int sh_stride, const float* dirs, c
     case 2: hipLaunchKernelGGL((k_sh_op<2, true>), grid, block, 0, s, N, sh_stride, dirs, v_colors, v_coeffs); break;
     default: hipLaunchKernelGGL((k_sh_op<3, true>), grid, block, 0, s, N, sh_stride, dirs, v_colors, v_coeffs); break;
   }
+  TGS_CHECK_LAUNCH();
+  return TGS_OK;
+}
+
+// K8 of the data-parallel step: geometry gradients + clamp-gated colour gradient, no SH rows.
+extern "C" int tgs_project_bwd_color(const TgsCamera* cam, int N, const float* means,
+                                     const float* log_scales, const float* quats,
+                                     const float* opac_logit, const float* sh, int sh_stride,
+                                     int sh_deg, const float* splats, const int32_t* group_base,
+                                     const float* partials, float* v_means, float* v_log_scales,
+                                     float* v_quats, float* v_opac_logit, float* v_color,
+                                     float* v_xy, void* stream) {
+  TGS_CHECK_ARG(camera_ok(cam), "bad camera");
+  if (N <= 0) return TGS_OK;
+  TGS_CHECK_ARG(means && log_scales && quats && opac_logit && sh && splats && group_base && partials,
+                "null pointer");
+  TGS_CHECK_ARG(v_means && v_log_scales && v_quats && v_opac_logit && v_color, "null output pointer");
+  TGS_CHECK_ARG(sh_deg >= 0 && sh_deg <= 3, "sh_deg out of range");
+  TGS_CHECK_ARG(sh_stride >= (sh_deg + 1) * (sh_deg + 1), "sh_stride too small");
+  const CamK k = make_camk(cam);
+  const dim3 grid((N + 255) / 256), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (sh_deg >= 1 && sh_stride == (sh_deg + 1) * (sh_deg + 1) && (3 * sh_stride) % 4 == 0) {
+    AdamK none{};
+    const size_t lds_bytes = 256 * (size_t)(3 * sh_stride + 4) * sizeof(float);
+#define LAUNCH_C(D)                                                                              \
+  hipLaunchKernelGGL((k_project_bwd_lds<D, false, true>), grid, block, lds_bytes, s, k, N,       \
+                     const_cast<float*>(means), const_cast<float*>(log_scales),                  \
+                     const_cast<float*>(quats), const_cast<float*>(opac_logit),                  \
+                     const_cast<float*>(sh), splats, group_base, partials, v_means, v_log_scales,\
+                     v_quats, v_opac_logit, v_color, v_xy, none, (float*)nullptr, (float*)nullptr)
+    if (sh_deg == 3) LAUNCH_C(3); else LAUNCH_C(1);
+#undef LAUNCH_C
+    TGS_CHECK_LAUNCH();
+    return TGS_OK;
+  }
+#define LAUNCH(D)                                                                                \
+  hipLaunchKernelGGL(k_project_bwd<D>, grid, block, 0, s, k, N, means, log_scales, quats,        \
+                     opac_logit, sh, sh_stride, splats, group_base, partials,                    \
+                     (const float*)nullptr, v_means, v_log_scales, v_quats, v_opac_logit,        \
+                     (float*)nullptr, v_color, v_xy)
+  switch (sh_deg) {
+    case 0: LAUNCH(0); break;
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    default: LAUNCH(3); break;
+  }
+#undef LAUNCH
+  TGS_CHECK_LAUNCH();
+  return TGS_OK;
+}
+
+extern "C" int tgs_adam_step_sh_gathered(int world, int N, int sh_stride, int sh_deg, float* params,
+                                         const float* v_color_all, float* exp_avg,
+                                         float* exp_avg_sq, const TgsAdamSpec* spec,
+                                         float grad_scale, void* stream) {
+  TGS_CHECK_ARG(world >= 1 && N >= 0, "bad size");
+  if (N == 0) return TGS_OK;
+  TGS_CHECK_ARG(params && v_color_all && exp_avg && exp_avg_sq && spec, "null pointer");
+  TGS_CHECK_ARG(sh_deg >= 0 && sh_deg <= 3 && sh_stride >= (sh_deg + 1) * (sh_deg + 1), "bad SH degree / stride");
+  TGS_CHECK_ARG((3 * sh_stride) % 4 == 0, "SH row (3*sh_stride floats) must be a multiple of 16 bytes");
+  const AdamK a = make_adamk(N, sh_stride, spec, grad_scale);
+  const dim3 grid((N + 255) / 256), block(256);
+  const size_t lds_bytes = 256 * (size_t)(3 * sh_stride + 4) * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_G(D)                                                                              \
+  hipLaunchKernelGGL((k_adam_sh_gathered<D>), grid, block, lds_bytes, s, world, N, sh_stride,    \
+                     params, params + a.e_opac, v_color_all, a, exp_avg, exp_avg_sq)
+  switch (sh_deg) {
+    case 0: LAUNCH_G(0); break;
+    case 1: LAUNCH_G(1); break;
+    case 2: LAUNCH_G(2); break;
+    default: LAUNCH_G(3); break;
+  }
+#undef LAUNCH_G
   TGS_CHECK_LAUNCH();
   return TGS_OK;
 }

@@ -88,6 +88,8 @@ class DepthGaussianSplattingModel:
         self.optimizer = FusedAdam(self.params, self.config.lrs())
         self.budget = ops.IntersectBudget()
         self.fuse_adam = True   # single-process steps use the fused K8+K9 kernel when it applies
+        self.dp_factored_sh = True   # data-parallel steps exchange colour gradients, not SH rows
+        self._color_block = self._color_all = None
         self.last = {}
 
     @property
@@ -176,7 +178,8 @@ class DepthGaussianSplattingModel:
                         uncertainty_weight=c.uncertainty_weight, eps=c.depth_eps)
         return spec
 
-    def forward_backward(self, view: View, want_v_xy: bool = False, fuse_adam: bool = False):
+    def forward_backward(self, view: View, want_v_xy: bool = False, fuse_adam: bool = False,
+                         color_block: Optional[torch.Tensor] = None):
         """Forward + loss + backward of one view into ``params.grad`` (overwritten) -- or, with
         ``fuse_adam``, straight through the optimizer update (K8+K9 fused, ``params.grad`` untouched).
         No host sync unless ``budget.sync``.  Returns device tensors (l1+depth tile losses, ssim sum)."""
@@ -194,6 +197,9 @@ class DepthGaussianSplattingModel:
                                                 loss=self.loss_spec(view), want_tile_loss=True)
         if fuse_adam:
             v_xy = self.optimizer.backward_and_step(cam, deg, splats, group_base, partials, want_v_xy)
+        elif color_block is not None:   # data-parallel: geometry gradients + colour-gradient block
+            v_xy = ops.project_bwd_color(cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, splats,
+                                         group_base, partials, p.grad_views()[:4], color_block, want_v_xy)
         else:
             v_xy = ops.project_bwd(cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, splats,
                                    group_base, partials, out=p.grad_views(), want_v_xy=want_v_xy)[5]
@@ -218,12 +224,28 @@ class DepthGaussianSplattingModel:
     def train_step(self, view: View, dp=None) -> None:
         """One optimizer iteration on one view (per rank).  ``dp``: a parallel.GradSync or None."""
         distributed = dp is not None and dp.world > 1
-        fuse = (not distributed) and self.fuse_adam and self.optimizer.can_fuse_with_backward(self.active_sh_degree())
+        opt = self.optimizer
+        deg = self.active_sh_degree()
+        fuse = (not distributed) and self.fuse_adam and opt.can_fuse_with_backward(deg)
+        factored = distributed and self.dp_factored_sh and opt.can_gather_sh()
         density = getattr(self, "density", None)
-        self.forward_backward(view, want_v_xy=density is not None, fuse_adam=fuse)
+        block = None
+        if factored:
+            n = 3 * self.params.N + 4
+            if self._color_block is None or self._color_block.numel() != n or self._color_all.numel() != n * dp.world:
+                dev = self.params.flat.device
+                self._color_block = torch.zeros(n, dtype=torch.float32, device=dev)
+                self._color_all = torch.zeros(dp.world, n, dtype=torch.float32, device=dev)
+            block = self._color_block
+        self.forward_backward(view, want_v_xy=density is not None, fuse_adam=fuse, color_block=block)
         if density is not None:
             density.accumulate(self.last["v_xy"], self.last["radii"], view.cam.W, view.cam.H)
-        if distributed:
+        if factored:
+            dp.gather_color_reduce_geom_and_step(
+                self.params.grad[:opt.geom_end()], block, self._color_all,
+                lambda allc, scale: opt.step_sh_gathered(dp.world, deg, allc, scale),
+                opt.step_range, opt.begin_step)
+        elif distributed:
             dp.reduce_and_step(self.params.grad, self.optimizer.step_range, self.optimizer.begin_step)
         elif not fuse:
             self.optimizer.step()

@@ -243,6 +243,25 @@ def project_bwd(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_deg, s
     return v_means, v_ls, v_q, v_ol, v_sh, v_xy
 
 
+def project_bwd_color(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_deg, splats, group_base,
+                      partials, out, v_color, want_v_xy=False):
+    """K8 of the data-parallel step (tgs_project_bwd_color): geometry gradients into ``out`` =
+    (v_means, v_log_scales, v_quats, v_opac_logit) and, instead of the SH gradient, the block
+    ``v_color`` [3N+4] = clamp-gated colour gradients | camera position | pad.  -> v_xy or None."""
+    lib = _lib.load()
+    N = means.shape[0]
+    if v_color.numel() != 3 * N + 4 or v_color.dtype != torch.float32:
+        raise ValueError("v_color must be a float32 tensor of 3N+4 elements")
+    v_means, v_ls, v_q, v_ol = out
+    v_xy = torch.empty(N, 2, dtype=torch.float32, device=means.device) if want_v_xy else None
+    cs = cam.c_struct()
+    check(lib.tgs_project_bwd_color(C.byref(cs), N, ptr(means), ptr(log_scales), ptr(quats), ptr(opac_logit),
+                                    ptr(sh), sh.shape[1], sh_deg, ptr(splats), ptr(group_base), ptr(partials),
+                                    ptr(v_means), ptr(v_ls), ptr(v_q), ptr(v_ol), ptr(v_color), ptr(v_xy),
+                                    _stream()), "tgs_project_bwd_color")
+    return v_xy
+
+
 # ------------------------------------------------------------------------------------------------
 # fused differentiable render
 # ------------------------------------------------------------------------------------------------

@@ -132,6 +132,26 @@ class FusedAdam:
                                        ptr(partials), ptr(v_xy), stream), "tgs_project_bwd_adam")
         return v_xy
 
+    def can_gather_sh(self) -> bool:
+        """tgs_adam_step_sh_gathered streams SH rows as float4s: 3K must be a multiple of 4."""
+        return (3 * self.p.K) % 4 == 0
+
+    def geom_end(self) -> int:
+        """First flat element of the SH segment (= number of geometry elements incl. padding)."""
+        return layout(self.p.N, self.p.K)["sh"][0]
+
+    def step_sh_gathered(self, world: int, sh_deg: int, v_color_all: torch.Tensor, grad_scale: float):
+        """Adam on the SH segment from the all-gathered colour-gradient blocks [world, 3N+4] of the
+        current step (call before the geometry segments are stepped: it reads the means)."""
+        lib = _lib.load()
+        if v_color_all.numel() != world * (3 * self.p.N + 4):
+            raise ValueError("v_color_all must hold world blocks of 3N+4 floats")
+        s = self._spec()
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.tgs_adam_step_sh_gathered(world, self.p.N, self.p.K, sh_deg, ptr(self.p.flat), ptr(v_color_all),
+                                            ptr(self.exp_avg), ptr(self.exp_avg_sq), C.byref(s),
+                                            C.c_float(grad_scale), stream), "tgs_adam_step_sh_gathered")
+
     def state_dict(self):
         return dict(t=self.t, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lrs=self.lrs)
 
