@@ -188,6 +188,15 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = args.steps * dp.world / elapsed
 
+    # ---- collective times of the exchange (outside the timed region; every rank takes part) ----
+    comm = None
+    if dp.world > 1:
+        dp.timing = True
+        for i in range(3):
+            step(args.warmup + args.steps + i)
+        comm = dp.comm_report()
+        dp.timing = False
+
     # ---- per-kernel timing of the same step (HIP events on the launch stream), rank 0 ----
     out = None
     if dp.rank == 0:
@@ -267,6 +276,8 @@ def main():
                                   if model._color_all is not None else "all-reduce flat gradient buffer",
                                   "payload_bytes_per_rank_per_step": int(dp.bytes_per_step),
                                   "dense_all_reduce_bytes": int(model.params.grad.numel() * 4)}
+            if comm:
+                out["dp_exchange"].update(comm)
         if dp.world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(N, W, H, deg, args.seed)

@@ -54,6 +54,8 @@ class GradSync:
         self.n_chunks = n_chunks
         self.bytes_per_step = 0
         self._comm_stream = None
+        self.timing = False        # record events around the collectives of the factored step
+        self._comm_events = None
 
     def all_reduce_(self, flat_grad: torch.Tensor) -> float:
         if self.world > 1:
@@ -140,17 +142,37 @@ class GradSync:
         ready = torch.cuda.Event()
         ready.record(comp)                     # K8 complete on the compute stream
         self._comm_stream.wait_event(ready)
+        t = self.timing
         with torch.cuda.stream(self._comm_stream):
+            begun = torch.cuda.Event(enable_timing=t)
+            begun.record(self._comm_stream)
             gather()
-            gathered = torch.cuda.Event()
+            gathered = torch.cuda.Event(enable_timing=t)
             gathered.record(self._comm_stream)
             dist.all_reduce(geom_grad, op=dist.ReduceOp.SUM)
-            reduced = torch.cuda.Event()
+            reduced = torch.cuda.Event(enable_timing=t)
             reduced.record(self._comm_stream)
+        if t:
+            self._comm_events = (begun, gathered, reduced, v_color.numel() * 4, geom_grad.numel() * 4)
         comp.wait_event(gathered)
         step_sh(v_color_all, scale)
         comp.wait_event(reduced)
         step_geom(0, geom_grad.numel(), scale)
+
+    def comm_report(self) -> Optional[dict]:
+        """Times and bus bandwidths of the last factored exchange recorded with ``timing = True``
+        (synchronises).  busbw follows the rccl-tests convention: all-gather total_bytes*(n-1)/n / t,
+        all-reduce bytes*2(n-1)/n / t."""
+        if self._comm_events is None:
+            return None
+        begun, gathered, reduced, block_bytes, geom_bytes = self._comm_events
+        reduced.synchronize()
+        n = self.world
+        tg, tr = begun.elapsed_time(gathered) * 1e-3, gathered.elapsed_time(reduced) * 1e-3
+        return {"all_gather_ms": round(tg * 1e3, 4), "all_gather_bytes_per_rank": block_bytes,
+                "all_gather_busbw_GBs": round(block_bytes * n * (n - 1) / n / tg / 1e9, 1),
+                "all_reduce_ms": round(tr * 1e3, 4), "all_reduce_bytes": geom_bytes,
+                "all_reduce_busbw_GBs": round(geom_bytes * 2 * (n - 1) / n / tr / 1e9, 1)}
 
     def barrier(self):
         if self.world > 1:
