@@ -20,9 +20,11 @@
 //    last-contributor index, no T/(1-alpha) division chain); per-pixel state is (T, prefix.v)
 //    only; each lane accumulates, over its <= 4 pixels,
 //    10 sums per Gaussian (v_rgb, v_depth and the six pixel-coordinate moments of
-//    q = alpha * v_alpha); a multiplexed DPP butterfly (35 VALU ops for all 10 values instead of
-//    10 x 6) leaves value i in lane i, which drops it into an LDS transpose buffer; at the end
-//    of the batch lane j converts Gaussian j's moments into (v_xy, v_conic, v_opacity) and stores
+//    q = alpha * v_alpha); the 64-lane sums go through LDS: every lane scatters its 10 values
+//    into a padded [10][68] image, lane (part, c) adds 16 lane contributions of value c read as
+//    four ds_read_b128, two ds_bpermute steps combine the four parts and value i lands in slot i
+//    of an LDS transpose buffer (17 VALU + 11 LDS instructions; a multiplexed DPP butterfly
+//    needs 37 VALU and the kernel is VALU bound); at the end of the batch lane j converts Gaussian j's moments into (v_xy, v_conic, v_opacity) and stores
 //    one 48-B partial record.  There are NO float atomics: cross-tile accumulation is a segmented
 //    sum in K8 (deterministic, and it avoids cross-XCD memory-side atomics).
 //  * blockIdx -> tile mapping gives each XCD a contiguous band of tiles so the gathered splat
@@ -251,36 +253,6 @@ __device__ __forceinline__ size_t pair_index(const int32_t* __restrict__ group_b
          (size_t)((ty - y0) * w + (tx - x0));
 }
 
-// one multiplexed butterfly step: lanes whose `bit` is clear keep A, the others keep B; each lane
-// adds its partner's copy of the value it keeps.  Halves the number of live registers.
-template <int CTRL>
-__device__ __forceinline__ float mux_step(float A, float B, bool bit) {
-  const float keep = bit ? B : A;
-  const float send = bit ? A : B;
-  const int s = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), CTRL, 0xf, 0xf, false);
-  return keep + __builtin_bit_cast(float, s);
-}
-
-// Sums v[0..9] over the 64 lanes; lane i (and i+16, i+32, i+48) ends up holding the total of v[i].
-__device__ __forceinline__ float butterfly10(const float* v, bool b0, bool b1, bool b2, bool b3) {
-  const float R0 = mux_step<0xB1>(v[0], v[1], b0);   // quad_perm [1,0,3,2]
-  const float R1 = mux_step<0xB1>(v[2], v[3], b0);
-  const float R2 = mux_step<0xB1>(v[4], v[5], b0);
-  const float R3 = mux_step<0xB1>(v[6], v[7], b0);
-  const float R4 = mux_step<0xB1>(v[8], v[9], b0);
-  const float Q0 = mux_step<0x4E>(R0, R1, b1);       // quad_perm [2,3,0,1]
-  const float Q1 = mux_step<0x4E>(R2, R3, b1);
-  const float Q2 = mux_step<0x4E>(R4, 0.f, b1);
-  const float P0 = mux_step<0x124>(Q0, Q1, b2);      // row_ror:4
-  const float P1 = mux_step<0x124>(Q2, 0.f, b2);
-  float O = mux_step<0x128>(P0, P1, b3);             // row_ror:8  -> per row: lane i = sum of v[i]
-  // lane-wise sum of the four rows (each lane of a row holds a different value, so the
-  // single-lane row_bcast DPP forms do not apply): two ds_bpermute exchanges
-  O += __shfl_xor(O, 16);
-  O += __shfl_xor(O, 32);
-  return O;
-}
-
 __global__ __launch_bounds__(64) void k_raster_bwd(
     CamK cam, int T_total, const float* __restrict__ splats, const int32_t* __restrict__ group_base,
     const int32_t* __restrict__ sorted_gid, const int32_t* __restrict__ tile_start,
@@ -297,7 +269,6 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
   const PixConst pc = make_pix_const(lane);
   const int start = tile_start[tile], end = tile_start[tile + 1];
   const int n = end - start;
-  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
 
   // The list is walked FRONT TO BACK exactly like the forward (same blend_step, hence the same
   // transmittance sequence and the same threshold decisions); the colour accumulated BEHIND a
@@ -362,6 +333,14 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
 
   __shared__ float4 recs[64 * 3];
   __shared__ float4 sums[64 * 4];  // [Gaussian j][16 slots], slot i < 10 = total of value i
+  // transposed reduction scratch: row c (value index) holds the 64 lane contributions, rows padded
+  // to 68 floats so that the 16 lanes of a quarter wave, reading 16 B each from 16 different rows,
+  // touch 64 distinct banks
+  constexpr int RED_RS = 68;
+  __shared__ float4 red4[10 * RED_RS / 4];
+  float* red = reinterpret_cast<float*>(red4);
+  const int red_c = lane & 15, red_part = lane >> 4;
+  const float* red_rd = red + (red_c < 10 ? red_c : 0) * RED_RS + red_part * 16;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   int base = start;
   for (; base < end; base += 64) {
@@ -431,8 +410,21 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
         }
       }
       if (__ballot(any) != 0ull) {
-        const float O = butterfly10(acc, b0, b1, b2, b3);
+        // LDS operations of one wave execute in order, so the (single-wave) workgroup needs no
+        // barrier between the scatter and the transposed read -- only the compiler must keep them
+        // in order, which the possible aliasing already forces
+#pragma unroll
+        for (int c = 0; c < 10; c++) red[c * RED_RS + lane] = acc[c];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float4 r0 = ld4(red_rd), r1 = ld4(red_rd + 4), r2 = ld4(red_rd + 8), r3 = ld4(red_rd + 12);
+        float O = ((r0.x + r0.y) + (r0.z + r0.w)) + ((r1.x + r1.y) + (r1.z + r1.w)) +
+                  (((r2.x + r2.y) + (r2.z + r2.w)) + ((r3.x + r3.y) + (r3.z + r3.w)));
+        O += __shfl_xor(O, 16);
+        O += __shfl_xor(O, 32);
         if (lane < 16) reinterpret_cast<float*>(sums)[j * 16 + lane] = O;
+        __builtin_amdgcn_wave_barrier();
       }
     }
     __syncthreads();
