@@ -1,0 +1,27 @@
+#!/bin/bash
+# Collects the judged profiles for cfg3 on the GPU box and writes them under gpurun_out/profiles_<tag>/:
+#   bench.json            -- `python bench.py` (un-profiled)
+#   kernel_stats.csv      -- rocprofv3 --kernel-trace --stats of the same bench command
+#   pmc_step_cfg3.json    -- four SEPARATE --pmc passes (FETCH_SIZE | WRITE_SIZE | 8 SQ | 6 SQ + GRBM) over
+#                            tools/step_run.py, averaged per kernel, HBM bytes corrected as
+#                            MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 on gfx950, KB units)
+# Usage (from the repo root on the GPU box):  bash tools/collect_profiles.sh r1_f
+set -e
+TAG=${1:-rX}
+OUT=gpurun_out/profiles_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+python bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
+rm -rf /tmp/prof_ks
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > /tmp/ks.log 2>&1
+cp $(ls /tmp/prof_ks/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" \
+           "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" \
+           "SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY GRBM_GUI_ACTIVE"; do
+  rm -rf /tmp/prof_pmc$i
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/prof_pmc$i -- python tools/step_run.py 3 separate > /tmp/pmc$i.log 2>&1
+  i=$((i+1))
+done
+python tools/pmc_to_json.py $OUT/kernel_stats.csv /tmp/prof_pmc0 /tmp/prof_pmc1 /tmp/prof_pmc2 /tmp/prof_pmc3 > $OUT/pmc_step_cfg3.json
+echo "wrote $OUT"
