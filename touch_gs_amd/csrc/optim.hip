@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void k_adam(AdamK a, float* __restrict__ p,
   bool in_sh = false;
   for (long long i = (a.e_begin >> 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     const long long e = 4 * i;
-    float4 P = ld4(p + e), G = ld4(g + e), M = ld4(m + e), V = ld4(v + e);
+    float4 P = ld4_nt(p + e), G = ld4_nt(g + e), M = ld4_nt(m + e), V = ld4_nt(v + e);
     float l0, l1, l2, l3;
     if (e < a.e_opac) {
       const float lr = e < a.e_means ? a.lr_means : (e < a.e_scales ? a.lr_scales
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void k_adam(AdamK a, float* __restrict__ p,
     adam1(a, l1, P.y, G.y, M.y, V.y);
     adam1(a, l2, P.z, G.z, M.z, V.z);
     adam1(a, l3, P.w, G.w, M.w, V.w);
-    st4(p + e, P); st4(m + e, M); st4(v + e, V);
+    st4_nt(p + e, P); st4_nt(m + e, M); st4_nt(v + e, V);
   }
 }
 

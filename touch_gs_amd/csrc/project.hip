@@ -261,8 +261,8 @@ __device__ __forceinline__ void sum_partials(const CamK& cam, const float* __res
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       if (k0 + u < hits) {
-        a[u] = ld4(p + u * TGS_PARTIAL_FLOATS);
-        b[u] = ld4(p + u * TGS_PARTIAL_FLOATS + 4);
+        a[u] = ld4_nt(p + u * TGS_PARTIAL_FLOATS);
+        b[u] = ld4_nt(p + u * TGS_PARTIAL_FLOATS + 4);
         c[u] = *reinterpret_cast<const float2*>(p + u * TGS_PARTIAL_FLOATS + 8);
       }
     }
@@ -615,11 +615,11 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
       }
       {
         const long long e = ad.e_scales + 4ll * g;
-        float4 M = ld4(ea + e), V = ld4(es + e);
+        float4 M = ld4_nt(ea + e), V = ld4_nt(es + e);
         float4 Q = make_float4(q[0], q[1], q[2], q[3]);
         adam1(ad, ad.lr_quats, Q.x, vq[0], M.x, V.x); adam1(ad, ad.lr_quats, Q.y, vq[1], M.y, V.y);
         adam1(ad, ad.lr_quats, Q.z, vq[2], M.z, V.z); adam1(ad, ad.lr_quats, Q.w, vq[3], M.w, V.w);
-        st4(quats + 4 * (size_t)g, Q); st4(ea + e, M); st4(es + e, V);
+        st4_nt(quats + 4 * (size_t)g, Q); st4_nt(ea + e, M); st4_nt(es + e, V);
       }
       {
         const long long e = ad.e_quats + g;
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
         const int f = f0 + 256 * u;
         if (f < nf) {
           const size_t e = blk + 4 * (size_t)f;
-          P[u] = ld4(sh + e); M[u] = ld4(exp_avg + ad.e_opac + e); V[u] = ld4(exp_avg_sq + ad.e_opac + e);
+          P[u] = ld4_nt(sh + e); M[u] = ld4_nt(exp_avg + ad.e_opac + e); V[u] = ld4_nt(exp_avg_sq + ad.e_opac + e);
         }
       }
 #pragma unroll
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
           adam1(ad, c + 1 < 3 ? ad.lr_dc : ad.lr_rest, P[u].y, G.y, M[u].y, V[u].y);
           adam1(ad, c + 2 < 3 ? ad.lr_dc : ad.lr_rest, P[u].z, G.z, M[u].z, V[u].z);
           adam1(ad, ad.lr_rest, P[u].w, G.w, M[u].w, V[u].w);
-          st4(sh + e, P[u]); st4(exp_avg + ad.e_opac + e, M[u]); st4(exp_avg_sq + ad.e_opac + e, V[u]);
+          st4_nt(sh + e, P[u]); st4_nt(exp_avg + ad.e_opac + e, M[u]); st4_nt(exp_avg_sq + ad.e_opac + e, V[u]);
         }
       }
     }
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(256) void k_adam_sh_gathered(
       const int f = f0 + 256 * u;
       if (f < nf) {
         const size_t e = blk + 4 * (size_t)f;
-        P[u] = ld4(sh + e); M[u] = ld4(exp_avg + ad.e_opac + e); V[u] = ld4(exp_avg_sq + ad.e_opac + e);
+        P[u] = ld4_nt(sh + e); M[u] = ld4_nt(exp_avg + ad.e_opac + e); V[u] = ld4_nt(exp_avg_sq + ad.e_opac + e);
       }
     }
 #pragma unroll
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256) void k_adam_sh_gathered(
         adam1(ad, c + 1 < 3 ? ad.lr_dc : ad.lr_rest, P[u].y, G.y, M[u].y, V[u].y);
         adam1(ad, c + 2 < 3 ? ad.lr_dc : ad.lr_rest, P[u].z, G.z, M[u].z, V[u].z);
         adam1(ad, ad.lr_rest, P[u].w, G.w, M[u].w, V[u].w);
-        st4(sh + e, P[u]); st4(exp_avg + ad.e_opac + e, M[u]); st4(exp_avg_sq + ad.e_opac + e, V[u]);
+        st4_nt(sh + e, P[u]); st4_nt(exp_avg + ad.e_opac + e, M[u]); st4_nt(exp_avg_sq + ad.e_opac + e, V[u]);
       }
     }
   }

@@ -131,5 +131,15 @@ __device__ __forceinline__ int wave_max_i(int v) {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// streaming (non-temporal) 16-byte accesses for data touched exactly once per launch
+typedef float tgs_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_nt(const float* p) {
+  const tgs_f4v v = __builtin_nontemporal_load(reinterpret_cast<const tgs_f4v*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st4_nt(float* p, float4 v) {
+  tgs_f4v t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+  __builtin_nontemporal_store(t, reinterpret_cast<tgs_f4v*>(p));
+}
 
 #endif  // __HIPCC__
