@@ -116,7 +116,8 @@ int tgs_sh_bwd(int N, int sh_deg, int sh_stride, const float* dirs, const float*
  *      sorted_gid[cap]  Gaussian ids, per tile, front to back, ties by id
  *      status[2]        {#intersections, overflow flag}; if #intersections > capacity nothing
  *                       past the scans is written, overflow=1 (caller grows and retries)
- * tmp: tile_cursor[T], scratch (tgs_sort_scratch_bytes(capacity)). */
+ * tmp: tile_cursor[T], scratch (tgs_sort_scratch_bytes(capacity)).  If status == tile_cursor + T (one
+ *      allocation of T+2 ints rounded up to a multiple of 4) both are cleared by a single fill. */
 int tgs_bin_sort(const TgsCamera* cam /*[host]*/, int N, float* splats, int32_t* group_base,
                  int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
                  int64_t capacity, void* scratch, int32_t* status, void* stream);

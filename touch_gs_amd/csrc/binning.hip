@@ -150,40 +150,44 @@ __global__ __launch_bounds__(THREADS) void k_sort_tiles_lds(
   }
 }
 
-// Fallback for lists longer than the largest LDS class: the same network in global memory, on a
-// power-of-two padded copy at fb[2*s ...) (next_pow2(n) < 2n, so per-tile regions never overlap).
-template <int LO>
-__global__ __launch_bounds__(1024) void k_sort_tiles_global(
+// Rare long lists: one launch covers both remaining classes.  (LO, CAP] sorts in 128 KB of LDS like
+// the common class; anything longer runs the same network in global memory on a power-of-two
+// padded copy at fb[2*s ...) (next_pow2(n) < 2n, so per-tile regions never overlap).
+template <int CAP, int LO>
+__global__ __launch_bounds__(1024) void k_sort_tiles_long(
     int T, const int32_t* __restrict__ tile_start, const unsigned long long* __restrict__ pairs,
     unsigned long long* __restrict__ fb, int32_t* __restrict__ sorted_gid) {
+  __shared__ unsigned long long lds_keys[CAP];
   const int tid = threadIdx.x;
   for (int tile = blockIdx.x; tile < T; tile += gridDim.x) {
-  const int s = tile_start[tile];
-  const int n = tile_start[tile + 1] - s;
-  if (n <= LO) continue;
-  const int np2 = next_pow2(n);
-  unsigned long long* keys = fb + 2 * (size_t)s;
-  for (int i = tid; i < np2; i += 1024) keys[i] = (i < n) ? pairs[s + i] : ~0ull;
-  __syncthreads();
-  for (int k = 2; k <= np2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < (np2 >> 1); i += 1024) {
-        const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
-        const int hi = lo | j;
-        const bool up = (lo & k) == 0;
-        const unsigned long long a = keys[lo], b = keys[hi];
-        if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+    const int s = tile_start[tile];
+    const int n = tile_start[tile + 1] - s;
+    if (n <= LO) continue;
+    const int np2 = next_pow2(n);
+    const bool in_lds = n <= CAP;
+    unsigned long long* keys = in_lds ? lds_keys : fb + 2 * (size_t)s;
+    __syncthreads();  // lds_keys reuse across iterations
+    for (int i = tid; i < np2; i += 1024) keys[i] = (i < n) ? pairs[s + i] : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < (np2 >> 1); i += 1024) {
+          const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+          const int hi = lo | j;
+          const bool up = (lo & k) == 0;
+          const unsigned long long a = keys[lo], b = keys[hi];
+          if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+        }
+        if (!in_lds) __threadfence_block();
+        __syncthreads();
       }
-      __threadfence_block();
-      __syncthreads();
     }
-  }
-  for (int i = tid; i < n; i += 1024) sorted_gid[s + i] = (int)(keys[i] & 0xffffffffull);
+    for (int i = tid; i < n; i += 1024) sorted_gid[s + i] = (int)(keys[i] & 0xffffffffull);
   }
 }
 
 constexpr int SORT_CAP_A = 2048;   // 16 KB LDS, 256 threads
-constexpr int SORT_CAP_B = 16384;  // 128 KB LDS, 1024 threads
+constexpr int SORT_CAP_B = 16384;  // 128 KB LDS, 1024 threads; longer lists sort in global memory
 
 }  // namespace
 
@@ -213,11 +217,8 @@ int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* gro
     hipLaunchKernelGGL((k_sort_tiles_lds<SORT_CAP_A, 256, 0>), dim3(T), dim3(256), 0, s, T,
                        tile_start, sc.pairs, sorted_gid);
     TGS_CHECK_LAUNCH();
-    hipLaunchKernelGGL((k_sort_tiles_lds<SORT_CAP_B, 1024, SORT_CAP_A>), dim3(small_grid),
-                       dim3(1024), 0, s, T, tile_start, sc.pairs, sorted_gid);
-    TGS_CHECK_LAUNCH();
-    hipLaunchKernelGGL((k_sort_tiles_global<SORT_CAP_B>), dim3(small_grid), dim3(1024), 0, s, T,
-                       tile_start, sc.pairs, sc.fb, sorted_gid);
+    hipLaunchKernelGGL((k_sort_tiles_long<SORT_CAP_B, SORT_CAP_A>), dim3(small_grid), dim3(1024), 0,
+                       s, T, tile_start, sc.pairs, sc.fb, sorted_gid);
     TGS_CHECK_LAUNCH();
   }
   return TGS_OK;
@@ -237,8 +238,14 @@ extern "C" int tgs_bin_sort(const TgsCamera* cam, int N, float* splats, int32_t*
   const int G = tgs_num_groups(N);
   hipStream_t s = (hipStream_t)stream;
   const BinScratch sc = carve_scratch(scratch, capacity);
-  TGS_HIP(hipMemsetAsync(tile_cursor, 0, sizeof(int32_t) * (size_t)T, s));
-  TGS_HIP(hipMemsetAsync(status, 0, sizeof(int32_t) * 2, s));
+  if (status == tile_cursor + T) {
+    // the caller placed status right behind the counters (and, by contract, padded that allocation
+    // to a multiple of 4 ints): one 16-byte-granular fill instead of two fills plus a tail
+    TGS_HIP(hipMemsetAsync(tile_cursor, 0, sizeof(int32_t) * (((size_t)T + 2 + 3) & ~(size_t)3), s));
+  } else {
+    TGS_HIP(hipMemsetAsync(tile_cursor, 0, sizeof(int32_t) * (size_t)T, s));
+    TGS_HIP(hipMemsetAsync(status, 0, sizeof(int32_t) * 2, s));
+  }
   if (G > 0) {
     hipLaunchKernelGGL(k_tile_count, dim3(G), dim3(TGS_GROUP), 0, s, k, N, splats, group_base,
                        tile_cursor, sc.rank, status, (long long)capacity);

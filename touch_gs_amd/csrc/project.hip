@@ -938,8 +938,14 @@ extern "C" int tgs_project_bin_sort(const TgsCamera* cam, int N, const float* me
   const int T = k.TW * k.TH;
   hipStream_t s = (hipStream_t)stream;
   const BinScratch sc = carve_scratch(scratch, capacity);
-  TGS_HIP(hipMemsetAsync(tile_cursor, 0, sizeof(int32_t) * (size_t)T, s));
-  TGS_HIP(hipMemsetAsync(status, 0, sizeof(int32_t) * 2, s));
+  if (status == tile_cursor + T) {
+    // the caller placed status right behind the counters (and, by contract, padded that allocation
+    // to a multiple of 4 ints): one 16-byte-granular fill instead of two fills plus a tail
+    TGS_HIP(hipMemsetAsync(tile_cursor, 0, sizeof(int32_t) * (((size_t)T + 2 + 3) & ~(size_t)3), s));
+  } else {
+    TGS_HIP(hipMemsetAsync(tile_cursor, 0, sizeof(int32_t) * (size_t)T, s));
+    TGS_HIP(hipMemsetAsync(status, 0, sizeof(int32_t) * 2, s));
+  }
   if (N > 0) {
     const dim3 grid((N + 255) / 256), block(256);
 #define LAUNCH(D)                                                                                  \

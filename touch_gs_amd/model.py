@@ -191,7 +191,7 @@ class DepthGaussianSplattingModel:
         rgb, depth_acc, fT, fidx = ops.rasterize_fwd(cam, splats, sorted_gid, tile_start)
         v_img, ssim_sum = None, None
         if c.ssim_lambda > 0:
-            ssim_sum, v_img = ops.ssim_fwd_bwd(rgb, view.rgb, weight=-c.ssim_lambda / (3 * H * W))
+            ssim_sum, v_img = ops.ssim_fwd_bwd(rgb, view.rgb, weight=-c.ssim_lambda / (3 * H * W), reduce=False)
         partials, tile_loss = ops.rasterize_bwd(cam, splats, group_base, sorted_gid, tile_start, rgb,
                                                 depth_acc, fT, v_rgb=v_img,
                                                 loss=self.loss_spec(view), want_tile_loss=True)
@@ -212,8 +212,8 @@ class DepthGaussianSplattingModel:
         H, W = view.rgb.shape[:2]
         t = tile_loss.sum(0)
         main = t[0]
-        if ssim_sum is not None:
-            main = main + c.ssim_lambda * (1 - ssim_sum / (3 * H * W))
+        if ssim_sum is not None:   # per-block partial sums (or an already reduced scalar)
+            main = main + c.ssim_lambda * (1 - ssim_sum.sum() / (3 * H * W))
         return {"main_loss": main, "depth_loss": t[1]}
 
     def enable_densification(self, cfg=None):

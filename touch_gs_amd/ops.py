@@ -101,8 +101,8 @@ def bin_sort(cam: Camera, splats, budget: Optional[IntersectBudget] = None):
     cs = cam.c_struct()
     group_base = torch.empty(max(G, 1), dtype=torch.int32, device=dev)
     tile_start = torch.empty(T + 1, dtype=torch.int32, device=dev)
-    tile_cursor = torch.empty(max(T, 1), dtype=torch.int32, device=dev)
-    status = torch.empty(2, dtype=torch.int32, device=dev)
+    counters = torch.empty((T + 2 + 3) & ~3, dtype=torch.int32, device=dev)   # tile counters | status | pad: one fill
+    tile_cursor, status = counters[:T], counters[T:T + 2]
     cap = budget.initial(N)
     while True:
         sorted_gid = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
@@ -137,8 +137,8 @@ def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_d
     radii = torch.empty(N, dtype=torch.int32, device=dev) if want_radii else None
     group_base = torch.empty(max(G, 1), dtype=torch.int32, device=dev)
     tile_start = torch.empty(T + 1, dtype=torch.int32, device=dev)
-    tile_cursor = torch.empty(max(T, 1), dtype=torch.int32, device=dev)
-    status = torch.empty(2, dtype=torch.int32, device=dev)
+    counters = torch.empty((T + 2 + 3) & ~3, dtype=torch.int32, device=dev)   # tile counters | status | pad: one fill
+    tile_cursor, status = counters[:T], counters[T:T + 2]
     sh_stride = sh.shape[1] if sh is not None else 0
     cap = budget.initial(N)
     while True:
@@ -496,8 +496,10 @@ def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opaci
 # ------------------------------------------------------------------------------------------------
 # image-space loss kernel (K10)
 # ------------------------------------------------------------------------------------------------
-def ssim_fwd_bwd(img, gt, weight: float = 1.0, want_grad: bool = True):
+def ssim_fwd_bwd(img, gt, weight: float = 1.0, want_grad: bool = True, reduce: bool = True):
     """K10 -> (sum of the SSIM map [device scalar], v_img = weight * d(sum)/d(img) or None).
+    ``reduce=False`` returns the per-block partial sums instead (the train step only needs the
+    total when the loss value is logged, so it skips the extra reduction launch).
 
     Mean SSIM = sum / (3*H*W).  For the loss term l*(1-mean SSIM) pass weight = -l/(3*H*W).
     (tgs_ssim_fwd_bwd)
@@ -512,4 +514,4 @@ def ssim_fwd_bwd(img, gt, weight: float = 1.0, want_grad: bool = True):
     scratch = torch.empty(9 * H * W, dtype=torch.float32, device=dev) if want_grad else None
     check(lib.tgs_ssim_fwd_bwd(W, H, ptr(img), ptr(gt), C.c_float(weight), ptr(bp), ptr(v_img),
                                ptr(scratch), _stream()), "tgs_ssim_fwd_bwd")
-    return bp.sum(), v_img
+    return (bp.sum() if reduce else bp), v_img
