@@ -50,40 +50,40 @@ __global__ __launch_bounds__(TGS_GROUP) void k_tile_count(
 }
 
 // K4: exclusive scan of tile counts -> tile_start[T+1] (single workgroup; T is a few 10^4).
+// Thread t owns the contiguous chunk [t*C, (t+1)*C), C = ceil(T/1024): one serial pass over its
+// chunk, one workgroup scan of the 1024 chunk totals, one pass to write -- two barriers in all.
 // On capacity overflow every list is made empty so that downstream kernels touch nothing.
 __global__ __launch_bounds__(1024) void k_scan_tiles(int T, const int32_t* __restrict__ tile_count,
                                                      int32_t* __restrict__ tile_start,
                                                      const int32_t* __restrict__ status) {
   __shared__ int wave_tot[16];
-  __shared__ int carry_s;
   const int tid = threadIdx.x;
   const bool overflow = status[1] != 0;
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < T; base += 1024) {
-    const int i = base + tid;
-    const int v = (i < T && !overflow) ? tile_count[i] : 0;
-    int incl = v;
+  const int C = (T + 1023) / 1024;
+  const int lo = min(tid * C, T), hi = min(lo + C, T);
+  int sum = 0;
+  if (!overflow)
+    for (int i = lo; i < hi; i++) sum += tile_count[i];
+  int incl = sum;
 #pragma unroll
-    for (int o = 1; o < TGS_WAVE; o <<= 1) {
-      const int t = __shfl_up(incl, o);
-      if ((tid & 63) >= o) incl += t;
-    }
-    if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
-    __syncthreads();
-    int wbase = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < 16; w++) {
-      if (w < (tid >> 6)) wbase += wave_tot[w];
-      tot += wave_tot[w];
-    }
-    const int carry = carry_s;
-    if (i < T) tile_start[i] = carry + wbase + incl - v;
-    __syncthreads();
-    if (tid == 0) carry_s = carry + tot;
-    __syncthreads();
+  for (int o = 1; o < TGS_WAVE; o <<= 1) {
+    const int t = __shfl_up(incl, o);
+    if ((tid & 63) >= o) incl += t;
   }
-  if (tid == 0) tile_start[T] = carry_s;
+  if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+  __syncthreads();
+  int wbase = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) {
+    if (w < (tid >> 6)) wbase += wave_tot[w];
+    tot += wave_tot[w];
+  }
+  int run = wbase + incl - sum;
+  for (int i = lo; i < hi; i++) {
+    tile_start[i] = run;
+    run += overflow ? 0 : tile_count[i];
+  }
+  if (tid == 0) tile_start[T] = tot;
 }
 
 // K3b: scatter (gid, depth bits) into the tile bins.  slot = tile_start + arrival rank.
