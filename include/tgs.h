@@ -82,6 +82,7 @@ const char* tgs_last_error(void);
 /* Number of binning groups / tiles for sizing the caller's buffers. */
 int tgs_num_groups(int N);                 /* ceil(N/TGS_GROUP) */
 int tgs_num_tiles(int W, int H);           /* ceil(W/16)*ceil(H/16) */
+int tgs_tile_order_len(int W, int H);      /* tiles rounded up to a multiple of 8 (one entry per K6/K7 block) */
 /* Bytes of scratch tgs_bin_sort needs for a given intersection capacity. */
 size_t tgs_sort_scratch_bytes(int64_t capacity);
 
@@ -114,13 +115,17 @@ int tgs_sh_bwd(int N, int sh_deg, int sh_stride, const float* dirs, const float*
  *                       space (G = tgs_num_groups; ranges are disjoint, their order is arbitrary)
  *      tile_start[T+1]  [start,end) of every tile's list; tile_start[T] = #intersections
  *      sorted_gid[cap]  Gaussian ids, per tile, front to back, ties by id
+ *      tile_order[L]    (may be NULL; L = tgs_tile_order_len) tile visited by block b of K6 / K7:
+ *                       block b runs on XCD b % 8, every XCD keeps its contiguous band of tiles
+ *                       but visits it longest list first; entries == T mean "no tile"
  *      status[2]        {#intersections, overflow flag}; if #intersections > capacity nothing
  *                       past the scans is written, overflow=1 (caller grows and retries)
  * tmp: tile_cursor[T], scratch (tgs_sort_scratch_bytes(capacity)).  If status == tile_cursor + T (one
  *      allocation of T+2 ints rounded up to a multiple of 4) both are cleared by a single fill. */
 int tgs_bin_sort(const TgsCamera* cam /*[host]*/, int N, float* splats, int32_t* group_base,
                  int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
-                 int64_t capacity, void* scratch, int32_t* status, void* stream);
+                 int32_t* tile_order, int64_t capacity, void* scratch, int32_t* status,
+                 void* stream);
 
 /* K1 + K2-K5 in one call (the fast path): the projection workgroup IS the 256-Gaussian binning
  *     group, so it also builds the group scan and counts its tile intersections -- the records are
@@ -130,18 +135,20 @@ int tgs_project_bin_sort(const TgsCamera* cam /*[host]*/, int N, const float* me
                          const float* log_scales, const float* quats, const float* opac_logit,
                          const float* sh, int sh_stride, int sh_deg, float* splats, int32_t* radii,
                          int32_t* group_base, int32_t* tile_start, int32_t* tile_cursor,
-                         int32_t* sorted_gid, int64_t capacity, void* scratch, int32_t* status,
-                         void* stream);
+                         int32_t* sorted_gid, int32_t* tile_order, int64_t capacity, void* scratch,
+                         int32_t* status, void* stream);
 
 /* K6  per-tile front-to-back compositing of RGB + depth in ONE pass  (stands behind gsplat
  *     `rasterize_gaussians` fwd, called twice by Splatfacto for rgb and depth; spec App. B.6).
  * out: out_rgb[H,W,3] (incl. background)  out_depth[H,W] (= sum w*depth, NOT divided by alpha)
  *      final_T[H,W]  final_idx[H,W] (list position of the last contributor, -1 if none; may be
- *      NULL -- the backward does not need it) */
+ *      NULL -- the backward does not need it)
+ * in : tile_order (may be NULL = spatial order) as produced by tgs_bin_sort: scheduling only, the
+ *      results do not depend on it */
 int tgs_rasterize_fwd(const TgsCamera* cam /*[host]*/, const float* splats,
                       const int32_t* sorted_gid, const int32_t* tile_start,
-                      float* out_rgb, float* out_depth, float* final_T, int32_t* final_idx,
-                      void* stream);
+                      const int32_t* tile_order, float* out_rgb, float* out_depth, float* final_T,
+                      int32_t* final_idx, void* stream);
 
 /* K7  compositing backward with the tactile depth/uncertainty loss fused in  (stands behind
  *     gsplat `rasterize_gaussians` bwd; spec App. B.7).
@@ -154,8 +161,8 @@ int tgs_rasterize_fwd(const TgsCamera* cam /*[host]*/, const float* splats,
  *      tile_loss[T,2] (may be NULL) per-tile {sum|C-gt|*l1_weight, depth-term} of the fused loss */
 int tgs_rasterize_bwd(const TgsCamera* cam /*[host]*/, const float* splats,
                       const int32_t* group_base, const int32_t* sorted_gid,
-                      const int32_t* tile_start, const float* out_rgb, const float* out_depth,
-                      const float* final_T,
+                      const int32_t* tile_start, const int32_t* tile_order /*may be NULL*/,
+                      const float* out_rgb, const float* out_depth, const float* final_T,
                       const float* v_rgb, const float* v_depth, const float* v_alpha,
                       const TgsLossSpec* loss /*[host]*/, float* partials, float* tile_loss,
                       void* stream);

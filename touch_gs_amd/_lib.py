@@ -41,15 +41,16 @@ SIGNATURES = {
     "tgs_last_error": (C.c_char_p, []),
     "tgs_num_groups": (C.c_int, [_I]),
     "tgs_num_tiles": (C.c_int, [_I, _I]),
+    "tgs_tile_order_len": (C.c_int, [_I, _I]),
     "tgs_sort_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "tgs_project_fwd": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "tgs_sh_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P]),
     "tgs_sh_bwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P]),
-    "tgs_bin_sort": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P]),
+    "tgs_bin_sort": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P]),
     "tgs_project_bin_sort": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P,
-                                       C.c_int64, _P, _P, _P]),
-    "tgs_rasterize_fwd": (C.c_int, [C.POINTER(TgsCamera), _P, _P, _P, _P, _P, _P, _P, _P]),
-    "tgs_rasterize_bwd": (C.c_int, [C.POINTER(TgsCamera)] + [_P] * 10 + [C.POINTER(TgsLossSpec), _P, _P, _P]),
+                                       _P, C.c_int64, _P, _P, _P]),
+    "tgs_rasterize_fwd": (C.c_int, [C.POINTER(TgsCamera), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "tgs_rasterize_bwd": (C.c_int, [C.POINTER(TgsCamera)] + [_P] * 11 + [C.POINTER(TgsLossSpec), _P, _P, _P]),
     "tgs_reduce_partials": (C.c_int, [_I, _P, _P, C.POINTER(TgsCamera), _P, _P, _P]),
     "tgs_project_bwd": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I] + [_P] * 11),
     "tgs_project_bwd_adam": (C.c_int, [C.POINTER(TgsCamera), _I, _I, _I, _P, _P, _P, C.POINTER(TgsAdamSpec), _P, _P, _P, _P, _P]),

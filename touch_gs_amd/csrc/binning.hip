@@ -53,11 +53,47 @@ __global__ __launch_bounds__(TGS_GROUP) void k_tile_count(
 // Thread t owns the contiguous chunk [t*C, (t+1)*C), C = ceil(T/1024): one serial pass over its
 // chunk, one workgroup scan of the 1024 chunk totals, one pass to write -- two barriers in all.
 // On capacity overflow every list is made empty so that downstream kernels touch nothing.
+//
+// Blocks 1..8 (launched only when a tile_order buffer is given) build the visiting order of the
+// compositing kernels: block b of K6/K7 runs on XCD b % 8 and owns tile tile_order[b]; every XCD keeps
+// its contiguous band of tiles (so the splat records neighbouring tiles share stay in its L2) but
+// visits it longest list first.  With ~2 tiles per resident wave slot the spatial order leaves the
+// last slots running alone for a whole tile; longest-first shortens that tail (K6 -3 %, K7 -4 %,
+// alternating same-box runs after clock warm-up).
 __global__ __launch_bounds__(1024) void k_scan_tiles(int T, const int32_t* __restrict__ tile_count,
                                                      int32_t* __restrict__ tile_start,
-                                                     const int32_t* __restrict__ status) {
+                                                     const int32_t* __restrict__ status,
+                                                     int32_t* __restrict__ tile_order) {
   __shared__ int wave_tot[16];
+  __shared__ unsigned long long okeys[8192];   // one XCD band: <= ceil(255*255/8) = 8129 tiles
   const int tid = threadIdx.x;
+  if (blockIdx.x > 0) {
+    const int x = blockIdx.x - 1;
+    const int per = (T + 7) >> 3;
+    const int t0 = x * per, len = max(0, min(per, T - t0));
+    int np2 = 2;
+    while (np2 < per) np2 <<= 1;
+    // ascending on (~n, tile) = descending list length, ties by tile id; pads sort to the end
+    for (int i = tid; i < np2; i += 1024)
+      okeys[i] = i < len ? ((unsigned long long)(~(unsigned)tile_count[t0 + i]) << 32) | (unsigned)(t0 + i)
+                         : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < (np2 >> 1); i += 1024) {
+          const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+          const int hi = lo | j;
+          const bool up = (lo & k) == 0;
+          const unsigned long long a = okeys[lo], b = okeys[hi];
+          if ((a > b) == up) { okeys[lo] = b; okeys[hi] = a; }
+        }
+        __syncthreads();
+      }
+    }
+    for (int i = tid; i < per; i += 1024)
+      tile_order[i * 8 + x] = i < len ? (int)(okeys[i] & 0xffffffffull) : T;   // T = no tile
+    return;
+  }
   const bool overflow = status[1] != 0;
   const int C = (T + 1023) / 1024;
   const int lo = min(tid * C, T), hi = min(lo + C, T);
@@ -195,6 +231,7 @@ extern "C" int tgs_num_groups(int N) { return (N + TGS_GROUP - 1) / TGS_GROUP; }
 extern "C" int tgs_num_tiles(int W, int H) {
   return ((W + TGS_BLOCK - 1) / TGS_BLOCK) * ((H + TGS_BLOCK - 1) / TGS_BLOCK);
 }
+extern "C" int tgs_tile_order_len(int W, int H) { return ((tgs_num_tiles(W, H) + 7) / 8) * 8; }
 // scratch layout: pairs u64[cap] | fallback u64[2*cap] | rank i32[cap]
 extern "C" size_t tgs_sort_scratch_bytes(int64_t capacity) {
   if (capacity < 0) capacity = 0;
@@ -202,12 +239,14 @@ extern "C" size_t tgs_sort_scratch_bytes(int64_t capacity) {
 }
 
 int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* group_base,
-                   int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid, int64_t capacity,
-                   void* scratch, int32_t* status, hipStream_t s) {
+                   int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
+                   int32_t* tile_order, int64_t capacity, void* scratch, int32_t* status,
+                   hipStream_t s) {
   const int T = k.TW * k.TH;
   const int G = tgs_num_groups(N);
   const BinScratch sc = carve_scratch(scratch, capacity);
-  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, T, tile_cursor, tile_start, status);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(tile_order ? 9 : 1), dim3(1024), 0, s, T, tile_cursor, tile_start,
+                     status, tile_order);
   TGS_CHECK_LAUNCH();
   if (G > 0) {
     hipLaunchKernelGGL(k_fill_bins, dim3(G), dim3(TGS_GROUP), 0, s, k, N, splats, group_base,
@@ -226,7 +265,8 @@ int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* gro
 
 extern "C" int tgs_bin_sort(const TgsCamera* cam, int N, float* splats, int32_t* group_base,
                             int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
-                            int64_t capacity, void* scratch, int32_t* status, void* stream) {
+                            int32_t* tile_order, int64_t capacity, void* scratch, int32_t* status,
+                            void* stream) {
   TGS_CHECK_ARG(camera_ok(cam), "bad camera");
   TGS_CHECK_ARG(N >= 0 && capacity >= 0, "negative size");
   TGS_CHECK_ARG(capacity < (1ll << 31), "capacity must be < 2^31");
@@ -251,6 +291,6 @@ extern "C" int tgs_bin_sort(const TgsCamera* cam, int N, float* splats, int32_t*
                        tile_cursor, sc.rank, status, (long long)capacity);
     TGS_CHECK_LAUNCH();
   }
-  return tgs_bin_finish(k, N, splats, group_base, tile_start, tile_cursor, sorted_gid, capacity,
-                        scratch, status, s);
+  return tgs_bin_finish(k, N, splats, group_base, tile_start, tile_cursor, sorted_gid, tile_order,
+                        capacity, scratch, status, s);
 }

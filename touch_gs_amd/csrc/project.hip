@@ -925,7 +925,8 @@ extern "C" int tgs_project_bin_sort(const TgsCamera* cam, int N, const float* me
                                     const float* opac_logit, const float* sh, int sh_stride,
                                     int sh_deg, float* splats, int32_t* radii, int32_t* group_base,
                                     int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
-                                    int64_t capacity, void* scratch, int32_t* status, void* stream) {
+                                    int32_t* tile_order, int64_t capacity, void* scratch,
+                                    int32_t* status, void* stream) {
   TGS_CHECK_ARG(camera_ok(cam), "bad camera");
   TGS_CHECK_ARG(N >= 0 && capacity >= 0 && capacity < (1ll << 31), "bad size");
   TGS_CHECK_ARG(cam->W <= 4080 && cam->H <= 4080, "image side > 4080 px (255 tiles)");
@@ -962,8 +963,8 @@ extern "C" int tgs_project_bin_sort(const TgsCamera* cam, int N, const float* me
 #undef LAUNCH
     TGS_CHECK_LAUNCH();
   }
-  return tgs_bin_finish(k, N, splats, group_base, tile_start, tile_cursor, sorted_gid, capacity,
-                        scratch, status, s);
+  return tgs_bin_finish(k, N, splats, group_base, tile_start, tile_cursor, sorted_gid, tile_order,
+                        capacity, scratch, status, s);
 }
 
 extern "C" int tgs_sh_fwd(int N, int sh_deg, int sh_stride, const float* dirs, const float* coeffs,

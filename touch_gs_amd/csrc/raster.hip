@@ -158,8 +158,9 @@ template <bool WANT_IDX>
 __global__ __launch_bounds__(64) void k_raster_fwd(
     CamK cam, int T_total, const float* __restrict__ splats, const int32_t* __restrict__ sorted_gid,
     const int32_t* __restrict__ tile_start, float* __restrict__ out_rgb,
-    float* __restrict__ out_depth, float* __restrict__ final_T, int32_t* __restrict__ final_idx) {
-  const int tile = xcd_tile(blockIdx.x, T_total);
+    float* __restrict__ out_depth, float* __restrict__ final_T, int32_t* __restrict__ final_idx,
+    const int32_t* __restrict__ tile_order) {
+  const int tile = tile_order ? tile_order[blockIdx.x] : xcd_tile(blockIdx.x, T_total);
   if (tile >= T_total) return;
   const int lane = threadIdx.x;
   const int ty = tile / cam.TW, tx = tile - ty * cam.TW;
@@ -259,8 +260,9 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
     const float* __restrict__ out_rgb, const float* __restrict__ out_depth,
     const float* __restrict__ final_T, const float* __restrict__ v_rgb,
     const float* __restrict__ v_depth, const float* __restrict__ v_alpha, LossK loss,
-    float* __restrict__ partials, float* __restrict__ tile_loss) {
-  const int tile = xcd_tile(blockIdx.x, T_total);
+    float* __restrict__ partials, float* __restrict__ tile_loss,
+    const int32_t* __restrict__ tile_order) {
+  const int tile = tile_order ? tile_order[blockIdx.x] : xcd_tile(blockIdx.x, T_total);
   if (tile >= T_total) return;
   const int lane = threadIdx.x;
   const int ty = tile / cam.TW, tx = tile - ty * cam.TW;
@@ -459,8 +461,8 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
 
 extern "C" int tgs_rasterize_fwd(const TgsCamera* cam, const float* splats,
                                  const int32_t* sorted_gid, const int32_t* tile_start,
-                                 float* out_rgb, float* out_depth, float* final_T,
-                                 int32_t* final_idx, void* stream) {
+                                 const int32_t* tile_order, float* out_rgb, float* out_depth,
+                                 float* final_T, int32_t* final_idx, void* stream) {
   TGS_CHECK_ARG(camera_ok(cam), "bad camera");
   TGS_CHECK_ARG(splats && sorted_gid && tile_start && out_rgb && out_depth && final_T,
                 "null pointer");
@@ -469,19 +471,19 @@ extern "C" int tgs_rasterize_fwd(const TgsCamera* cam, const float* splats,
   const int grid = ((T + 7) / 8) * 8;
   if (final_idx)
     hipLaunchKernelGGL(k_raster_fwd<true>, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T,
-                       splats, sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx);
+                       splats, sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx, tile_order);
   else
     hipLaunchKernelGGL(k_raster_fwd<false>, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T,
-                       splats, sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx);
+                       splats, sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx, tile_order);
   TGS_CHECK_LAUNCH();
   return TGS_OK;
 }
 
 extern "C" int tgs_rasterize_bwd(const TgsCamera* cam, const float* splats,
                                  const int32_t* group_base, const int32_t* sorted_gid,
-                                 const int32_t* tile_start, const float* out_rgb,
-                                 const float* out_depth, const float* final_T,
-                                 const float* v_rgb,
+                                 const int32_t* tile_start, const int32_t* tile_order,
+                                 const float* out_rgb, const float* out_depth,
+                                 const float* final_T, const float* v_rgb,
                                  const float* v_depth, const float* v_alpha,
                                  const TgsLossSpec* loss, float* partials, float* tile_loss,
                                  void* stream) {
@@ -504,7 +506,7 @@ extern "C" int tgs_rasterize_bwd(const TgsCamera* cam, const float* splats,
   const int grid = ((T + 7) / 8) * 8;
   hipLaunchKernelGGL(k_raster_bwd, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T, splats,
                      group_base, sorted_gid, tile_start, out_rgb, out_depth, final_T,
-                     v_rgb, v_depth, v_alpha, lk, partials, tile_loss);
+                     v_rgb, v_depth, v_alpha, lk, partials, tile_loss, tile_order);
   TGS_CHECK_LAUNCH();
   return TGS_OK;
 }

@@ -103,13 +103,17 @@ def bin_sort(cam: Camera, splats, budget: Optional[IntersectBudget] = None):
     tile_start = torch.empty(T + 1, dtype=torch.int32, device=dev)
     counters = torch.empty((T + 2 + 3) & ~3, dtype=torch.int32, device=dev)   # tile counters | status | pad: one fill
     tile_cursor, status = counters[:T], counters[T:T + 2]
+    # block -> tile schedule of K6 / K7 (longest list first inside each XCD's band); it rides on the
+    # tile_start tensor object so that the (tile_start, sorted_gid) pair keeps its meaning for callers
+    tile_order = torch.empty((T + 7) // 8 * 8, dtype=torch.int32, device=dev)
+    tile_start.tile_order = tile_order
     cap = budget.initial(N)
     while True:
         sorted_gid = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
         scratch = torch.empty(lib.tgs_sort_scratch_bytes(cap), dtype=torch.uint8, device=dev)
         check(lib.tgs_bin_sort(C.byref(cs), N, ptr(splats), ptr(group_base), ptr(tile_start),
-                               ptr(tile_cursor), ptr(sorted_gid), cap, ptr(scratch), ptr(status),
-                               _stream()), "tgs_bin_sort")
+                               ptr(tile_cursor), ptr(sorted_gid), ptr(tile_order), cap, ptr(scratch),
+                               ptr(status), _stream()), "tgs_bin_sort")
         budget.last_status = status
         if not budget.sync:
             break
@@ -139,6 +143,10 @@ def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_d
     tile_start = torch.empty(T + 1, dtype=torch.int32, device=dev)
     counters = torch.empty((T + 2 + 3) & ~3, dtype=torch.int32, device=dev)   # tile counters | status | pad: one fill
     tile_cursor, status = counters[:T], counters[T:T + 2]
+    # block -> tile schedule of K6 / K7 (longest list first inside each XCD's band); it rides on the
+    # tile_start tensor object so that the (tile_start, sorted_gid) pair keeps its meaning for callers
+    tile_order = torch.empty((T + 7) // 8 * 8, dtype=torch.int32, device=dev)
+    tile_start.tile_order = tile_order
     sh_stride = sh.shape[1] if sh is not None else 0
     cap = budget.initial(N)
     while True:
@@ -147,7 +155,8 @@ def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_d
         check(lib.tgs_project_bin_sort(C.byref(cs), N, ptr(means), ptr(log_scales), ptr(quats), ptr(opac_logit),
                                        ptr(sh), sh_stride, sh_deg if sh is not None else -1, ptr(splats),
                                        ptr(radii), ptr(group_base), ptr(tile_start), ptr(tile_cursor),
-                                       ptr(sorted_gid), cap, ptr(scratch), ptr(status), _stream()),
+                                       ptr(sorted_gid), ptr(tile_order), cap, ptr(scratch), ptr(status),
+                                       _stream()),
               "tgs_project_bin_sort")
         budget.last_status = status
         if not budget.sync:
@@ -171,7 +180,8 @@ def rasterize_fwd(cam: Camera, splats, sorted_gid, tile_start, want_idx: bool = 
     fT = torch.empty(H, W, dtype=torch.float32, device=dev)
     fidx = torch.empty(H, W, dtype=torch.int32, device=dev) if want_idx else None
     cs = cam.c_struct()
-    check(lib.tgs_rasterize_fwd(C.byref(cs), ptr(splats), ptr(sorted_gid), ptr(tile_start), ptr(rgb),
+    check(lib.tgs_rasterize_fwd(C.byref(cs), ptr(splats), ptr(sorted_gid), ptr(tile_start),
+                                ptr(getattr(tile_start, "tile_order", None)), ptr(rgb),
                                 ptr(depth), ptr(fT), ptr(fidx), _stream()), "tgs_rasterize_fwd")
     return rgb, depth, fT, fidx
 
@@ -202,7 +212,8 @@ def rasterize_bwd(cam: Camera, splats, group_base, sorted_gid, tile_start, rgb, 
         ls.eps = float(loss.get("eps", 1e-6))
     v_rgb, v_depth, v_alpha = _f32c(v_rgb), _f32c(v_depth), _f32c(v_alpha)
     check(lib.tgs_rasterize_bwd(C.byref(cs), ptr(splats), ptr(group_base), ptr(sorted_gid),
-                                ptr(tile_start), ptr(rgb), ptr(depth), ptr(fT),
+                                ptr(tile_start), ptr(getattr(tile_start, "tile_order", None)),
+                                ptr(rgb), ptr(depth), ptr(fT),
                                 ptr(v_rgb), ptr(v_depth), ptr(v_alpha),
                                 C.byref(ls) if ls is not None else None, ptr(partials),
                                 ptr(tile_loss), _stream()), "tgs_rasterize_bwd")
