@@ -74,6 +74,9 @@ typedef struct TgsAdamSpec {
   float lr_means, lr_scales, lr_quats, lr_opac, lr_sh_dc, lr_sh_rest;
   float beta1, beta2, eps;
   float bias_corr1, bias_corr2;   /* 1-beta1^t, 1-beta2^t */
+  const float* device_bias_corr;  /* NULL, or device {bias_corr1, bias_corr2} read by the kernel at
+                                     run time instead of the two host fields: lets a captured
+                                     hipGraph of the step be replayed with each step's values */
 } TgsAdamSpec;
 
 int tgs_version(void);
@@ -120,8 +123,7 @@ int tgs_sh_bwd(int N, int sh_deg, int sh_stride, const float* dirs, const float*
  *                       but visits it longest list first; entries == T mean "no tile"
  *      status[2]        {#intersections, overflow flag}; if #intersections > capacity nothing
  *                       past the scans is written, overflow=1 (caller grows and retries)
- * tmp: tile_cursor[T], scratch (tgs_sort_scratch_bytes(capacity)).  If status == tile_cursor + T (one
- *      allocation of T+2 ints rounded up to a multiple of 4) both are cleared by a single fill. */
+ * tmp: tile_cursor[T], scratch (tgs_sort_scratch_bytes(capacity)). */
 int tgs_bin_sort(const TgsCamera* cam /*[host]*/, int N, float* splats, int32_t* group_base,
                  int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
                  int32_t* tile_order, int64_t capacity, void* scratch, int32_t* status,
@@ -218,6 +220,11 @@ int tgs_project_bwd_color(const TgsCamera* cam /*[host]*/, int N, const float* m
 int tgs_adam_step_sh_gathered(int world, int N, int sh_stride, int sh_deg, float* params,
                               const float* v_color_all, float* exp_avg, float* exp_avg_sq,
                               const TgsAdamSpec* spec /*[host]*/, float grad_scale, void* stream);
+
+/* Stores n <= 8 host floats into device memory; the values travel as launch arguments, so the call is
+ * stream ordered without any host staging buffer.  Used to refresh TgsAdamSpec.device_bias_corr
+ * before a captured step graph is replayed. */
+int tgs_store_small(float* dst, const float* host_vals /*[host]*/, int n, void* stream);
 
 /* K9  fused Adam over the flat parameter buffer (torch.optim.Adam semantics, no weight decay).
  *     Updates elements [elem_begin, elem_end) of the flat buffers (multiples of 4; pass 0, -1 for

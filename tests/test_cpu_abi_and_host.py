@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     from touch_gs_amd import _lib
     assert C.sizeof(_lib.TgsCamera) == 16 * 4 + 4 * 4 + 2 * 4 + 2 * 4 + 3 * 4 + 4
-    assert C.sizeof(_lib.TgsAdamSpec) == 11 * 4
+    assert C.sizeof(_lib.TgsAdamSpec) == 11 * 4 + 4 + 8   # 11 floats, pad, device pointer
     assert C.sizeof(_lib.TgsLossSpec) == 3 * 8 + 4 * 4
 
 

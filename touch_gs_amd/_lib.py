@@ -30,7 +30,7 @@ class TgsAdamSpec(C.Structure):
     _fields_ = [("lr_means", C.c_float), ("lr_scales", C.c_float), ("lr_quats", C.c_float),
                 ("lr_opac", C.c_float), ("lr_sh_dc", C.c_float), ("lr_sh_rest", C.c_float),
                 ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("bias_corr1", C.c_float), ("bias_corr2", C.c_float)]
+                ("bias_corr1", C.c_float), ("bias_corr2", C.c_float), ("device_bias_corr", C.c_void_p)]
 
 
 _P = C.c_void_p
@@ -56,6 +56,7 @@ SIGNATURES = {
     "tgs_project_bwd_adam": (C.c_int, [C.POINTER(TgsCamera), _I, _I, _I, _P, _P, _P, C.POINTER(TgsAdamSpec), _P, _P, _P, _P, _P]),
     "tgs_project_bwd_color": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I] + [_P] * 10),
     "tgs_adam_step_sh_gathered": (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _P, C.POINTER(TgsAdamSpec), C.c_float, _P]),
+    "tgs_store_small": (C.c_int, [_P, C.POINTER(C.c_float), _I, _P]),
     "tgs_adam_step": (C.c_int, [_I, _I, _P, _P, _P, _P, C.POINTER(TgsAdamSpec), C.c_float, C.c_int64, C.c_int64, _P]),
     "tgs_ssim_fwd_bwd": (C.c_int, [_I, _I, _P, _P, C.c_float, _P, _P, _P, _P]),
 }

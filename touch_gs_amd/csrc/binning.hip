@@ -278,14 +278,8 @@ extern "C" int tgs_bin_sort(const TgsCamera* cam, int N, float* splats, int32_t*
   const int G = tgs_num_groups(N);
   hipStream_t s = (hipStream_t)stream;
   const BinScratch sc = carve_scratch(scratch, capacity);
-  if (status == tile_cursor + T) {
-    // the caller placed status right behind the counters (and, by contract, padded that allocation
-    // to a multiple of 4 ints): one 16-byte-granular fill instead of two fills plus a tail
-    TGS_HIP(hipMemsetAsync(tile_cursor, 0, sizeof(int32_t) * (((size_t)T + 2 + 3) & ~(size_t)3), s));
-  } else {
-    TGS_HIP(hipMemsetAsync(tile_cursor, 0, sizeof(int32_t) * (size_t)T, s));
-    TGS_HIP(hipMemsetAsync(status, 0, sizeof(int32_t) * 2, s));
-  }
+  hipLaunchKernelGGL(k_clear_counters, dim3((max(T, 2) + 255) / 256), dim3(256), 0, s, tile_cursor, T, status);
+  TGS_CHECK_LAUNCH();
   if (G > 0) {
     hipLaunchKernelGGL(k_tile_count, dim3(G), dim3(TGS_GROUP), 0, s, k, N, splats, group_base,
                        tile_cursor, sc.rank, status, (long long)capacity);

@@ -14,7 +14,12 @@ declare -A EXTRA=([raster]="-fno-slp-vectorize")
 pids=()
 for s in $SRCS; do
   [ -f "$HERE/$s.hip" ] || continue
-  if [ ! -f "$OUT/$s.o" ] || [ "$HERE/$s.hip" -nt "$OUT/$s.o" ] || [ "$HERE/tgs_common.h" -nt "$OUT/$s.o" ] || [ "$HERE/../../include/tgs.h" -nt "$OUT/$s.o" ] || [ "$0" -nt "$OUT/$s.o" ]; then
+  stale=0
+  [ -f "$OUT/$s.o" ] || stale=1
+  for dep in "$HERE/$s.hip" "$HERE"/*.h "$HERE/../../include/tgs.h" "$0"; do
+    [ "$dep" -nt "$OUT/$s.o" ] && stale=1
+  done
+  if [ $stale = 1 ]; then
     $HIPCC $FLAGS ${EXTRA[$s]} -c "$HERE/$s.hip" -o "$OUT/$s.o" &
     pids+=($!)
   fi

@@ -15,9 +15,10 @@ namespace {
 // a float4 never straddles two parameter groups; inside the SH block the DC/rest split needs the
 // element's position in its 3K-float row, which is tracked incrementally (one 64-bit modulo per
 // thread when it first enters the block, none in the steady state).
-__global__ __launch_bounds__(256) void k_adam(AdamK a, float* __restrict__ p,
+__global__ __launch_bounds__(256) void k_adam(AdamK a_in, float* __restrict__ p,
                                               const float* __restrict__ g, float* __restrict__ m,
                                               float* __restrict__ v) {
+  const AdamK a = adam_resolve(a_in);
   const long long n4 = a.e_end >> 2;
   const long long stride = (long long)gridDim.x * blockDim.x;
   unsigned r = 0;
@@ -47,7 +48,23 @@ __global__ __launch_bounds__(256) void k_adam(AdamK a, float* __restrict__ p,
   }
 }
 
+struct Small8 { float v[8]; };
+__global__ void k_store_small(float* __restrict__ dst, Small8 vals, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = vals.v[threadIdx.x];
+}
+
 }  // namespace
+
+// Up to 8 floats travel as launch arguments (no host buffer that could be overwritten before an
+// asynchronous copy runs): how the per-step Adam bias corrections reach TgsAdamSpec.device_bias_corr.
+extern "C" int tgs_store_small(float* dst, const float* host_vals, int n, void* stream) {
+  TGS_CHECK_ARG(dst && host_vals && n >= 1 && n <= 8, "need 1..8 values");
+  Small8 v{};
+  for (int i = 0; i < n; i++) v.v[i] = host_vals[i];
+  hipLaunchKernelGGL(k_store_small, dim3(1), dim3(64), 0, (hipStream_t)stream, dst, v, n);
+  TGS_CHECK_LAUNCH();
+  return TGS_OK;
+}
 
 extern "C" int tgs_adam_step(int N, int sh_stride, float* params, const float* grads,
                              float* exp_avg, float* exp_avg_sq, const TgsAdamSpec* spec,

@@ -492,7 +492,8 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
     const float* __restrict__ partials, float* __restrict__ v_means,
     float* __restrict__ v_log_scales, float* __restrict__ v_quats,
     float* __restrict__ v_opac_logit, float* __restrict__ v_sh, float* __restrict__ v_xy,
-    AdamK ad, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq) {
+    AdamK ad_in, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq) {
+  const AdamK ad = FUSE_ADAM ? adam_resolve(ad_in) : ad_in;
   constexpr int K = (DEG + 1) * (DEG + 1);   // requires sh_stride == K here (3K % 4 == 0)
   constexpr int ROW = 3 * K, RS = ROW + 4, F4 = ROW / 4;
   extern __shared__ float4 lds4[];
@@ -685,8 +686,9 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
 template <int DEG>
 __global__ __launch_bounds__(256) void k_adam_sh_gathered(
     int world, int N, int sh_stride, const float* __restrict__ means,
-    float* __restrict__ sh, const float* __restrict__ v_color_all, AdamK ad,
+    float* __restrict__ sh, const float* __restrict__ v_color_all, AdamK ad_in,
     float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq) {
+  const AdamK ad = adam_resolve(ad_in);
   constexpr int K = (DEG + 1) * (DEG + 1);
   const int ROW = 3 * sh_stride, RS = ROW + 4, F4 = ROW / 4;
   extern __shared__ float4 lds4[];
@@ -939,14 +941,8 @@ extern "C" int tgs_project_bin_sort(const TgsCamera* cam, int N, const float* me
   const int T = k.TW * k.TH;
   hipStream_t s = (hipStream_t)stream;
   const BinScratch sc = carve_scratch(scratch, capacity);
-  if (status == tile_cursor + T) {
-    // the caller placed status right behind the counters (and, by contract, padded that allocation
-    // to a multiple of 4 ints): one 16-byte-granular fill instead of two fills plus a tail
-    TGS_HIP(hipMemsetAsync(tile_cursor, 0, sizeof(int32_t) * (((size_t)T + 2 + 3) & ~(size_t)3), s));
-  } else {
-    TGS_HIP(hipMemsetAsync(tile_cursor, 0, sizeof(int32_t) * (size_t)T, s));
-    TGS_HIP(hipMemsetAsync(status, 0, sizeof(int32_t) * 2, s));
-  }
+  hipLaunchKernelGGL(k_clear_counters, dim3((max(T, 2) + 255) / 256), dim3(256), 0, s, tile_cursor, T, status);
+  TGS_CHECK_LAUNCH();
   if (N > 0) {
     const dim3 grid((N + 255) / 256), block(256);
 #define LAUNCH(D)                                                                                  \

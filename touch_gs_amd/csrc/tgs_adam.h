@@ -10,6 +10,7 @@ struct AdamK {
   unsigned row_step;                                      // (4 * grid stride) mod sh_row
   float lr_means, lr_scales, lr_quats, lr_opac, lr_dc, lr_rest;
   float b1, b2, eps, ibc1, isq_bc2, gscale;
+  const float* dyn;   // device {bias_corr1, bias_corr2} of the current step, or NULL
 };
 
 static inline long long tgs_al4(long long x) { return (x + 3) & ~3ll; }
@@ -31,10 +32,21 @@ static inline AdamK make_adamk(int N, int sh_stride, const TgsAdamSpec* spec, fl
   a.ibc1 = 1.0f / spec->bias_corr1;
   a.isq_bc2 = 1.0f / sqrtf(spec->bias_corr2);
   a.gscale = grad_scale;
+  a.dyn = spec->device_bias_corr;
   return a;
 }
 
 #ifdef __HIPCC__
+// Bias corrections kept in device memory (a captured hipGraph of the step is replayed with the
+// current step's values): same IEEE division / square root as make_adamk does on the host.
+__device__ __forceinline__ AdamK adam_resolve(AdamK a) {
+  if (a.dyn) {
+    a.ibc1 = 1.0f / a.dyn[0];
+    a.isq_bc2 = 1.0f / sqrtf(a.dyn[1]);
+  }
+  return a;
+}
+
 __device__ __forceinline__ void adam1(const AdamK& a, float lr, float& p, float g, float& m, float& v) {
   g *= a.gscale;
   m = a.b1 * m + (1.f - a.b1) * g;

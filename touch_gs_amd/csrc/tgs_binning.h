@@ -59,6 +59,17 @@ __device__ __forceinline__ int group_scan_store(GroupScan& S, int hits, int x0, 
   return total;
 }
 
+// Clears the per-tile counters and the status word.  A kernel rather than hipMemsetAsync: the call
+// then is an ordinary node when the step is captured into a hipGraph (a memset root node was seen to
+// start before the previous graph launch on the same stream had drained), and it is a little
+// cheaper than the runtime's fill.
+static __global__ __launch_bounds__(256) void k_clear_counters(int32_t* __restrict__ tile_cursor, int T,
+                                                        int32_t* __restrict__ status) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < T) tile_cursor[i] = 0;
+  if (i < 2) status[i] = 0;
+}
+
 // pair i of the group -> (local Gaussian j, tile id)
 __device__ __forceinline__ void group_pair(const GroupScan& S, int TW, int i, int& j, int& tile) {
   int lo = 0, hi = TGS_GROUP;

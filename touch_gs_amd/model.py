@@ -179,7 +179,7 @@ class DepthGaussianSplattingModel:
         return spec
 
     def forward_backward(self, view: View, want_v_xy: bool = False, fuse_adam: bool = False,
-                         color_block: Optional[torch.Tensor] = None):
+                         color_block: Optional[torch.Tensor] = None, begin_step: bool = True):
         """Forward + loss + backward of one view into ``params.grad`` (overwritten) -- or, with
         ``fuse_adam``, straight through the optimizer update (K8+K9 fused, ``params.grad`` untouched).
         No host sync unless ``budget.sync``.  Returns device tensors (l1+depth tile losses, ssim sum)."""
@@ -196,7 +196,8 @@ class DepthGaussianSplattingModel:
                                                 depth_acc, fT, v_rgb=v_img,
                                                 loss=self.loss_spec(view), want_tile_loss=True)
         if fuse_adam:
-            v_xy = self.optimizer.backward_and_step(cam, deg, splats, group_base, partials, want_v_xy)
+            v_xy = self.optimizer.backward_and_step(cam, deg, splats, group_base, partials, want_v_xy,
+                                                    begin=begin_step)
         elif color_block is not None:   # data-parallel: geometry gradients + colour-gradient block
             v_xy = ops.project_bwd_color(cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, splats,
                                          group_base, partials, p.grad_views()[:4], color_block, want_v_xy)
@@ -221,11 +222,60 @@ class DepthGaussianSplattingModel:
         from .densify import DensifyConfig, DensityController
         self.density = DensityController(cfg or DensifyConfig(), self.params.N, self.params.flat.device)
 
+    # -- hipGraph replay of the step (small scenes are launch bound) ----------------------------
+    def capture_step_graphs(self, views, headroom: float = 1.3, share_pool: bool = True) -> None:
+        """Capture the fused single-process train step of every view into a hipGraph (via
+        torch.cuda.CUDAGraph: memset + K1..K8/K9 nodes, one graph per view because the camera and
+        the ground-truth pointers are launch arguments; all graphs share one memory pool).
+        ``train_step`` then replays the view's graph: one launch per step instead of ~12, no Python
+        between the kernels.  The only per-step scalars, Adam's bias corrections, live in device
+        memory (TgsAdamSpec.device_bias_corr).  The intersection buffers are sized once from the
+        views (x ``headroom``) and the overflow flag is checked lazily (``budget.check``).
+        Graphs are dropped when the active SH degree or the number of Gaussians changes."""
+        opt, deg = self.optimizer, self.active_sh_degree()
+        if not opt.can_fuse_with_backward(deg):
+            raise RuntimeError("step graphs need the fused K8+K9 path (dense SH at its full degree 1 or 3)")
+        p = self.params
+        need = 0
+        for v in views:
+            v.valid_count()
+            b = ops.IntersectBudget()
+            ops.project_bin_sort(v.cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, b)
+            need = max(need, b.last_n)
+        self.budget = ops.IntersectBudget(capacity=int(need * headroom) + 4096, sync=False)
+        opt.use_device_bias_corr = True
+        opt.upload_bias_corr()
+        torch.cuda.synchronize()
+        self._graphs, pool = {}, None
+        for v in views:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                self.forward_backward(v, fuse_adam=True, begin_step=False)
+            pool = (pool or g.pool()) if share_pool else None
+            self._graphs[id(v)] = (g, self.last, deg, p.N)
+        opt.use_device_bias_corr = False   # only the captured launches read the device scalars
+
+    def drop_step_graphs(self) -> None:
+        self._graphs = {}
+        self.optimizer.use_device_bias_corr = False
+
     def train_step(self, view: View, dp=None) -> None:
         """One optimizer iteration on one view (per rank).  ``dp``: a parallel.GradSync or None."""
         distributed = dp is not None and dp.world > 1
         opt = self.optimizer
         deg = self.active_sh_degree()
+        graphs = getattr(self, "_graphs", None)
+        if graphs and not distributed and getattr(self, "density", None) is None:
+            entry = graphs.get(id(view))
+            if entry is not None and entry[2] == deg and entry[3] == self.params.N:
+                opt.begin_step()
+                opt.upload_bias_corr()
+                entry[0].replay()
+                self.last = entry[1]
+                self.step += 1
+                return
+            if entry is not None:
+                self.drop_step_graphs()
         fuse = (not distributed) and self.fuse_adam and opt.can_fuse_with_backward(deg)
         factored = distributed and self.dp_factored_sh and opt.can_gather_sh()
         density = getattr(self, "density", None)

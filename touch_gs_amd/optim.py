@@ -88,6 +88,10 @@ class FusedAdam:
         self.exp_avg = torch.zeros_like(params.flat)
         self.exp_avg_sq = torch.zeros_like(params.flat)
         self.t = 0
+        # device copy of the step's bias corrections: read by the launches recorded while
+        # ``use_device_bias_corr`` is set (a captured step graph), refreshed before every replay
+        self._dyn = None
+        self.use_device_bias_corr = False
 
     def _spec(self):
         s = _lib.TgsAdamSpec()
@@ -96,7 +100,17 @@ class FusedAdam:
         s.beta1, s.beta2, s.eps = self.betas[0], self.betas[1], self.eps
         s.bias_corr1 = 1.0 - self.betas[0] ** self.t
         s.bias_corr2 = 1.0 - self.betas[1] ** self.t
+        s.device_bias_corr = self._dyn.data_ptr() if (self.use_device_bias_corr and self._dyn is not None) else None
         return s
+
+    def upload_bias_corr(self):
+        """Write the current step's {1-beta1^t, 1-beta2^t} to the device scalars (stream ordered,
+        no host sync): called once per step before a captured step graph is replayed."""
+        if self._dyn is None:
+            self._dyn = torch.ones(2, dtype=torch.float32, device=self.p.flat.device)
+        vals = (C.c_float * 2)(1.0 - self.betas[0] ** self.t, 1.0 - self.betas[1] ** self.t)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(_lib.load().tgs_store_small(ptr(self._dyn), vals, 2, stream), "tgs_store_small")
 
     def begin_step(self):
         """Advance the step counter once per optimizer iteration (before step_range calls)."""
@@ -119,10 +133,12 @@ class FusedAdam:
         """tgs_project_bwd_adam needs the SH tensor evaluated at its full (dense) degree 1 or 3."""
         return sh_deg in (1, 3) and self.p.K == (sh_deg + 1) ** 2
 
-    def backward_and_step(self, cam, sh_deg: int, splats, group_base, partials, want_v_xy: bool = False):
+    def backward_and_step(self, cam, sh_deg: int, splats, group_base, partials, want_v_xy: bool = False,
+                          begin: bool = True):
         """K8 + K9 in one launch (single-process training): gradients never reach HBM."""
         lib = _lib.load()
-        self.begin_step()
+        if begin:
+            self.begin_step()
         s = self._spec()
         cs = cam.c_struct()
         v_xy = torch.empty(self.p.N, 2, dtype=torch.float32, device=self.p.flat.device) if want_v_xy else None
