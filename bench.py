@@ -204,7 +204,7 @@ def main():
         I = n_isect[0]
         ev = lambda: torch.cuda.Event(enable_timing=True)
         names = ["project_bin_sort", "raster_fwd", "ssim", "raster_bwd", "project_bwd", "adam"]
-        acc = {k: 0.0 for k in names}
+        acc = {k: [] for k in names}
         reps = min(args.steps, 20)
         p = params
         for _ in range(reps):
@@ -229,9 +229,10 @@ def main():
             e7b = ev(); e7b.record()
             torch.cuda.synchronize()
             for j, k in enumerate(names[:5]):
-                acc[k] += e[j].elapsed_time(e[j + 1])
-            acc["adam"] += e[6].elapsed_time(e7b)
-        kern_ms = {k: v / reps for k, v in acc.items()}
+                acc[k].append(e[j].elapsed_time(e[j + 1]))
+            acc["adam"].append(e[6].elapsed_time(e7b))
+        # median over the repetitions: a single disturbed launch must not move the roofline line
+        kern_ms = {k: sorted(v)[len(v) // 2] for k, v in acc.items()}
         # render-only throughput (K1..K6)
         torch.cuda.synchronize()
         r0 = time.perf_counter()
