@@ -453,3 +453,39 @@ def test_degenerate_sizes(dev):
         o, *_ = O.render(means.detach().cpu().double(), ls.detach().cpu().double(), q.detach().cpu().double(),
                          op.detach().cpu().double(), sh.detach().cpu().double(), ocam, 0)
         assert np.abs(rgb.detach().cpu().numpy() - o["rgb"].numpy()).max() < 1e-5
+
+
+@pytest.mark.parametrize("W,H", [(208, 144), (70, 50), (16, 16)])
+def test_tile_order_schedule(dev, W, H):
+    """tgs_bin_sort's tile_order: block b (XCD b % 8) gets a tile of band b % 8, every band is visited
+    longest list first (ties by tile id), every tile appears exactly once, padding entries are T; the
+    compositing kernels give bit-identical results with and without the schedule."""
+    from touch_gs_amd import ops
+    P, cam = scene(3000, W, H, 2, 23)
+    acam = amd_cam(cam)
+    D = to_dev(P, dev)
+    splats = ops.project_fwd(acam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], 2)
+    gb, ts, sg, st = ops.bin_sort(acam, splats)
+    T = acam.num_tiles
+    order = ts.tile_order.cpu().numpy()
+    n = np.diff(ts.cpu().numpy())
+    per = (T + 7) // 8
+    assert order.shape[0] == per * 8
+    assert sorted(order[order < T].tolist()) == list(range(T)) and int((order == T).sum()) == per * 8 - T
+    for x in range(8):
+        band = order[x::8]
+        band = band[band < T]
+        assert np.all((band >= x * per) & (band < (x + 1) * per))
+        keys = [(-int(n[t]), int(t)) for t in band]
+        assert keys == sorted(keys)
+    out_a = ops.rasterize_fwd(acam, splats, sg, ts)
+    bwd_a = ops.rasterize_bwd(acam, splats, gb, sg, ts, out_a[0], out_a[1], out_a[2],
+                              v_rgb=torch.ones_like(out_a[0]), v_depth=torch.ones_like(out_a[1]))[0]
+    n_pairs = int(ts[-1])
+    del ts.tile_order                      # wrappers now pass NULL: spatial order
+    out_b = ops.rasterize_fwd(acam, splats, sg, ts)
+    bwd_b = ops.rasterize_bwd(acam, splats, gb, sg, ts, out_b[0], out_b[1], out_b[2],
+                              v_rgb=torch.ones_like(out_b[0]), v_depth=torch.ones_like(out_b[1]))[0]
+    for a, b in zip(out_a[:3], out_b[:3]):
+        assert torch.equal(a, b)
+    assert torch.equal(bwd_a[:n_pairs], bwd_b[:n_pairs])
