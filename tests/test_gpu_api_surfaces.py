@@ -159,10 +159,18 @@ def test_training_reduces_loss_and_checkpoint_roundtrip(dev, tmp_path):
 def test_trainer_cli_synthetic(dev, tmp_path):
     from touch_gs_amd import train
     run = train.main(["--synthetic", "3000", "128", "80", "--max-num-iterations", "12", "--steps-per-eval", "6",
-                      "--steps-per-save", "12", "--sh-degree", "1", "--output-dir", str(tmp_path)])
+                      "--steps-per-save", "12", "--sh-degree", "1", "--output-dir", str(tmp_path),
+                      "--render-output", str(tmp_path / "renders")])
     import json, os
     ev = json.load(open(os.path.join(run, "eval.json")))
     assert {"psnr", "ssim", "depth_mse"} <= set(ev["results"]) and os.path.exists(os.path.join(run, "step-000000012.ckpt"))
+    # render dump (the ns-render counterpart): 8-bit rgb + 16-bit millimetre depth of the eval view
+    from PIL import Image
+    from touch_gs_amd.plumbing import read_png16
+    rgb = np.asarray(Image.open(tmp_path / "renders" / "rgb" / "00000.png"))
+    mm = read_png16(str(tmp_path / "renders" / "depth" / "00000.png"))
+    assert rgb.shape == (80, 128, 3) and rgb.dtype == np.uint8 and mm.shape == (80, 128) and mm.dtype == np.uint16
+    assert rgb.max() > 0 and mm.max() > 1000    # depths of the synthetic scene are metres -> thousands of mm
 
 
 _DP_WORKER = r'''

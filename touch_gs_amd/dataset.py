@@ -59,6 +59,7 @@ class Scene:
                                    depth=None if depth is None else depth.to(device).contiguous(),
                                    uncertainty=None if unc is None else unc.to(device).contiguous()))
         names = [fr["file_path"] for fr in frames]
+        self.names = names
         self.i_train, self.i_eval = get_train_eval_split_fraction(names, train_split_fraction)
         self._centre = np.stack([np.array(fr["transform_matrix"], dtype=np.float64)[:3, 3] for fr in frames]).mean(0) \
             if scale_poses else np.zeros(3)

@@ -70,6 +70,23 @@ def evaluate(model: DepthGaussianSplattingModel, views) -> dict:
     return {k: float(sum(x) / len(x)) for k, x in acc.items()}
 
 
+def render_views(model: DepthGaussianSplattingModel, views, out_dir: str, names=None) -> None:
+    """The build's counterpart of ``ns-render dataset`` (reference experiment_utils/run_eval.py:48):
+    ``<out_dir>/rgb/<name>.png`` (8-bit) and ``<out_dir>/depth/<name>.png`` (uint16 millimetres, the
+    convention of the dataset's own depth maps: utils/fuse_touch_vision.py:372-376)."""
+    from PIL import Image
+    from .plumbing import write_png16
+    os.makedirs(os.path.join(out_dir, "rgb"), exist_ok=True)
+    os.makedirs(os.path.join(out_dir, "depth"), exist_ok=True)
+    for i, v in enumerate(views):
+        out = model.get_outputs(v.cam, sh_degree=model.active_sh_degree())
+        name = os.path.splitext(os.path.basename(names[i]))[0] if names else f"{i:05d}"
+        rgb = (out["rgb"].clamp(0, 1) * 255.0 + 0.5).to(torch.uint8).cpu().numpy()
+        Image.fromarray(rgb).save(os.path.join(out_dir, "rgb", name + ".png"))
+        mm = (out["depth"].reshape(v.cam.H, v.cam.W) * 1000.0).clamp(0, 65535).round().to(torch.int32).cpu().numpy()
+        write_png16(os.path.join(out_dir, "depth", name + ".png"), mm.astype("uint16"))
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--data", type=str, default=None)
@@ -83,6 +100,8 @@ def main(argv=None):
     ap.add_argument("--steps-per-eval", type=int, default=500)
     ap.add_argument("--num-gaussians", type=int, default=100000)
     ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--render-output", type=str, default=None,
+                    help="also dump the eval views' renders (rgb/ + 16-bit mm depth/), like ns-render dataset")
     ap.add_argument("--output-dir", type=str, default="outputs")
     ap.add_argument("--load-checkpoint", type=str, default=None)
     ap.add_argument("--seed", type=int, default=0)
@@ -142,6 +161,9 @@ def main(argv=None):
             json.dump({"experiment_name": scene_name, "method_name": "depth-gaussian-splatting",
                        "checkpoint": run_dir, "results": results}, f, indent=2)
         print(json.dumps(results))
+        if args.render_output:
+            render_views(model, eval_views, args.render_output,
+                         None if args.synthetic is not None else [scene.names[i] for i in i_eval] if i_eval else None)
     dp.barrier()
     return run_dir
 
