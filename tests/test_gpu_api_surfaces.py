@@ -388,3 +388,53 @@ def test_step_graph_replay_equals_eager_steps(dev):
     other = make_view(N, W, H, deg, 7, dev, view=3, n_views=4)
     graphed.train_step(other); eager.train_step(other)
     assert torch.equal(graphed.params.flat, eager.params.flat)
+
+
+def test_trainer_on_disk_dataset_in_reference_format(dev, tmp_path):
+    """End to end on the on-disk contract the reference's plumbing produces:
+    transforms.json (fl_x.., per-frame OpenGL camera->world, depth_file_path, uncertainty_file_path),
+    8-bit RGB PNGs, 16-bit millimetre depth / uncertainty PNGs, touch seed points -> Scene loader ->
+    trainer -> eval.json + render dump."""
+    import json, os
+    from PIL import Image
+    from touch_gs_amd import plumbing, train
+    from touch_gs_amd.dataset import Scene
+    from touch_gs_amd.scene import make_view
+    N, W, H, deg = 3000, 96, 64, 1
+    root = tmp_path / "scene"
+    for d in ("images", "fused_output_dir", "fused_output_dir_uncertainty"):
+        os.makedirs(root / d)
+    frames, centres = [], []
+    for i in range(6):
+        v = make_view(N, W, H, deg, 11, dev, view=i, n_views=6)
+        Image.fromarray((v.rgb.clamp(0, 1) * 255).to(torch.uint8).cpu().numpy()).save(root / "images" / f"{i}.png")
+        plumbing.write_png16(str(root / "fused_output_dir" / f"{i}.png"), plumbing.to_uint16_mm(v.depth.cpu().numpy().astype(np.float64)))
+        plumbing.write_png16(str(root / "fused_output_dir_uncertainty" / f"{i}.png"),
+                             plumbing.to_uint16_mm(v.uncertainty.cpu().numpy().astype(np.float64)))
+        c2w = np.linalg.inv(np.asarray(v.cam.viewmat, dtype=np.float64)) @ np.diag([1.0, -1.0, -1.0, 1.0])
+        centres.append(c2w[:3, 3])
+        frames.append({"file_path": f"images/{i}.png", "transform_matrix": c2w.tolist()})
+    meta = {"fl_x": v.cam.fx, "fl_y": v.cam.fy, "cx": v.cam.cx, "cy": v.cam.cy, "w": W, "h": H, "frames": frames}
+    plumbing.add_depth_file_paths(meta, "fused_output_dir", "fused_output_dir_uncertainty")
+    (root / "transforms.json").write_text(json.dumps(meta))
+    rng = np.random.default_rng(0)
+    np.save(root / "points_touch.npy", rng.uniform(-0.5, 0.5, (200, 3)) + np.array([0, 0, 4.0]))
+    np.save(root / "points_colors.npy", rng.uniform(0, 255, (200, 3)))
+
+    sc = Scene(str(root), train_split_fraction=0.8, device=dev)
+    assert len(sc.views) == 6 and len(sc.i_train) == 5 and len(sc.i_eval) == 1
+    # poses are centred and scaled by 1 / max|t|, depths by the same factor (legacy/dataparser_tactile.py:222-235)
+    c = np.stack(centres); c = c - c.mean(0)
+    assert abs(sc.scale - 1.0 / np.abs(c).max()) < 1e-9
+    v0 = make_view(N, W, H, deg, 11, dev, view=0, n_views=6)
+    got, want = sc.views[0].depth, v0.depth * sc.scale
+    assert torch.allclose(got, want, atol=1e-3 * sc.scale + 1e-6)            # millimetre quantisation
+    assert sc.seed_points()[0].shape == (200, 3)
+
+    run = train.main(["--data", str(root), "--train-split-fraction", "0.8", "--max-num-iterations", "10",
+                      "--steps-per-eval", "5", "--steps-per-save", "10", "--sh-degree", "1", "--num-gaussians", "2000",
+                      "--depth-loss-mult", "0.005", "--uncertainty-weight", "0.01", "--output-dir", str(tmp_path / "out"),
+                      "--render-output", str(tmp_path / "renders")])
+    ev = json.load(open(os.path.join(run, "eval.json")))
+    assert {"psnr", "ssim", "depth_mse", "supervised_depth_mse"} <= set(ev["results"])
+    assert len(os.listdir(tmp_path / "renders" / "rgb")) == 1 and len(os.listdir(tmp_path / "renders" / "depth")) == 1
