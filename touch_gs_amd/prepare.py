@@ -1,0 +1,195 @@
+"""Directory-level data preparation: what ``scripts/train_<scene>.sh`` does before ``ns-train``
+(reference scripts/train_bunny_real.sh:16-48), step for step and with the reference's directory and
+flag names, on top of the array-level functions in :mod:`touch_gs_amd.plumbing`.
+
+    python -m touch_gs_amd.prepare read_touch_depths --base_repo_path SCENE
+    python -m touch_gs_amd.prepare fuse_touch_vision --root_dir SCENE --aligning_depths realsense_depths \\
+        --touch_depth touch_depth --zoe_depth_path zoe_depth --use_uncertainty --vision_output_dir vision \\
+        --fused_output_dir fused_output_dir --touch_var touch_var [--is_sim]
+    python -m touch_gs_amd.prepare add_depth_file_path_to_transforms --base_repo_path SCENE --filename transforms.json \\
+        --depth_file_path_template fused_output_dir --uncertainty_file_path_template fused_output_dir_uncertainty
+    python -m touch_gs_amd.prepare create_point_cloud_from_touches --root_dir SCENE --touch_depth_dir touch_depth \\
+        --touch_var_dir touch_var --image_dir imgs --transform_json_path transforms.json --train_split 0.08
+
+On-disk contract (all depth-like images are uint16 PNGs in millimetres):
+  imgs/<n>.png, gpis_depth/Image<n>.npy, gpis_var/Image<n>.npy  (utils/read_touch_depths.py:24-45)
+  touch_depth/<n>.png, touch_var/<n>.png                        (utils/read_touch_depths.py:55-56)
+  <vision_output_dir>/, <vision_output_dir>_baseline/, <fused_output_dir>/, <fused_output_dir>_uncertainty/
+                                                                (utils/fuse_touch_vision.py:229-234,372-386)
+  points_touch.npy, points_colors.npy                           (utils/create_point_cloud_from_touches.py:243-244)
+CPU / NumPy like the reference's own plumbing; monocular depth (ZoeDepth) and the RealSense
+conversion are inputs here (pretrained weights / sensor dumps are not part of the hot path).
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import json
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import plumbing as P
+
+
+def _read_m(path: str) -> np.ndarray:
+    """uint16-mm PNG -> metres (float64)."""
+    return P.from_uint16_mm(P.read_png16(path))
+
+
+def resize_bilinear(a: np.ndarray, height: int, width: int) -> np.ndarray:
+    """Bilinear resize with pixel centres at half-integers and edge clamping (the convention of the
+    reference's ``cv2.resize(..., interpolation=cv2.INTER_LINEAR)``, fuse_touch_vision.py:277)."""
+    a = np.asarray(a, dtype=np.float64)
+    h, w = a.shape
+    if (h, w) == (height, width):
+        return a.copy()
+    ys = np.clip((np.arange(height) + 0.5) * h / height - 0.5, 0, h - 1)
+    xs = np.clip((np.arange(width) + 0.5) * w / width - 0.5, 0, w - 1)
+    y0, x0 = np.floor(ys).astype(int), np.floor(xs).astype(int)
+    y1, x1 = np.minimum(y0 + 1, h - 1), np.minimum(x0 + 1, w - 1)
+    fy, fx = (ys - y0)[:, None], (xs - x0)[None, :]
+    top = a[y0][:, x0] * (1 - fx) + a[y0][:, x1] * fx
+    bot = a[y1][:, x0] * (1 - fx) + a[y1][:, x1] * fx
+    return top * (1 - fy) + bot * fy
+
+
+# ------------------------------------------------------------------------------------------------
+def read_touch_depths(base_repo_path: str) -> int:
+    """gpis_depth/Image<n>.npy + gpis_var/Image<n>.npy -> touch_depth/<n>.png + touch_var/<n>.png for
+    every imgs/<n>.png (reference utils/read_touch_depths.py:24-56).  Returns the number of images."""
+    out_d, out_v = os.path.join(base_repo_path, "touch_depth"), os.path.join(base_repo_path, "touch_var")
+    os.makedirs(out_d, exist_ok=True)
+    os.makedirs(out_v, exist_ok=True)
+    imgs = sorted(glob.glob(os.path.join(base_repo_path, "imgs", "*.png")))
+    for img in imgs:
+        n = os.path.basename(img)[:-4]
+        d_mm, v_mm = P.gpis_npy_to_mm(np.load(os.path.join(base_repo_path, "gpis_depth", f"Image{n}.npy")),
+                                      np.load(os.path.join(base_repo_path, "gpis_var", f"Image{n}.npy")))
+        P.write_png16(os.path.join(out_d, f"{n}.png"), d_mm)
+        P.write_png16(os.path.join(out_v, f"{n}.png"), v_mm)
+    return len(imgs)
+
+
+def fuse_touch_vision(root_dir: str, aligning_depths: str, touch_depth: str, zoe_depth_path: str,
+                      vision_output_dir: str, fused_output_dir: str, touch_var: str, use_uncertainty: bool = True,
+                      is_sim: bool = False, seed: Optional[int] = None) -> int:
+    """Per image: align the monocular depth to 1 % of the grounded (RealSense / simulator) depth and
+    to the touch depth, fuse it with the touch depth by inverse-variance weighting, and write the four
+    uint16-mm maps (reference utils/fuse_touch_vision.py:316-386).  ``seed`` makes the 1 % draw
+    reproducible (the reference's is unseeded).  Returns the number of images."""
+    j = lambda d: os.path.join(root_dir, d)
+    for d in (vision_output_dir, vision_output_dir + "_baseline", fused_output_dir, fused_output_dir + "_uncertainty"):
+        os.makedirs(j(d), exist_ok=True)
+    grounded = sorted(os.listdir(j(aligning_depths)))
+    touches = sorted(os.listdir(j(touch_depth)))
+    visions = sorted(os.listdir(j(zoe_depth_path)))
+    rng = np.random.default_rng(seed) if seed is not None else None
+    for idx, g_name in enumerate(grounded):
+        n = os.path.splitext(os.path.basename(touches[idx]))[0]
+        g = _read_m(os.path.join(j(aligning_depths), g_name))
+        t = _read_m(os.path.join(j(touch_depth), touches[idx]))
+        v = _read_m(os.path.join(j(zoe_depth_path), visions[idx]))
+        tv = _read_m(os.path.join(j(touch_var), f"{n}.png"))
+        if not is_sim:   # the sensor's depth image is brought to the resolution of the other maps
+            g = resize_bilinear(g, *t.shape)
+        if use_uncertainty:
+            r = P.fuse_vision_and_touch_arrays(g, t, v, tv, is_real_world=not is_sim, rng=rng)
+        else:            # touch overwrites vision where it exists; no uncertainty map in this mode
+            g_sparse = P.create_sparse_depth_map(g, 0.01, rng)
+            ds, va, _ = P.align_vision_depth(g_sparse, t, v, not is_sim)
+            fused = np.where(t > 0, t, va)
+            r = dict(vision=va, vision_baseline=ds, fused_depth=np.clip(fused, 0, None),
+                     fused_uncertainty=np.zeros_like(fused))
+        P.write_png16(os.path.join(j(vision_output_dir), f"{n}.png"), P.to_uint16_mm(r["vision"]))
+        P.write_png16(os.path.join(j(vision_output_dir + "_baseline"), f"{n}.png"), P.to_uint16_mm(r["vision_baseline"]))
+        P.write_png16(os.path.join(j(fused_output_dir), f"{n}.png"), P.to_uint16_mm(r["fused_depth"]))
+        P.write_png16(os.path.join(j(fused_output_dir + "_uncertainty"), f"{n}.png"), P.to_uint16_mm(r["fused_uncertainty"]))
+    return len(grounded)
+
+
+def add_depth_file_path_to_transforms(base_repo_path: str, filename: str, depth_file_path_template: str,
+                                      uncertainty_file_path_template: str) -> dict:
+    """Rewrites <base>/<filename> with depth_file_path / uncertainty_file_path on every frame
+    (reference utils/add_depth_file_path_to_transforms.py:22-55)."""
+    full = os.path.join(base_repo_path, filename)
+    with open(full) as f:
+        data = json.load(f)
+    P.add_depth_file_paths(data, depth_file_path_template, uncertainty_file_path_template)
+    with open(full, "w") as f:
+        json.dump(data, f, indent=4)
+    return data
+
+
+def create_point_cloud_from_touches(root_dir: str, image_dir: str, touch_depth_dir: str, touch_var_dir: str,
+                                    transform_json_path: str, train_split: float, percent_take: float = 100.0,
+                                    seed: Optional[int] = None):
+    """Back-projects the touch depth of the TRAIN images into one world-space point cloud and saves
+    points_touch.npy / points_colors.npy (reference utils/create_point_cloud_from_touches.py:113-171,
+    :226-244).  Depth maps whose size differs from the image are resized to the image (the reference
+    passes swapped dimensions to cv2.resize there, :137; the intent is kept, not the bug)."""
+    from PIL import Image
+    j = lambda d: os.path.join(root_dir, d)
+    images = sorted(os.listdir(j(image_dir)))
+    depths = sorted(os.listdir(j(touch_depth_dir)))
+    i_train, _ = P.get_train_eval_split_fraction(images, train_split)
+    data, poses = P.load_transforms(j(transform_json_path))
+    intr = (data["fl_x"], data["fl_y"], data["cx"], data["cy"])
+    D, C, T = [], [], []
+    for i in i_train:
+        img = np.asarray(Image.open(os.path.join(j(image_dir), images[i])).convert("RGB"))
+        d = _read_m(os.path.join(j(touch_depth_dir), depths[i]))
+        if d.shape != img.shape[:2]:
+            d = resize_bilinear(d, img.shape[0], img.shape[1])
+        D.append(d)
+        C.append(img)
+        T.append(poses[os.path.splitext(images[i])[0]])
+    pts, cols = P.seed_points_from_touches(D, C, T, intr, percent_take,
+                                           np.random.default_rng(seed) if seed is not None else None)
+    np.save(os.path.join(root_dir, "points_touch.npy"), pts)
+    np.save(os.path.join(root_dir, "points_colors.npy"), cols)
+    return pts, cols
+
+
+# ------------------------------------------------------------------------------------------------
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    sub = ap.add_subparsers(dest="step", required=True)
+    s = sub.add_parser("read_touch_depths")
+    s.add_argument("--base_repo_path", required=True)
+    s = sub.add_parser("fuse_touch_vision")
+    for a in ("root_dir", "zoe_depth_path", "touch_depth", "touch_var", "vision_output_dir", "fused_output_dir"):
+        s.add_argument("--" + a, required=True)
+    s.add_argument("--aligning_depths", required=True)
+    s.add_argument("--use_uncertainty", action="store_true")
+    s.add_argument("--is_sim", action="store_true")
+    s.add_argument("--seed", type=int, default=None)
+    s = sub.add_parser("add_depth_file_path_to_transforms")
+    for a in ("base_repo_path", "filename", "depth_file_path_template", "uncertainty_file_path_template"):
+        s.add_argument("--" + a, required=True)
+    s = sub.add_parser("create_point_cloud_from_touches")
+    for a in ("root_dir", "image_dir", "touch_depth_dir", "touch_var_dir", "transform_json_path"):
+        s.add_argument("--" + a, required=True)
+    s.add_argument("--train_split", type=float, required=True)
+    s.add_argument("--percent_take", type=float, default=100.0)
+    s.add_argument("--seed", type=int, default=None)
+    s.add_argument("--viz", action="store_true", help="accepted for compatibility; there is no viewer here")
+    a = ap.parse_args(argv)
+    if a.step == "read_touch_depths":
+        print("wrote", read_touch_depths(a.base_repo_path), "touch depth / variance images")
+    elif a.step == "fuse_touch_vision":
+        print("fused", fuse_touch_vision(a.root_dir, a.aligning_depths, a.touch_depth, a.zoe_depth_path,
+                                         a.vision_output_dir, a.fused_output_dir, a.touch_var,
+                                         a.use_uncertainty, a.is_sim, a.seed), "images")
+    elif a.step == "add_depth_file_path_to_transforms":
+        add_depth_file_path_to_transforms(a.base_repo_path, a.filename, a.depth_file_path_template,
+                                          a.uncertainty_file_path_template)
+    else:
+        pts, _ = create_point_cloud_from_touches(a.root_dir, a.image_dir, a.touch_depth_dir, a.touch_var_dir,
+                                                 a.transform_json_path, a.train_split, a.percent_take, a.seed)
+        print("saved", len(pts), "touch points")
+
+
+if __name__ == "__main__":
+    main()
