@@ -163,7 +163,8 @@ def test_trainer_cli_synthetic(dev, tmp_path):
                       "--render-output", str(tmp_path / "renders")])
     import json, os
     ev = json.load(open(os.path.join(run, "eval.json")))
-    assert {"psnr", "ssim", "depth_mse"} <= set(ev["results"]) and os.path.exists(os.path.join(run, "step-000000012.ckpt"))
+    assert {"psnr", "ssim", "lpips", "depth_mse"} <= set(ev["results"]) and os.path.exists(os.path.join(run, "step-000000012.ckpt"))
+    assert math.isnan(ev["results"]["lpips"])     # key present for the reference's aggregator, value unavailable
     # render dump (the ns-render counterpart): 8-bit rgb + 16-bit millimetre depth of the eval view
     from PIL import Image
     from touch_gs_amd.plumbing import read_png16
