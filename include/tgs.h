@@ -123,11 +123,17 @@ int tgs_sh_bwd(int N, int sh_deg, int sh_stride, const float* dirs, const float*
  *                       but visits it longest list first; entries == T mean "no tile"
  *      status[2]        {#intersections, overflow flag}; if #intersections > capacity nothing
  *                       past the scans is written, overflow=1 (caller grows and retries)
+ *      sticky_overflow  (may be NULL) one persistent int32: set to 1 by an overflowing frame and
+ *                       never cleared by the library; while it is 1 every frame starts with
+ *                       status[1] = 1 (empty lists).  Together with the `skip_if_overflow` argument of
+ *                       the optimizer entry points this lets a caller read the status words late,
+ *                       without a per-frame host sync: after an overflow nothing touches the model
+ *                       until the caller has cleared the word, grown the buffers and replayed.
  * tmp: tile_cursor[T], scratch (tgs_sort_scratch_bytes(capacity)). */
 int tgs_bin_sort(const TgsCamera* cam /*[host]*/, int N, float* splats, int32_t* group_base,
                  int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
                  int32_t* tile_order, int64_t capacity, void* scratch, int32_t* status,
-                 void* stream);
+                 int32_t* sticky_overflow, void* stream);
 
 /* K1 + K2-K5 in one call (the fast path): the projection workgroup IS the 256-Gaussian binning
  *     group, so it also builds the group scan and counts its tile intersections -- the records are
@@ -138,7 +144,7 @@ int tgs_project_bin_sort(const TgsCamera* cam /*[host]*/, int N, const float* me
                          const float* sh, int sh_stride, int sh_deg, float* splats, int32_t* radii,
                          int32_t* group_base, int32_t* tile_start, int32_t* tile_cursor,
                          int32_t* sorted_gid, int32_t* tile_order, int64_t capacity, void* scratch,
-                         int32_t* status, void* stream);
+                         int32_t* status, int32_t* sticky_overflow, void* stream);
 
 /* K6  per-tile front-to-back compositing of RGB + depth in ONE pass  (stands behind gsplat
  *     `rasterize_gaussians` fwd, called twice by Splatfacto for rgb and depth; spec App. B.6).
@@ -186,7 +192,8 @@ int tgs_project_bwd(const TgsCamera* cam /*[host]*/, int N, const float* means,
                     const float* sh, int sh_stride, int sh_deg, const float* splats,
                     const int32_t* group_base, const float* partials, const float* v_splats,
                     float* v_means, float* v_log_scales, float* v_quats, float* v_opac_logit,
-                    float* v_sh, float* v_xy, void* stream);
+                    float* v_sh, float* v_xy,
+                    const int32_t* skip_if_overflow /*status[2] of the frame, or NULL*/, void* stream);
 
 /* K8+K9 fused (single-process training): projection/SH backward whose gradients go straight
  *     through the Adam update of the flat parameter buffer `params` (layout of TgsAdamSpec) and
@@ -197,6 +204,7 @@ int tgs_project_bwd_adam(const TgsCamera* cam /*[host]*/, int N, int sh_stride, 
                          float* params, float* exp_avg, float* exp_avg_sq,
                          const TgsAdamSpec* spec /*[host]*/, const float* splats,
                          const int32_t* group_base, const float* partials, float* v_xy,
+                         const int32_t* skip_if_overflow /*status[2] of the frame, or NULL*/,
                          void* stream);
 
 /* Data-parallel step (one view per rank, SURVEY section 8 row e).  The SH gradient of a rank is the
@@ -231,7 +239,8 @@ int tgs_store_small(float* dst, const float* host_vals /*[host]*/, int n, void* 
  *     everything) so that chunks can be stepped as their gradient all-reduce completes. */
 int tgs_adam_step(int N, int sh_stride, float* params, const float* grads, float* exp_avg,
                   float* exp_avg_sq, const TgsAdamSpec* spec /*[host]*/, float grad_scale,
-                  int64_t elem_begin, int64_t elem_end, void* stream);
+                  int64_t elem_begin, int64_t elem_end,
+                  const int32_t* skip_if_overflow /*status[2] of the frame, or NULL*/, void* stream);
 
 /* K10 SSIM (11x11 Gaussian window, sigma 1.5, zero padding) forward + gradient image; the
  *     (1-SSIM) term of the Splatfacto-style loss.

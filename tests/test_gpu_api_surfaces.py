@@ -439,3 +439,35 @@ def test_trainer_on_disk_dataset_in_reference_format(dev, tmp_path):
     ev = json.load(open(os.path.join(run, "eval.json")))
     assert {"psnr", "ssim", "depth_mse", "supervised_depth_mse"} <= set(ev["results"])
     assert len(os.listdir(tmp_path / "renders" / "rgb")) == 1 and len(os.listdir(tmp_path / "renders" / "depth")) == 1
+
+
+@pytest.mark.parametrize("capacity", [0, 3000])
+def test_speculative_budget_equals_synchronous_budget(dev, capacity):
+    """Sync-free training: status words are read late; capacity=3000 is far too small, so frames
+    overflow, the sticky device word turns the following steps into no-ops, and the host replays them
+    with grown buffers -- parameters, moments and step counters end bit-identical to the synchronous
+    budget (capacity=0 = generous default: no overflow at all)."""
+    from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
+    from touch_gs_amd.optim import GaussianParams
+    from touch_gs_amd.scene import make_view, synthetic_gaussians
+    N, W, H, deg = 6000, 160, 96, 3
+    views = [make_view(N, W, H, deg, 7, dev, view=v, n_views=4) for v in range(4)]
+    P, _ = synthetic_gaussians(N, W, H, deg, 99)
+    def fresh():
+        params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
+        return DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=4), params)
+    ref, spec = fresh(), fresh()
+    spec.enable_speculative_budget(capacity=capacity, max_in_flight=3)
+    for step in range(11):
+        ref.train_step(views[step % 4])
+        spec.train_step(views[step % 4])
+    spec.flush()
+    torch.cuda.synchronize()
+    assert spec.step == ref.step == 11 and spec.optimizer.t == ref.optimizer.t == 11
+    replays = getattr(spec, "speculative_replays", 0)
+    assert (replays > 0) == (capacity > 0)
+    assert spec.budget.capacity >= int(spec.last["status"][0])
+    for x, y in ((spec.params.flat, ref.params.flat), (spec.optimizer.exp_avg, ref.optimizer.exp_avg),
+                 (spec.optimizer.exp_avg_sq, ref.optimizer.exp_avg_sq)):
+        assert torch.equal(x, y)
+    assert torch.equal(spec.last["rgb"], ref.last["rgb"])

@@ -1,5 +1,5 @@
-"""Developer tool: train-step time with the synchronous intersection budget (default of the trainer)
-against the pre-sized, sync-free budget bench.py uses."""
+"""Developer tool: train-step time with the synchronous intersection budget against the pre-sized
+sync-free budget bench.py uses and the speculative sync-free budget the trainer uses."""
 import sys, time, torch
 sys.path.insert(0, '.')
 from touch_gs_amd import ops
@@ -14,13 +14,16 @@ for name, (N, W, H, deg, seed) in cfgs.items():
     model = DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=0), params)
     views = [make_view(N, W, H, deg, seed, dev, view=v, n_views=8) for v in range(8)]
     for v in views: v.valid_count()
-    for mode in ("sync", "presized"):
+    for mode in ("sync", "presized", "speculative"):
         if mode == "presized":
             model.budget = ops.IntersectBudget(capacity=int(model.budget.capacity * 1.25), sync=False)
+        if mode == "speculative":
+            model.enable_speculative_budget()
         for i in range(16): model.train_step(views[i % 8])
         torch.cuda.synchronize(); t0 = time.perf_counter()
         n = 200
         for i in range(n): model.train_step(views[i % 8])
+        model.flush()
         torch.cuda.synchronize()
         print(name, mode, "ms/step", round((time.perf_counter() - t0) / n * 1e3, 4))
     del model, params, views; torch.cuda.empty_cache()

@@ -40,13 +40,13 @@ __device__ __forceinline__ int group_load_scan(const CamK& cam, int N,
 __global__ __launch_bounds__(TGS_GROUP) void k_tile_count(
     CamK cam, int N, float* __restrict__ splats, int32_t* __restrict__ group_base,
     int32_t* __restrict__ tile_count, int32_t* __restrict__ rank, int32_t* __restrict__ status,
-    long long capacity) {
+    long long capacity, int32_t* __restrict__ sticky) {
   __shared__ GroupScan S;
   int my_off;
   const int total = group_load_scan(cam, N, splats, S, my_off);
   const int g = blockIdx.x * TGS_GROUP + threadIdx.x;
   if (g < N) splats[(size_t)g * TGS_SPLAT_FLOATS + 11] = __int_as_float(my_off);
-  group_count_tiles(S, cam.TW, total, group_base, tile_count, rank, status, capacity);
+  group_count_tiles(S, cam.TW, total, group_base, tile_count, rank, status, capacity, sticky);
 }
 
 // K4: exclusive scan of tile counts -> tile_start[T+1] (single workgroup; T is a few 10^4).
@@ -266,7 +266,7 @@ int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* gro
 extern "C" int tgs_bin_sort(const TgsCamera* cam, int N, float* splats, int32_t* group_base,
                             int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
                             int32_t* tile_order, int64_t capacity, void* scratch, int32_t* status,
-                            void* stream) {
+                            int32_t* sticky_overflow, void* stream) {
   TGS_CHECK_ARG(camera_ok(cam), "bad camera");
   TGS_CHECK_ARG(N >= 0 && capacity >= 0, "negative size");
   TGS_CHECK_ARG(capacity < (1ll << 31), "capacity must be < 2^31");
@@ -278,11 +278,12 @@ extern "C" int tgs_bin_sort(const TgsCamera* cam, int N, float* splats, int32_t*
   const int G = tgs_num_groups(N);
   hipStream_t s = (hipStream_t)stream;
   const BinScratch sc = carve_scratch(scratch, capacity);
-  hipLaunchKernelGGL(k_clear_counters, dim3((max(T, 2) + 255) / 256), dim3(256), 0, s, tile_cursor, T, status);
+  hipLaunchKernelGGL(k_clear_counters, dim3((max(T, 2) + 255) / 256), dim3(256), 0, s, tile_cursor, T, status,
+                     sticky_overflow);
   TGS_CHECK_LAUNCH();
   if (G > 0) {
     hipLaunchKernelGGL(k_tile_count, dim3(G), dim3(TGS_GROUP), 0, s, k, N, splats, group_base,
-                       tile_cursor, sc.rank, status, (long long)capacity);
+                       tile_cursor, sc.rank, status, (long long)capacity, sticky_overflow);
     TGS_CHECK_LAUNCH();
   }
   return tgs_bin_finish(k, N, splats, group_base, tile_start, tile_cursor, sorted_gid, tile_order,

@@ -18,6 +18,7 @@ namespace {
 __global__ __launch_bounds__(256) void k_adam(AdamK a_in, float* __restrict__ p,
                                               const float* __restrict__ g, float* __restrict__ m,
                                               float* __restrict__ v) {
+  if (a_in.guard && a_in.guard[1]) return;   // the frame overflowed its intersection buffers: no update
   const AdamK a = adam_resolve(a_in);
   const long long n4 = a.e_end >> 2;
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -68,7 +69,8 @@ extern "C" int tgs_store_small(float* dst, const float* host_vals, int n, void* 
 
 extern "C" int tgs_adam_step(int N, int sh_stride, float* params, const float* grads,
                              float* exp_avg, float* exp_avg_sq, const TgsAdamSpec* spec,
-                             float grad_scale, int64_t elem_begin, int64_t elem_end, void* stream) {
+                             float grad_scale, int64_t elem_begin, int64_t elem_end,
+                             const int32_t* skip_if_overflow, void* stream) {
   TGS_CHECK_ARG(N >= 0 && sh_stride >= 0, "negative size");
   if (N == 0) return TGS_OK;
   TGS_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && spec, "null pointer");
@@ -80,6 +82,7 @@ extern "C" int tgs_adam_step(int N, int sh_stride, float* params, const float* g
   TGS_CHECK_ARG((elem_begin & 3) == 0 && (elem_end & 3) == 0, "element range must be a multiple of 4");
   if (elem_end <= elem_begin) return TGS_OK;
   a.e_begin = elem_begin; a.e_end = elem_end;
+  a.guard = skip_if_overflow;
   const long long n4 = (elem_end - elem_begin) >> 2;
   long long blocks = (n4 + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 blocks per CU

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void k_project_fwd(
     const float* __restrict__ sh, int sh_stride, const float* __restrict__ colors_in,
     float* __restrict__ splats, int32_t* __restrict__ radii, int32_t* __restrict__ group_base,
     int32_t* __restrict__ tile_count, int32_t* __restrict__ rank, int32_t* __restrict__ status,
-    long long capacity) {
+    long long capacity, int32_t* __restrict__ sticky) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if constexpr (!FUSED) { if (g >= N) return; }
   unsigned rect = 0u;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_project_fwd(
       float* o = splats + (size_t)g * TGS_SPLAT_FLOATS;
       st4(o + 8, make_float4(c1, c2, __uint_as_float(rect), __int_as_float(my_off)));
     }
-    group_count_tiles(S, cam.TW, total, group_base, tile_count, rank, status, capacity);
+    group_count_tiles(S, cam.TW, total, group_base, tile_count, rank, status, capacity, sticky);
   }
 }
 
@@ -380,9 +380,10 @@ __global__ __launch_bounds__(256) void k_project_bwd(
     const float* __restrict__ v_splats, float* __restrict__ v_means,
     float* __restrict__ v_log_scales, float* __restrict__ v_quats,
     float* __restrict__ v_opac_logit, float* __restrict__ v_sh, float* __restrict__ v_color,
-    float* __restrict__ v_xy) {
+    float* __restrict__ v_xy, const int32_t* __restrict__ guard) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= N) return;
+  if (guard && guard[1]) return;   // overflowed frame: the pair index space is not backed by memory
   if (v_color && g == 0) {  // trailer of the colour-gradient block: this view's camera position
     v_color[3 * (size_t)N] = cam.campos[0]; v_color[3 * (size_t)N + 1] = cam.campos[1];
     v_color[3 * (size_t)N + 2] = cam.campos[2]; v_color[3 * (size_t)N + 3] = 0.f;
@@ -493,6 +494,8 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
     float* __restrict__ v_log_scales, float* __restrict__ v_quats,
     float* __restrict__ v_opac_logit, float* __restrict__ v_sh, float* __restrict__ v_xy,
     AdamK ad_in, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq) {
+  // overflowed frame: the pair index space is not backed by memory and the step must not touch the model
+  if (ad_in.guard && ad_in.guard[1]) return;
   const AdamK ad = FUSE_ADAM ? adam_resolve(ad_in) : ad_in;
   constexpr int K = (DEG + 1) * (DEG + 1);   // requires sh_stride == K here (3K % 4 == 0)
   constexpr int ROW = 3 * K, RS = ROW + 4, F4 = ROW / 4;
@@ -814,7 +817,7 @@ extern "C" int tgs_project_fwd(const TgsCamera* cam, int N, const float* means,
 #define LAUNCH(D)                                                                              \
   hipLaunchKernelGGL((k_project_fwd<D, false>), grid, block, 0, s, k, N, means, log_scales, quats, \
                      opac_logit, sh, sh_stride, colors_in, splats, radii, (int32_t*)nullptr,       \
-                     (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, 0ll)
+                     (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, 0ll, (int32_t*)nullptr)
   switch (sh_deg) {
     case 0: LAUNCH(0); break;
     case 1: LAUNCH(1); break;
@@ -846,7 +849,8 @@ extern "C" int tgs_project_bwd(const TgsCamera* cam, int N, const float* means,
                                const float* splats, const int32_t* group_base,
                                const float* partials, const float* v_splats, float* v_means,
                                float* v_log_scales, float* v_quats, float* v_opac_logit,
-                               float* v_sh, float* v_xy, void* stream) {
+                               float* v_sh, float* v_xy, const int32_t* skip_if_overflow,
+                               void* stream) {
   TGS_CHECK_ARG(camera_ok(cam), "bad camera");
   if (N <= 0) return TGS_OK;
   TGS_CHECK_ARG(means && log_scales && quats && opac_logit && splats, "null pointer");
@@ -862,6 +866,7 @@ extern "C" int tgs_project_bwd(const TgsCamera* cam, int N, const float* means,
   if (partials && sh && v_sh && sh_deg >= 1 && sh_stride == (sh_deg + 1) * (sh_deg + 1) &&
       (3 * sh_stride) % 4 == 0) {
     AdamK none{};
+    none.guard = skip_if_overflow;
     const size_t lds_bytes = 256 * (size_t)(3 * sh_stride + 4) * sizeof(float);
 #define LAUNCH_LDS(D)                                                                            \
   hipLaunchKernelGGL((k_project_bwd_lds<D, false>), grid, block, lds_bytes, s, k, N,             \
@@ -877,7 +882,7 @@ extern "C" int tgs_project_bwd(const TgsCamera* cam, int N, const float* means,
 #define LAUNCH(D)                                                                                \
   hipLaunchKernelGGL(k_project_bwd<D>, grid, block, 0, s, k, N, means, log_scales, quats,        \
                      opac_logit, sh, sh_stride, splats, group_base, partials, v_splats, v_means, \
-                     v_log_scales, v_quats, v_opac_logit, v_sh, (float*)nullptr, v_xy)
+                     v_log_scales, v_quats, v_opac_logit, v_sh, (float*)nullptr, v_xy, skip_if_overflow)
   switch (sh_deg) {
     case 0: LAUNCH(0); break;
     case 1: LAUNCH(1); break;
@@ -894,14 +899,15 @@ extern "C" int tgs_project_bwd_adam(const TgsCamera* cam, int N, int sh_stride, 
                                     float* params, float* exp_avg, float* exp_avg_sq,
                                     const TgsAdamSpec* spec, const float* splats,
                                     const int32_t* group_base, const float* partials, float* v_xy,
-                                    void* stream) {
+                                    const int32_t* skip_if_overflow, void* stream) {
   TGS_CHECK_ARG(camera_ok(cam), "bad camera");
   if (N <= 0) return TGS_OK;
   TGS_CHECK_ARG(params && exp_avg && exp_avg_sq && spec && splats && group_base && partials, "null pointer");
   TGS_CHECK_ARG((sh_deg == 3 || sh_deg == 1) && sh_stride == (sh_deg + 1) * (sh_deg + 1),
                 "fused K8+Adam needs a dense SH tensor at its full degree (1 or 3)");
   const CamK k = make_camk(cam);
-  const AdamK a = make_adamk(N, sh_stride, spec, 1.0f);
+  AdamK a = make_adamk(N, sh_stride, spec, 1.0f);
+  a.guard = skip_if_overflow;
   float* means = params;
   float* log_scales = params + a.e_means;
   float* quats = params + a.e_scales;
@@ -928,7 +934,7 @@ extern "C" int tgs_project_bin_sort(const TgsCamera* cam, int N, const float* me
                                     int sh_deg, float* splats, int32_t* radii, int32_t* group_base,
                                     int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
                                     int32_t* tile_order, int64_t capacity, void* scratch,
-                                    int32_t* status, void* stream) {
+                                    int32_t* status, int32_t* sticky_overflow, void* stream) {
   TGS_CHECK_ARG(camera_ok(cam), "bad camera");
   TGS_CHECK_ARG(N >= 0 && capacity >= 0 && capacity < (1ll << 31), "bad size");
   TGS_CHECK_ARG(cam->W <= 4080 && cam->H <= 4080, "image side > 4080 px (255 tiles)");
@@ -941,14 +947,15 @@ extern "C" int tgs_project_bin_sort(const TgsCamera* cam, int N, const float* me
   const int T = k.TW * k.TH;
   hipStream_t s = (hipStream_t)stream;
   const BinScratch sc = carve_scratch(scratch, capacity);
-  hipLaunchKernelGGL(k_clear_counters, dim3((max(T, 2) + 255) / 256), dim3(256), 0, s, tile_cursor, T, status);
+  hipLaunchKernelGGL(k_clear_counters, dim3((max(T, 2) + 255) / 256), dim3(256), 0, s, tile_cursor, T, status,
+                     sticky_overflow);
   TGS_CHECK_LAUNCH();
   if (N > 0) {
     const dim3 grid((N + 255) / 256), block(256);
 #define LAUNCH(D)                                                                                  \
   hipLaunchKernelGGL((k_project_fwd<D, true>), grid, block, 0, s, k, N, means, log_scales, quats,  \
                      opac_logit, sh, sh_stride, (const float*)nullptr, splats, radii, group_base,   \
-                     tile_cursor, sc.rank, status, (long long)capacity)
+                     tile_cursor, sc.rank, status, (long long)capacity, sticky_overflow)
     switch (sh_deg) {
       case 0: LAUNCH(0); break;
       case 1: LAUNCH(1); break;
@@ -1035,7 +1042,7 @@ extern "C" int tgs_project_bwd_color(const TgsCamera* cam, int N, const float* m
   hipLaunchKernelGGL(k_project_bwd<D>, grid, block, 0, s, k, N, means, log_scales, quats,        \
                      opac_logit, sh, sh_stride, splats, group_base, partials,                    \
                      (const float*)nullptr, v_means, v_log_scales, v_quats, v_opac_logit,        \
-                     (float*)nullptr, v_color, v_xy)
+                     (float*)nullptr, v_color, v_xy, (const int32_t*)nullptr)
   switch (sh_deg) {
     case 0: LAUNCH(0); break;
     case 1: LAUNCH(1); break;

@@ -11,6 +11,7 @@ struct AdamK {
   float lr_means, lr_scales, lr_quats, lr_opac, lr_dc, lr_rest;
   float b1, b2, eps, ibc1, isq_bc2, gscale;
   const float* dyn;   // device {bias_corr1, bias_corr2} of the current step, or NULL
+  const int32_t* guard;  // status word of the frame's binning ({n, overflow}), or NULL: overflow => no-op
 };
 
 static inline long long tgs_al4(long long x) { return (x + 3) & ~3ll; }
@@ -33,6 +34,7 @@ static inline AdamK make_adamk(int N, int sh_stride, const TgsAdamSpec* spec, fl
   a.isq_bc2 = 1.0f / sqrtf(spec->bias_corr2);
   a.gscale = grad_scale;
   a.dyn = spec->device_bias_corr;
+  a.guard = nullptr;
   return a;
 }
 

@@ -63,11 +63,16 @@ __device__ __forceinline__ int group_scan_store(GroupScan& S, int hits, int x0, 
 // then is an ordinary node when the step is captured into a hipGraph (a memset root node was seen to
 // start before the previous graph launch on the same stream had drained), and it is a little
 // cheaper than the runtime's fill.
+// `sticky` (may be NULL): a persistent overflow word.  Once an overflowing frame has set it, every
+// later frame starts with status[1] = 1 -- empty lists, and the guarded optimizer kernels do nothing
+// -- until the host, which reads the status words late and without blocking, clears it and replays.
 static __global__ __launch_bounds__(256) void k_clear_counters(int32_t* __restrict__ tile_cursor, int T,
-                                                        int32_t* __restrict__ status) {
+                                                        int32_t* __restrict__ status,
+                                                        const int32_t* __restrict__ sticky) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < T) tile_cursor[i] = 0;
-  if (i < 2) status[i] = 0;
+  if (i == 0) status[0] = 0;
+  if (i == 1) status[1] = sticky ? (*sticky != 0) : 0;
 }
 
 // pair i of the group -> (local Gaussian j, tile id)
@@ -92,13 +97,17 @@ __device__ __forceinline__ void group_count_tiles(GroupScan& S, int TW, int tota
                                                   int32_t* __restrict__ group_base,
                                                   int32_t* __restrict__ tile_count,
                                                   int32_t* __restrict__ rank,
-                                                  int32_t* __restrict__ status, long long capacity) {
+                                                  int32_t* __restrict__ status, long long capacity,
+                                                  int32_t* __restrict__ sticky) {
   const int tid = threadIdx.x;
   if (tid == 0) {
     const int base = total ? atomicAdd(&status[0], total) : 0;
     S.base = base;
     group_base[blockIdx.x] = base;
-    if ((long long)base + total > capacity) status[1] = 1;
+    if ((long long)base + total > capacity) {
+      status[1] = 1;
+      if (sticky) *sticky = 1;
+    }
   }
   __syncthreads();
   const long long base = S.base;

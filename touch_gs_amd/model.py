@@ -16,6 +16,7 @@ Two execution paths over the same kernels:
 """
 from __future__ import annotations
 
+import collections
 import dataclasses
 import math
 from typing import Dict, Optional
@@ -186,8 +187,9 @@ class DepthGaussianSplattingModel:
         p, c, cam = self.params, self.config, view.cam
         deg = self.active_sh_degree()
         H, W = cam.H, cam.W
-        splats, radii, group_base, tile_start, sorted_gid, _ = ops.project_bin_sort(
+        splats, radii, group_base, tile_start, sorted_gid, status = ops.project_bin_sort(
             cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, self.budget, want_radii=want_v_xy)
+        guard = status if self.budget.speculative else None   # overflowed frame => optimizer kernels are no-ops
         rgb, depth_acc, fT, fidx = ops.rasterize_fwd(cam, splats, sorted_gid, tile_start)
         v_img, ssim_sum = None, None
         if c.ssim_lambda > 0:
@@ -197,15 +199,15 @@ class DepthGaussianSplattingModel:
                                                 loss=self.loss_spec(view), want_tile_loss=True)
         if fuse_adam:
             v_xy = self.optimizer.backward_and_step(cam, deg, splats, group_base, partials, want_v_xy,
-                                                    begin=begin_step)
+                                                    begin=begin_step, guard=guard)
         elif color_block is not None:   # data-parallel: geometry gradients + colour-gradient block
             v_xy = ops.project_bwd_color(cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, splats,
                                          group_base, partials, p.grad_views()[:4], color_block, want_v_xy)
         else:
             v_xy = ops.project_bwd(cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, splats,
-                                   group_base, partials, out=p.grad_views(), want_v_xy=want_v_xy)[5]
+                                   group_base, partials, out=p.grad_views(), want_v_xy=want_v_xy, guard=guard)[5]
         self.last = dict(rgb=rgb, depth_acc=depth_acc, final_T=fT, splats=splats, v_xy=v_xy, radii=radii,
-                         tile_loss=tile_loss, ssim_sum=ssim_sum)
+                         tile_loss=tile_loss, ssim_sum=ssim_sum, status=status, guard=guard)
         return tile_loss, ssim_sum
 
     def loss_from(self, tile_loss, ssim_sum, view: View) -> Dict[str, torch.Tensor]:
@@ -221,6 +223,59 @@ class DepthGaussianSplattingModel:
         """Turn on Splatfacto-style clone / split / cull refinement (touch_gs_amd.densify)."""
         from .densify import DensifyConfig, DensityController
         self.density = DensityController(cfg or DensifyConfig(), self.params.N, self.params.flat.device)
+
+    # -- sync-free intersection budget ---------------------------------------------------------
+    def enable_speculative_budget(self, capacity: int = 0, max_in_flight: int = 4) -> None:
+        """Train without the per-step read-back of the intersection count (single process, no
+        densification).  Every step's status word is copied to pinned host memory asynchronously and
+        looked at a few steps later.  Correctness does not depend on guessing the capacity right: a
+        frame that overflows sets a sticky device word that empties every later frame and turns the
+        guarded optimizer kernels into no-ops, so when the host notices it clears the word, grows the
+        buffers, rewinds its step counters and replays the affected views -- the model ends up exactly
+        where the synchronous budget would have put it (tests/test_gpu_api_surfaces.py)."""
+        if getattr(self, "density", None) is not None:
+            raise RuntimeError("the speculative budget does not combine with densification")
+        self.budget = ops.IntersectBudget(capacity=capacity, sync=False, speculative=True)
+        self._pending = collections.deque()
+        self._max_in_flight = max_in_flight
+        self._pinned = []
+
+    def _speculative_track(self, view: View) -> None:
+        host = self._pinned.pop() if self._pinned else torch.empty(2, dtype=torch.int32).pin_memory()
+        host.copy_(self.last["status"], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending.append((view, host, ev))
+        self._speculative_poll(block=len(self._pending) > self._max_in_flight)
+
+    def _speculative_poll(self, block: bool = False, drain: bool = False) -> None:
+        while self._pending and (drain or block or self._pending[0][2].query()):
+            view, host, ev = self._pending[0]
+            ev.synchronize()
+            block = False
+            if int(host[1]) == 0:
+                self._pending.popleft()
+                self._pinned.append(host)
+                continue
+            # overflow: this step and everything enqueued after it did nothing on the device
+            torch.cuda.synchronize()
+            redo = list(self._pending)
+            self._pending.clear()
+            need = max(int(h[0]) for _, h, _ in redo)
+            self.budget.capacity = int(need * self.budget.growth) + 1024
+            self.budget.sticky.zero_()
+            self.optimizer.t -= len(redo)
+            self.step -= len(redo)
+            self.speculative_replays = getattr(self, "speculative_replays", 0) + len(redo)
+            for v, h, _ in redo:
+                self._pinned.append(h)
+                self.train_step(v)
+
+    def flush(self) -> None:
+        """Wait for every enqueued step and settle pending overflow checks (call before reading
+        ``last``, saving a checkpoint or evaluating when the speculative budget is on)."""
+        if getattr(self, "_pending", None) is not None and self.budget.speculative:
+            self._speculative_poll(drain=True)
 
     # -- hipGraph replay of the step (small scenes are launch bound) ----------------------------
     def capture_step_graphs(self, views, headroom: float = 1.3, share_pool: bool = True) -> None:
@@ -279,6 +334,8 @@ class DepthGaussianSplattingModel:
         fuse = (not distributed) and self.fuse_adam and opt.can_fuse_with_backward(deg)
         factored = distributed and self.dp_factored_sh and opt.can_gather_sh()
         density = getattr(self, "density", None)
+        if self.budget.speculative and (distributed or density is not None):
+            raise RuntimeError("the speculative intersection budget is for single-process training without densification")
         block = None
         if factored:
             n = 3 * self.params.N + 4
@@ -298,8 +355,10 @@ class DepthGaussianSplattingModel:
         elif distributed:
             dp.reduce_and_step(self.params.grad, self.optimizer.step_range, self.optimizer.begin_step)
         elif not fuse:
-            self.optimizer.step()
+            self.optimizer.step(guard=self.last["guard"])
         self.step += 1
+        if self.budget.speculative and not distributed and density is None:
+            self._speculative_track(view)
         if density is not None and density.due(self.step):
             self.params, self.optimizer, self.last_refine = density.refine(self.params, self.optimizer, self.step, dp)
             self.budget = ops.IntersectBudget()  # the intersection count changes with N

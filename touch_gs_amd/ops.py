@@ -44,14 +44,27 @@ class IntersectBudget:
     frame) and the frame is re-binned with a larger buffer if it overflowed -- always correct.
     ``sync=False``: no read-back; the caller must size ``capacity`` itself and call
     :meth:`check` at a convenient sync point (bench.py does this once after the timed region).
+    ``speculative=True`` (implies ``sync=False``): additionally hands the kernels a persistent
+    "sticky overflow" word: after an overflowing frame every later frame is empty and the guarded
+    optimizer kernels are no-ops, so the caller may read the status words late, grow the buffers,
+    clear the word and replay (``DepthGaussianSplattingModel.enable_speculative_budget``).
     """
 
-    def __init__(self, capacity: int = 0, sync: bool = True, growth: float = 1.25):
+    def __init__(self, capacity: int = 0, sync: bool = True, growth: float = 1.25, speculative: bool = False):
         self.capacity = int(capacity)
-        self.sync = sync
+        self.sync = sync and not speculative
+        self.speculative = speculative
         self.growth = growth
         self.last_status = None  # device int32[2] of the most recent frame
         self.last_n = None
+        self.sticky = None       # device int32[1], allocated on first use
+
+    def sticky_word(self, device):
+        if not self.speculative:
+            return None
+        if self.sticky is None:
+            self.sticky = torch.zeros(1, dtype=torch.int32, device=device)
+        return self.sticky
 
     def initial(self, N: int):
         if self.capacity <= 0:
@@ -113,7 +126,7 @@ def bin_sort(cam: Camera, splats, budget: Optional[IntersectBudget] = None):
         scratch = torch.empty(lib.tgs_sort_scratch_bytes(cap), dtype=torch.uint8, device=dev)
         check(lib.tgs_bin_sort(C.byref(cs), N, ptr(splats), ptr(group_base), ptr(tile_start),
                                ptr(tile_cursor), ptr(sorted_gid), ptr(tile_order), cap, ptr(scratch),
-                               ptr(status), _stream()), "tgs_bin_sort")
+                               ptr(status), ptr(budget.sticky_word(dev)), _stream()), "tgs_bin_sort")
         budget.last_status = status
         if not budget.sync:
             break
@@ -156,7 +169,7 @@ def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_d
                                        ptr(sh), sh_stride, sh_deg if sh is not None else -1, ptr(splats),
                                        ptr(radii), ptr(group_base), ptr(tile_start), ptr(tile_cursor),
                                        ptr(sorted_gid), ptr(tile_order), cap, ptr(scratch), ptr(status),
-                                       _stream()),
+                                       ptr(budget.sticky_word(dev)), _stream()),
               "tgs_project_bin_sort")
         budget.last_status = status
         if not budget.sync:
@@ -232,7 +245,7 @@ def reduce_partials(cam: Camera, splats, group_base, partials):
 
 
 def project_bwd(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_deg, splats,
-                group_base=None, partials=None, v_splats=None, out=None, want_v_xy=False):
+                group_base=None, partials=None, v_splats=None, out=None, want_v_xy=False, guard=None):
     """K8 -> (v_means, v_log_scales, v_quats, v_opac_logit, v_sh, v_xy).  (tgs_project_bwd)
 
     ``out`` may supply pre-allocated gradient tensors (e.g. views into a flat gradient buffer).
@@ -250,7 +263,7 @@ def project_bwd(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_deg, s
     check(lib.tgs_project_bwd(C.byref(cs), N, ptr(means), ptr(log_scales), ptr(quats), ptr(opac_logit),
                               ptr(sh), sh_stride, sh_deg if sh is not None else -1, ptr(splats),
                               ptr(group_base), ptr(partials), ptr(v_splats), ptr(v_means), ptr(v_ls),
-                              ptr(v_q), ptr(v_ol), ptr(v_sh), ptr(v_xy), _stream()), "tgs_project_bwd")
+                              ptr(v_q), ptr(v_ol), ptr(v_sh), ptr(v_xy), ptr(guard), _stream()), "tgs_project_bwd")
     return v_means, v_ls, v_q, v_ol, v_sh, v_xy
 
 

@@ -116,25 +116,26 @@ class FusedAdam:
         """Advance the step counter once per optimizer iteration (before step_range calls)."""
         self.t += 1
 
-    def step_range(self, elem_begin: int, elem_end: int, grad_scale: float = 1.0):
-        """Adam on flat elements [elem_begin, elem_end) (multiples of 4) of the current step."""
+    def step_range(self, elem_begin: int, elem_end: int, grad_scale: float = 1.0, guard=None):
+        """Adam on flat elements [elem_begin, elem_end) (multiples of 4) of the current step.
+        ``guard``: the frame's binning status word; the launch is a no-op if its overflow flag is set."""
         lib = _lib.load()
         s = self._spec()
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(lib.tgs_adam_step(self.p.N, self.p.K, ptr(self.p.flat), ptr(self.p.grad), ptr(self.exp_avg),
                                 ptr(self.exp_avg_sq), C.byref(s), C.c_float(grad_scale), elem_begin, elem_end,
-                                stream), "tgs_adam_step")
+                                ptr(guard), stream), "tgs_adam_step")
 
-    def step(self, grad_scale: float = 1.0):
+    def step(self, grad_scale: float = 1.0, guard=None):
         self.begin_step()
-        self.step_range(0, -1, grad_scale)
+        self.step_range(0, -1, grad_scale, guard)
 
     def can_fuse_with_backward(self, sh_deg: int) -> bool:
         """tgs_project_bwd_adam needs the SH tensor evaluated at its full (dense) degree 1 or 3."""
         return sh_deg in (1, 3) and self.p.K == (sh_deg + 1) ** 2
 
     def backward_and_step(self, cam, sh_deg: int, splats, group_base, partials, want_v_xy: bool = False,
-                          begin: bool = True):
+                          begin: bool = True, guard=None):
         """K8 + K9 in one launch (single-process training): gradients never reach HBM."""
         lib = _lib.load()
         if begin:
@@ -145,7 +146,7 @@ class FusedAdam:
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(lib.tgs_project_bwd_adam(C.byref(cs), self.p.N, self.p.K, sh_deg, ptr(self.p.flat), ptr(self.exp_avg),
                                        ptr(self.exp_avg_sq), C.byref(s), ptr(splats), ptr(group_base),
-                                       ptr(partials), ptr(v_xy), stream), "tgs_project_bwd_adam")
+                                       ptr(partials), ptr(v_xy), ptr(guard), stream), "tgs_project_bwd_adam")
         return v_xy
 
     def can_gather_sh(self) -> bool:

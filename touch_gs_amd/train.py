@@ -100,6 +100,8 @@ def main(argv=None):
     ap.add_argument("--steps-per-eval", type=int, default=500)
     ap.add_argument("--num-gaussians", type=int, default=100000)
     ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--sync-budget", action="store_true",
+                    help="read the intersection count back every step instead of the sync-free speculative budget")
     ap.add_argument("--render-output", type=str, default=None,
                     help="also dump the eval views' renders (rgb/ + 16-bit mm depth/), like ns-render dataset")
     ap.add_argument("--output-dir", type=str, default="outputs")
@@ -141,6 +143,8 @@ def main(argv=None):
         os.makedirs(run_dir, exist_ok=True)
         with open(os.path.join(run_dir, "config.json"), "w") as f:
             json.dump(dict(vars(args), model=dataclasses.asdict(cfg), world_size=dp.world), f, indent=2)
+    if dp.world == 1 and not args.densify and not args.sync_budget:
+        model.enable_speculative_budget()     # no per-step host sync; overflow is detected late and replayed
     train_views = [views[i] for i in i_train]
     eval_views = [views[i] for i in i_eval] or train_views[:1]
     t0 = time.time()
@@ -148,11 +152,14 @@ def main(argv=None):
         view = train_views[dp.views_for_step(step, len(train_views))]
         model.train_step(view, dp if dp.world > 1 else None)
         if dp.rank == 0 and (step + 1) % args.steps_per_eval == 0:
+            model.flush()
             loss = model.loss_from(model.last["tile_loss"], model.last["ssim_sum"], view)
             print(f"step {step + 1}: " + " ".join(f"{k}={float(v):.5f}" for k, v in loss.items()) +
                   f"  {(step + 1 - 0) / (time.time() - t0):.1f} it/s", flush=True)
         if dp.rank == 0 and ((step + 1) % args.steps_per_save == 0 or step + 1 == args.max_num_iterations):
+            model.flush()
             torch.save(model.state_dict(), os.path.join(run_dir, f"step-{step + 1:09d}.ckpt"))
+    model.flush()
     if dp.world > 1:
         dp.assert_replicas_identical(model.params.flat)
     if dp.rank == 0:
