@@ -45,8 +45,9 @@ class GradSync:
     ``reduce_and_step`` is the pipelined form used by the trainer: the flat gradient buffer is cut
     into ``n_chunks`` contiguous ranges; their all-reduces are enqueued back to back on a side
     stream and the fused Adam of range c is enqueued on the compute stream behind an event that
-    fires when range c has been reduced -- so the optimizer (0.37 ms at 1 M Gaussians) runs under
-    the shadow of the collective (~1 ms for 236 MB on xGMI) instead of after it.
+    fires when range c has been reduced -- so the optimizer (~0.3 ms at 1 M Gaussians) runs under
+    the shadow of the collective (estimated >1 ms for 236 MB on xGMI) instead of after it.
+    ``gather_color_reduce_geom_and_step`` is the default of the trainer (see its docstring).
     """
 
     def __init__(self, rank: int = 0, world: int = 1, local_rank: int = 0, n_chunks: int = 8):
