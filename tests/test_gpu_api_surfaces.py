@@ -216,6 +216,22 @@ d = (ref.params.flat - model.params.flat).abs().max().item()
 d2 = (ref.params.flat - dense.params.flat).abs().max().item()
 assert d < 1e-6 and d2 < 1e-6, (d, d2)
 dp.barrier()
+# densification under data parallelism: statistics are reduced (sum, sum, max) and the split sampler
+# is seeded from the step, so both replicas refine identically
+from touch_gs_amd.densify import DensifyConfig
+dm = fresh()
+dm.enable_densification(DensifyConfig(warmup_length=2, refine_every=4, densify_grad_thresh=1e-5,
+                                      densify_size_thresh=0.02, cull_alpha_thresh=0.01, reset_alpha_every=0))
+for step in range(9):
+    dm.train_step(views[dp.views_for_step(step, 4)], dp)
+torch.cuda.synchronize()
+n = torch.tensor([dm.params.N], dtype=torch.int64)
+lo, hi = n.clone(), n.clone()
+dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+assert int(lo) == int(hi) and dm.params.N != N, (int(lo), int(hi), N)
+dp.assert_replicas_identical(dm.params.flat)
+dp.assert_replicas_identical(dm.optimizer.exp_avg_sq)
+dp.barrier()
 if dp.rank == 0: print("DP_OK", d)
 '''
 
