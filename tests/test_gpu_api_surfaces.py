@@ -301,6 +301,12 @@ def test_densification_clone_split_cull(dev):
     assert model.params.N == info["after"] and info["after"] != N
     assert model.optimizer.exp_avg.shape == model.params.flat.shape and model.optimizer.t == 8
     n1 = model.params.N
+    # a checkpoint taken after refinement restores into a model built with the original count
+    fresh_params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
+    resumed = DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=0), fresh_params)
+    resumed.load_state_dict(model.state_dict())
+    assert resumed.params.N == model.params.N != N and torch.equal(resumed.params.flat, model.params.flat)
+    assert torch.equal(resumed.optimizer.exp_avg_sq, model.optimizer.exp_avg_sq) and resumed.optimizer.t == model.optimizer.t
     for step in range(8, 12):   # training continues on the refined set (fused and unfused paths)
         model.train_step(views[step % 4])
     assert torch.isfinite(model.params.flat).all() and model.params.N == n1

@@ -369,7 +369,20 @@ class DepthGaussianSplattingModel:
                     optim=self.optimizer.state_dict(), config=dataclasses.asdict(self.config))
 
     def load_state_dict(self, sd):
-        assert sd["N"] == self.params.N and sd["K"] == self.params.K
+        """Restores parameters, Adam state and the step counter.  A checkpoint written after
+        densification holds a different number of Gaussians: the flat stores are then re-allocated
+        at the checkpoint's size (same SH storage degree required)."""
+        if sd["K"] != self.params.K:
+            raise ValueError(f"checkpoint stores {sd['K']} SH bases per Gaussian, the model {self.params.K}")
+        if sd["N"] != self.params.N:
+            dev = self.params.flat.device
+            self.params = GaussianParams.allocate(sd["N"], sd["K"], dev)
+            self.optimizer = FusedAdam(self.params, self.config.lrs())
+            self.budget = ops.IntersectBudget()
+            self._color_block = self._color_all = None
+            self._graphs = {}
+            if getattr(self, "density", None) is not None:
+                self.density.reset_stats(sd["N"], dev)
         self.params.flat.copy_(sd["flat"])
         self.step = sd["step"]
         self.optimizer.load_state_dict(sd["optim"])
