@@ -197,8 +197,9 @@ int tgs_project_bwd(const TgsCamera* cam /*[host]*/, int N, const float* means,
 
 /* K8+K9 fused (single-process training): projection/SH backward whose gradients go straight
  *     through the Adam update of the flat parameter buffer `params` (layout of TgsAdamSpec) and
- *     its moment buffers -- the 59-float gradient of a Gaussian never touches HBM.  Requires a
- *     dense SH tensor evaluated at its full degree (sh_stride == (sh_deg+1)^2, sh_deg 1 or 3).
+ *     its moment buffers -- the 59-float gradient of a Gaussian never touches HBM.  Requires an
+ *     SH tensor that stores 4 or 16 bases per Gaussian (sh_stride 4 or 16); sh_deg may be any
+ *     degree the storage holds (rows above it receive a zero gradient).
  *     Not usable when gradients must first be all-reduced across ranks. */
 int tgs_project_bwd_adam(const TgsCamera* cam /*[host]*/, int N, int sh_stride, int sh_deg,
                          float* params, float* exp_avg, float* exp_avg_sq,

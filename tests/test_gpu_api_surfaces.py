@@ -252,9 +252,11 @@ def test_data_parallel_train_step_two_ranks_one_gpu(dev, tmp_path):
     assert r.returncode == 0 and "DP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-@pytest.mark.parametrize("deg", [3, 1])
-def test_fused_backward_adam_equals_separate_kernels(dev, deg):
-    """tgs_project_bwd_adam == tgs_project_bwd followed by tgs_adam_step (same Adam arithmetic)."""
+@pytest.mark.parametrize("deg,interval", [(3, 0), (1, 0), (3, 1000), (3, 2)])
+def test_fused_backward_adam_equals_separate_kernels(dev, deg, interval):
+    """tgs_project_bwd_adam == tgs_project_bwd followed by tgs_adam_step (same Adam arithmetic);
+    interval > 0 ramps the ACTIVE degree below the stored one (1000: stays at 0; 2: 0,0,1 over the
+    three steps), exercising the zero-gradient rows of the fused kernel."""
     from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
     from touch_gs_amd.optim import GaussianParams
     from touch_gs_amd.scene import make_view, synthetic_gaussians
@@ -263,8 +265,9 @@ def test_fused_backward_adam_equals_separate_kernels(dev, deg):
     P, _ = synthetic_gaussians(N, W, H, deg, 99)
     def run(fuse, steps):
         params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
-        m = DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=0), params)
+        m = DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=interval), params)
         m.fuse_adam = fuse
+        assert m.optimizer.can_fuse_with_backward(m.active_sh_degree())
         for step in range(steps):
             m.train_step(views[step % 2])
         return m

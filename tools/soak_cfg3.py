@@ -11,7 +11,7 @@ params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAME
 model = DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=200), params)
 model.enable_speculative_budget()
 t0 = time.time()
-for step in range(3000):
+for step in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3000):
     v = views[step % 8]
     model.train_step(v)
     if (step + 1) % 500 == 0:

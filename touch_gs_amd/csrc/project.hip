@@ -485,7 +485,10 @@ __global__ __launch_bounds__(256) void k_project_bwd(
 // updated by their owner thread.
 // COLOR_ONLY (data-parallel training): `v_sh` receives the clamp-gated colour gradient [N,3] instead
 // of the SH gradient image; nothing is streamed out at the end.
-template <int DEG, bool FUSE_ADAM, bool COLOR_ONLY = false>
+// DEG is the ACTIVE SH degree, KS the number of bases each Gaussian STORES (KS >= (DEG+1)^2, 3*KS a
+// multiple of 4): while the trainer ramps the degree up, the rows above the active degree receive a
+// zero gradient (and, fused, a plain Adam step on it).
+template <int DEG, int KS, bool FUSE_ADAM, bool COLOR_ONLY = false>
 __global__ __launch_bounds__(256) void k_project_bwd_lds(
     CamK cam, int N, float* __restrict__ means, float* __restrict__ log_scales,
     float* __restrict__ quats, float* __restrict__ opac_logit, float* __restrict__ sh,
@@ -497,8 +500,9 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
   // overflowed frame: the pair index space is not backed by memory and the step must not touch the model
   if (ad_in.guard && ad_in.guard[1]) return;
   const AdamK ad = FUSE_ADAM ? adam_resolve(ad_in) : ad_in;
-  constexpr int K = (DEG + 1) * (DEG + 1);   // requires sh_stride == K here (3K % 4 == 0)
-  constexpr int ROW = 3 * K, RS = ROW + 4, F4 = ROW / 4;
+  constexpr int K = (DEG + 1) * (DEG + 1);   // active bases; sh_stride == KS here
+  static_assert(KS >= K && (3 * KS) % 4 == 0, "storage must hold the active degree in whole float4s");
+  constexpr int ROW = 3 * KS, RS = ROW + 4, F4 = ROW / 4;
   extern __shared__ float4 lds4[];
   float* lds = reinterpret_cast<float*>(lds4);
   const int tid = threadIdx.x;
@@ -576,11 +580,11 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
     // own row <- SH gradient (only this thread ever touches this row before the barrier)
 #pragma unroll
     for (int i = 0; i < (COLOR_ONLY ? 0 : F4); i++) {
-      float4 t;
-      t.x = Y[(4 * i) / 3] * vr[(4 * i) % 3];
-      t.y = Y[(4 * i + 1) / 3] * vr[(4 * i + 1) % 3];
-      t.z = Y[(4 * i + 2) / 3] * vr[(4 * i + 2) % 3];
-      t.w = Y[(4 * i + 3) / 3] * vr[(4 * i + 3) % 3];
+      float4 t;   // element e of the row belongs to basis e / 3, channel e % 3; inactive bases get 0
+      t.x = (4 * i) / 3 < K ? Y[(4 * i) / 3] * vr[(4 * i) % 3] : 0.f;
+      t.y = (4 * i + 1) / 3 < K ? Y[(4 * i + 1) / 3] * vr[(4 * i + 1) % 3] : 0.f;
+      t.z = (4 * i + 2) / 3 < K ? Y[(4 * i + 2) / 3] * vr[(4 * i + 2) % 3] : 0.f;
+      t.w = (4 * i + 3) / 3 < K ? Y[(4 * i + 3) / 3] * vr[(4 * i + 3) % 3] : 0.f;
       st4(row + 4 * i, t);
     }
     // ---- geometry backward (B.8) ----
@@ -793,6 +797,20 @@ __global__ __launch_bounds__(256) void k_sh_op(int N, int sh_stride, const float
   }
 }
 
+// the LDS-staged K8 variants exist for rows of 4 or 16 stored bases and any active degree they hold
+inline bool lds_k8_ok(int sh_deg, int sh_stride) {
+  return (sh_stride == 16 && sh_deg >= 0 && sh_deg <= 3) || (sh_stride == 4 && sh_deg >= 0 && sh_deg <= 1);
+}
+#define DISPATCH_DEG_KS(M, deg, ks)                                                              \
+  do {                                                                                           \
+    if ((ks) == 16) {                                                                            \
+      switch (deg) { case 0: M(0, 16); break; case 1: M(1, 16); break; case 2: M(2, 16); break;  \
+                     default: M(3, 16); break; }                                                 \
+    } else {                                                                                     \
+      if ((deg) == 0) M(0, 4); else M(1, 4);                                                     \
+    }                                                                                            \
+  } while (0)
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -862,19 +880,18 @@ extern "C" int tgs_project_bwd(const TgsCamera* cam, int N, const float* means,
   const CamK k = make_camk(cam);
   const dim3 grid((N + 255) / 256), block(256);
   hipStream_t s = (hipStream_t)stream;
-  // fast path: SH rows staged through LDS (needs a dense [N,K,3] tensor with 3K % 4 == 0)
-  if (partials && sh && v_sh && sh_deg >= 1 && sh_stride == (sh_deg + 1) * (sh_deg + 1) &&
-      (3 * sh_stride) % 4 == 0) {
+  // fast path: SH rows staged through LDS (storage of 4 or 16 bases, any active degree it holds)
+  if (partials && sh && v_sh && sh_deg >= 0 && lds_k8_ok(sh_deg, sh_stride)) {
     AdamK none{};
     none.guard = skip_if_overflow;
     const size_t lds_bytes = 256 * (size_t)(3 * sh_stride + 4) * sizeof(float);
-#define LAUNCH_LDS(D)                                                                            \
-  hipLaunchKernelGGL((k_project_bwd_lds<D, false>), grid, block, lds_bytes, s, k, N,             \
+#define LAUNCH_LDS(D, KS)                                                                        \
+  hipLaunchKernelGGL((k_project_bwd_lds<D, KS, false>), grid, block, lds_bytes, s, k, N,         \
                      const_cast<float*>(means), const_cast<float*>(log_scales),                  \
                      const_cast<float*>(quats), const_cast<float*>(opac_logit),                  \
                      const_cast<float*>(sh), splats, group_base, partials, v_means, v_log_scales,\
                      v_quats, v_opac_logit, v_sh, v_xy, none, (float*)nullptr, (float*)nullptr)
-    if (sh_deg == 3) LAUNCH_LDS(3); else LAUNCH_LDS(1);
+    DISPATCH_DEG_KS(LAUNCH_LDS, sh_deg, sh_stride);
 #undef LAUNCH_LDS
     TGS_CHECK_LAUNCH();
     return TGS_OK;
@@ -903,8 +920,8 @@ extern "C" int tgs_project_bwd_adam(const TgsCamera* cam, int N, int sh_stride, 
   TGS_CHECK_ARG(camera_ok(cam), "bad camera");
   if (N <= 0) return TGS_OK;
   TGS_CHECK_ARG(params && exp_avg && exp_avg_sq && spec && splats && group_base && partials, "null pointer");
-  TGS_CHECK_ARG((sh_deg == 3 || sh_deg == 1) && sh_stride == (sh_deg + 1) * (sh_deg + 1),
-                "fused K8+Adam needs a dense SH tensor at its full degree (1 or 3)");
+  TGS_CHECK_ARG(sh_deg >= 0 && lds_k8_ok(sh_deg, sh_stride),
+                "fused K8+Adam needs an SH tensor storing 4 or 16 bases per Gaussian (degree 1 or 3)");
   const CamK k = make_camk(cam);
   AdamK a = make_adamk(N, sh_stride, spec, 1.0f);
   a.guard = skip_if_overflow;
@@ -916,12 +933,12 @@ extern "C" int tgs_project_bwd_adam(const TgsCamera* cam, int N, int sh_stride, 
   const dim3 grid((N + 255) / 256), block(256);
   const size_t lds_bytes = 256 * (size_t)(3 * sh_stride + 4) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
-#define LAUNCH_F(D)                                                                              \
-  hipLaunchKernelGGL((k_project_bwd_lds<D, true>), grid, block, lds_bytes, s, k, N, means,       \
+#define LAUNCH_F(D, KS)                                                                          \
+  hipLaunchKernelGGL((k_project_bwd_lds<D, KS, true>), grid, block, lds_bytes, s, k, N, means,   \
                      log_scales, quats, opac, sh, splats, group_base, partials, (float*)nullptr, \
                      (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, v_xy, a,\
                      exp_avg, exp_avg_sq)
-  if (sh_deg == 3) LAUNCH_F(3); else LAUNCH_F(1);
+  DISPATCH_DEG_KS(LAUNCH_F, sh_deg, sh_stride);
 #undef LAUNCH_F
   TGS_CHECK_LAUNCH();
   return TGS_OK;
@@ -1024,16 +1041,16 @@ extern "C" int tgs_project_bwd_color(const TgsCamera* cam, int N, const float* m
   const CamK k = make_camk(cam);
   const dim3 grid((N + 255) / 256), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (sh_deg >= 1 && sh_stride == (sh_deg + 1) * (sh_deg + 1) && (3 * sh_stride) % 4 == 0) {
+  if (lds_k8_ok(sh_deg, sh_stride)) {
     AdamK none{};
     const size_t lds_bytes = 256 * (size_t)(3 * sh_stride + 4) * sizeof(float);
-#define LAUNCH_C(D)                                                                              \
-  hipLaunchKernelGGL((k_project_bwd_lds<D, false, true>), grid, block, lds_bytes, s, k, N,       \
+#define LAUNCH_C(D, KS)                                                                          \
+  hipLaunchKernelGGL((k_project_bwd_lds<D, KS, false, true>), grid, block, lds_bytes, s, k, N,   \
                      const_cast<float*>(means), const_cast<float*>(log_scales),                  \
                      const_cast<float*>(quats), const_cast<float*>(opac_logit),                  \
                      const_cast<float*>(sh), splats, group_base, partials, v_means, v_log_scales,\
                      v_quats, v_opac_logit, v_color, v_xy, none, (float*)nullptr, (float*)nullptr)
-    if (sh_deg == 3) LAUNCH_C(3); else LAUNCH_C(1);
+    DISPATCH_DEG_KS(LAUNCH_C, sh_deg, sh_stride);
 #undef LAUNCH_C
     TGS_CHECK_LAUNCH();
     return TGS_OK;

@@ -131,8 +131,9 @@ class FusedAdam:
         self.step_range(0, -1, grad_scale, guard)
 
     def can_fuse_with_backward(self, sh_deg: int) -> bool:
-        """tgs_project_bwd_adam needs the SH tensor evaluated at its full (dense) degree 1 or 3."""
-        return sh_deg in (1, 3) and self.p.K == (sh_deg + 1) ** 2
+        """tgs_project_bwd_adam needs 4 or 16 stored SH bases per Gaussian (storage degree 1 or 3);
+        the active degree may be anything the storage holds (rows above it get a zero gradient)."""
+        return self.p.K in (4, 16) and 0 <= sh_deg and (sh_deg + 1) ** 2 <= self.p.K
 
     def backward_and_step(self, cam, sh_deg: int, splats, group_base, partials, want_v_xy: bool = False,
                           begin: bool = True, guard=None):
