@@ -31,6 +31,53 @@ def test_library_exports_every_declared_symbol():
     assert lib.tgs_version() == 100
 
 
+def _declared_prototypes():
+    """name -> list of parameter kinds ('ptr' | 'int' | 'int64' | 'float' | 'size') parsed from the header."""
+    txt = open(os.path.join(ROOT, "include", "tgs.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(?:int|size_t|const char\s*\*|void)\s+(tgs_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
+        name, args = m.group(1), " ".join(m.group(2).split())
+        kinds = []
+        if args not in ("", "void"):
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    kinds.append("ptr")
+                elif a.startswith("int64_t"):
+                    kinds.append("int64")
+                elif a.startswith("float"):
+                    kinds.append("float")
+                elif a.startswith("size_t"):
+                    kinds.append("size")
+                elif a.startswith("int"):
+                    kinds.append("int")
+                else:
+                    raise AssertionError(f"unparsed parameter {a!r} of {name}")
+        protos[name] = kinds
+    return protos
+
+
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Arity and parameter kinds of every ctypes signature equal the C prototype in include/tgs.h
+    (a drifted signature would pass garbage through the ABI without any error)."""
+    from touch_gs_amd import _lib
+    protos = _declared_prototypes()
+    assert set(protos) == set(_lib.SIGNATURES)
+    def kind(t):
+        if t in (C.c_int, C.c_int32):
+            return "int"
+        if t is C.c_int64:
+            return "int64"
+        if t is C.c_float:
+            return "float"
+        if t is C.c_size_t:
+            return "size"
+        return "ptr"          # c_void_p, c_char_p, POINTER(...)
+    for name, (restype, argtypes) in _lib.SIGNATURES.items():
+        assert [kind(t) for t in argtypes] == protos[name], (name, [kind(t) for t in argtypes], protos[name])
+
+
 def test_struct_layouts_match_header():
     from touch_gs_amd import _lib
     assert C.sizeof(_lib.TgsCamera) == 16 * 4 + 4 * 4 + 2 * 4 + 2 * 4 + 3 * 4 + 4
