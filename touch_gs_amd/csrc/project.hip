@@ -516,7 +516,13 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
     for (int f0 = tid; f0 < nf; f0 += 256 * 4) {
       float4 t[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) if (f0 + 256 * u < nf) t[u] = ld4(sh + blk + 4 * (size_t)(f0 + 256 * u));
+      for (int u = 0; u < 4; u++)
+        if (f0 + 256 * u < nf) {
+          // fused: the row is read again by the Adam stream below, keep it cached; otherwise this is
+          // the only read of the step
+          const float* src = sh + blk + 4 * (size_t)(f0 + 256 * u);
+          t[u] = FUSE_ADAM ? ld4(src) : ld4_nt(src);
+        }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int f = f0 + 256 * u;
