@@ -83,6 +83,30 @@ class RefC:
         o["alpha"] = 1 - o["final_T"]
         return o
 
+    def blend_margin(self, xy, conic, opac, gid, ts, cam, W, H):
+        """Per-pixel decision margin (see ref_blend_margin_range) -> float64 [H,W]."""
+        xy, conic, opac = map(self._r, (xy, conic, opac))
+        gid = np.ascontiguousarray(gid, np.int32)
+        ts = np.ascontiguousarray(ts, np.int64)
+        m = np.zeros((H, W), np.float64)
+        self.lib.ref_blend_margin_range(self._p(xy), self._p(conic), self._p(opac), self._p(gid), self._p(ts),
+                                        self._p(cam), C.c_int(W), C.c_int(H), self._p(m), C.c_int(0),
+                                        C.c_int(((W + 15) // 16) * ((H + 15) // 16)))
+        return m
+
+    def dropped_pairs_max_alpha(self, xy, conic, opac, rect, tiles_hit, tight, cam, W, H):
+        """-> (max o*exp(-sigma) per Gaussian over the tiles of `rect` outside `tight`, #dropped pairs)."""
+        xy, conic, opac = map(self._r, (xy, conic, opac))
+        rect = np.ascontiguousarray(rect, np.int32)
+        tight = np.ascontiguousarray(tight, np.int32)
+        tiles_hit = np.ascontiguousarray(tiles_hit, np.int32)
+        out = np.zeros(xy.shape[0], self.dt)
+        cnt = np.zeros(1, np.int64)
+        self.lib.ref_dropped_pairs_max_alpha(C.c_int(xy.shape[0]), self._p(xy), self._p(conic), self._p(opac),
+                                             self._p(rect), self._p(tiles_hit), self._p(tight), self._p(cam),
+                                             C.c_int(W), C.c_int(H), self._p(out), self._p(cnt))
+        return out, int(cnt[0])
+
     def blend_bwd(self, xy, conic, opac, rgb, depth, gid, ts, cam, W, H, final_T, final_idx,
                   v_rgb_img, v_depth_img, v_alpha_img, tile_range=None):
         xy, conic, opac, rgb, depth, final_T, v_rgb_img, v_depth_img, v_alpha_img = map(

@@ -253,6 +253,73 @@ void ref_blend_fwd(const real *xy, const real *conic, const real *opac, const re
     ref_blend_fwd_range(xy, conic, opac, rgb, depth, sorted_gid, tile_start, cam, W, H, o_rgb, o_depth, o_T, o_idx, 0, TW * TH);
 }
 
+/* Per-pixel decision margin of the forward blend (test aid for full-size parity): the smallest
+ * relative distance of any threshold test that B.6 actually evaluates for the pixel (alpha vs 1/255,
+ * T' vs 1e-4) from its threshold.  A pixel with a tiny margin is decision-ambiguous under fp32
+ * rounding; parity is asserted on the others.  Same loop as ref_blend_fwd_range. */
+void ref_blend_margin_range(const real *xy, const real *conic, const real *opac,
+                   const int32_t *sorted_gid, const int64_t *tile_start, const cam_t *cam, int W, int H,
+                   double *o_margin, int t0, int t1) {
+    int TW = (W + BLK - 1) / BLK;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int t = t0; t < t1; t++) {
+        int ty = t / TW, tx = t % TW;
+        int64_t s = tile_start[t], e = tile_start[t + 1];
+        for (int py = ty * BLK; py < (ty + 1) * BLK && py < H; py++)
+            for (int px = tx * BLK; px < (tx + 1) * BLK && px < W; px++) {
+                real fxp = px + cam->pc, fyp = py + cam->pc;
+                real T = 1; double m = 1e30;
+                for (int64_t k = s; k < e; k++) {
+                    int g = sorted_gid[k];
+                    real dx = xy[2 * g] - fxp, dy = xy[2 * g + 1] - fyp;
+                    real sig = (real)0.5 * (conic[3 * g] * dx * dx + conic[3 * g + 2] * dy * dy) + conic[3 * g + 1] * dx * dy;
+                    if (sig < 0) continue;
+                    real araw = opac[g] * exp(-sig), al = araw > ALPHA_MAX ? ALPHA_MAX : araw;
+                    double ma = fabs((double)araw - (double)ALPHA_MIN) / (double)ALPHA_MIN;
+                    if (ma < m) m = ma;
+                    if (al < ALPHA_MIN) continue;
+                    real Tn = T * (1 - al);
+                    double mt = fabs((double)Tn - (double)T_STOP) / (double)T_STOP;
+                    if (mt < m) m = mt;
+                    if (Tn <= T_STOP) break;
+                    T = Tn;
+                }
+                o_margin[(size_t)py * W + px] = m;
+            }
+    }
+}
+
+/* Test aid for the product's tight tile rectangle: for every Gaussian, the
+ * largest o*exp(-sigma) over the pixel centres of all tiles that lie in the NORMATIVE B.4 rect
+ * `rect` but outside `tight` (both x0,y0,x1,y1).  Output preservation requires it to stay below
+ * 1/255 (B.6 skips such pixels).  o_count receives the number of dropped (tile, Gaussian) pairs. */
+void ref_dropped_pairs_max_alpha(int N, const real *xy, const real *conic, const real *opac,
+                   const int32_t *rect, const int32_t *tiles_hit, const int32_t *tight,
+                   const cam_t *cam, int W, int H, real *o_max_alpha, int64_t *o_count) {
+    int64_t count = 0;
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : count)
+    for (int i = 0; i < N; i++) {
+        real best = 0;
+        if (tiles_hit[i])
+            for (int ty = rect[4 * i + 1]; ty < rect[4 * i + 3]; ty++)
+                for (int tx = rect[4 * i]; tx < rect[4 * i + 2]; tx++) {
+                    if (tx >= tight[4 * i] && tx < tight[4 * i + 2] && ty >= tight[4 * i + 1] && ty < tight[4 * i + 3])
+                        continue;
+                    count++;
+                    for (int py = ty * BLK; py < (ty + 1) * BLK && py < H; py++)
+                        for (int px = tx * BLK; px < (tx + 1) * BLK && px < W; px++) {
+                            real dx = xy[2 * i] - (px + cam->pc), dy = xy[2 * i + 1] - (py + cam->pc);
+                            real sig = (real)0.5 * (conic[3 * i] * dx * dx + conic[3 * i + 2] * dy * dy) + conic[3 * i + 1] * dx * dy;
+                            if (sig < 0) continue;
+                            real al = opac[i] * exp(-sig);
+                            if (al > best) best = al;
+                        }
+                }
+        o_max_alpha[i] = best;
+    }
+    *o_count = count;
+}
+
 /* B.7 backward blend.  v_rgb_img [H,W,3], v_depth_img [H,W] (w.r.t. depth_acc), v_alpha_img [H,W].
  * Accumulates (+=) into v_xy [N,2], v_conic [N,3], v_opac [N], v_rgb [N,3], v_depth [N] (caller zeroes). */
 void ref_blend_bwd_range(const real *xy, const real *conic, const real *opac, const real *rgb, const real *depth,

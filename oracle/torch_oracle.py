@@ -226,7 +226,10 @@ def blend(xy, conic, opac, rgb, depth, sorted_gid: np.ndarray, tile_start: np.nd
             a, b, c = conic[g, 0][:, None], conic[g, 1][:, None], conic[g, 2][:, None]
             sigma = 0.5 * (a * dx * dx + c * dy * dy) + b * dx * dy
             araw = opac[g][:, None] * torch.exp(-sigma)
-            alpha = torch.clamp(araw, max=ALPHA_MAX)
+            # B.6 value min(0.999, o e^-sigma); B.7 gradient: "no special-casing of the 0.999 clamp",
+            # i.e. the clamp is straight-through (v_sigma = -o e^-sigma v_alpha, v_o = e^-sigma
+            # v_alpha also where the clamp is active) -- torch.clamp alone would zero it there.
+            alpha = araw + (torch.clamp(araw, max=ALPHA_MAX) - araw).detach()
             skip = (sigma.detach() < 0) | (alpha.detach() < ALPHA_MIN)
             a_eff = torch.where(skip, torch.zeros_like(alpha), alpha)
             Tp = torch.cumprod(1 - a_eff, dim=0)  # T' after each element

@@ -8,7 +8,7 @@ import torch
 
 from oracle import torch_oracle as O
 from oracle.ref_c import RefC
-from tests.util import scene
+from tests.util import clamp_scene, count_clamped, scene
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "raster_selforacle.npz")
 
@@ -18,13 +18,20 @@ def refc():
     return RefC("f64")
 
 
-@pytest.mark.parametrize("N,W,H,deg,seed", [(300, 80, 48, 3, 11), (150, 50, 35, 1, 12), (60, 32, 32, 0, 13)])
-def test_c_and_torch_restatements_agree(refc, N, W, H, deg, seed):
-    P, cam = scene(N, W, H, deg, seed)
+@pytest.mark.parametrize("N,W,H,deg,seed,clamp", [(300, 80, 48, 3, 11, False), (150, 50, 35, 1, 12, False),
+                                                   (60, 32, 32, 0, 13, False), (300, 80, 48, 3, 11, True),
+                                                   (200, 64, 64, 2, 14, True)])
+def test_c_and_torch_restatements_agree(refc, N, W, H, deg, seed, clamp):
+    """The two independent restatements agree in value AND gradient -- also ON the alpha = 0.999
+    clamp, where App. B.7 prescribes a pass-through gradient (clamp=True scenes hold > 50 clamped
+    (pixel, Gaussian) pairs; torch.clamp's own autograd would disagree there by ~1e-3 relative)."""
+    P, cam = (clamp_scene if clamp else scene)(N, W, H, deg, seed)
     for k in P:
         P[k].requires_grad_(True)
     out, pr, gid, ts = O.render(P["means"], P["log_scales"], P["quats"], P["opac_logit"], P["sh"], cam, deg)
     n = lambda t: t.detach().numpy()
+    if clamp:
+        assert count_clamped(pr, gid, ts, cam) > 50
     cb = refc.cam_block(cam.viewmat.numpy(), cam.fx, cam.fy, cam.cx, cam.cy, bg=cam.bg)
     pc = refc.project_fwd(n(P["means"]), n(P["log_scales"]), n(P["quats"]), n(P["opac_logit"]), n(P["sh"]), deg, cb, W, H)
     v = pr["valid"].numpy()

@@ -252,8 +252,9 @@ def test_data_parallel_train_step_two_ranks_one_gpu(dev, tmp_path):
     assert r.returncode == 0 and "DP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-@pytest.mark.parametrize("deg,interval", [(3, 0), (1, 0), (3, 1000), (3, 2)])
-def test_fused_backward_adam_equals_separate_kernels(dev, deg, interval):
+@pytest.mark.parametrize("deg,interval,clamp", [(3, 0, False), (1, 0, False), (3, 1000, False), (3, 2, False),
+                                                 (3, 0, True)])
+def test_fused_backward_adam_equals_separate_kernels(dev, deg, interval, clamp):
     """tgs_project_bwd_adam == tgs_project_bwd followed by tgs_adam_step (same Adam arithmetic);
     interval > 0 ramps the ACTIVE degree below the stored one (1000: stays at 0; 2: 0,0,1 over the
     three steps), exercising the zero-gradient rows of the fused kernel."""
@@ -263,6 +264,9 @@ def test_fused_backward_adam_equals_separate_kernels(dev, deg, interval):
     N, W, H = 4100, 160, 96   # N not a multiple of 256: exercises the ragged last group
     views = [make_view(N, W, H, deg, 7, dev, view=v, n_views=4) for v in range(2)]
     P, _ = synthetic_gaussians(N, W, H, deg, 99)
+    if clamp:   # alpha = 0.999 clamp regime (App. B.7 pass-through gradient): 1 in 5 at opacity logit 12
+        P["opac_logit"][::5] = 12.0
+        P["log_scales"][::5] += 1.5
     def run(fuse, steps):
         params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
         m = DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=interval), params)

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import torch_oracle as O
-from tests.util import amd_cam, rect_from, relerr, scene, splat_fields, to_dev
+from tests.util import amd_cam, clamp_scene, count_clamped, rect_from, relerr, scene, splat_fields, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -67,9 +67,9 @@ def test_bin_sort_exact(dev, N, W, H, seed):
     assert np.array_equal(sg[:n].cpu().numpy().astype(np.int64), gid)
 
 
-def _blend_inputs(dev, N, W, H, deg, seed, **kw):
+def _blend_inputs(dev, N, W, H, deg, seed, clamp=False, **kw):
     from touch_gs_amd import ops
-    P, cam = scene(N, W, H, deg, seed, **kw)
+    P, cam = (clamp_scene if clamp else scene)(N, W, H, deg, seed, **kw)
     D, sp, _ = _project(dev, P, cam, deg)
     acam = amd_cam(cam)
     gb, ts, sg, st = ops.bin_sort(acam, sp)
@@ -77,10 +77,11 @@ def _blend_inputs(dev, N, W, H, deg, seed, **kw):
     return P, cam, acam, D, sp, gb, ts, sg, n
 
 
-@pytest.mark.parametrize("N,W,H,deg,seed", [(3000, 160, 96, 3, 11), (600, 50, 35, 1, 12), (8000, 256, 144, 0, 13)])
-def test_rasterize_fwd(dev, N, W, H, deg, seed):
+@pytest.mark.parametrize("N,W,H,deg,seed,clamp", [(3000, 160, 96, 3, 11, False), (600, 50, 35, 1, 12, False),
+                                                   (8000, 256, 144, 0, 13, False), (2000, 128, 80, 2, 14, True)])
+def test_rasterize_fwd(dev, N, W, H, deg, seed, clamp):
     from touch_gs_amd import ops
-    P, cam, acam, D, sp, gb, ts, sg, n = _blend_inputs(dev, N, W, H, deg, seed)
+    P, cam, acam, D, sp, gb, ts, sg, n = _blend_inputs(dev, N, W, H, deg, seed, clamp=clamp)
     rgb, depth, fT, fidx = ops.rasterize_fwd(acam, sp, sg, ts, want_idx=True)
     rgb2, depth2, fT2, none_idx = ops.rasterize_fwd(acam, sp, sg, ts)
     assert none_idx is None and torch.equal(rgb, rgb2) and torch.equal(depth, depth2) and torch.equal(fT, fT2)
@@ -98,10 +99,14 @@ def test_rasterize_fwd(dev, N, W, H, deg, seed):
     assert np.abs(rgb.cpu().numpy() - out["rgb"].numpy()).max() < 0.02
 
 
-@pytest.mark.parametrize("N,W,H,deg,seed", [(2000, 128, 80, 3, 21), (500, 50, 35, 0, 22)])
-def test_rasterize_bwd(dev, N, W, H, deg, seed):
+@pytest.mark.parametrize("N,W,H,deg,seed,clamp", [(2000, 128, 80, 3, 21, False), (500, 50, 35, 0, 22, False),
+                                                   (2000, 128, 80, 3, 23, True), (600, 64, 64, 1, 24, True)])
+def test_rasterize_bwd(dev, N, W, H, deg, seed, clamp):
+    """clamp=True: a third of the Gaussians have opacity > 0.999 and e^2 larger axes, so that
+    thousands of (pixel, Gaussian) pairs sit ON the alpha = 0.999 clamp, whose gradient App. B.7
+    passes through (K7: raster.hip `q *= max(exp2(-s)/0.999, 1)`)."""
     from touch_gs_amd import ops
-    P, cam, acam, D, sp, gb, ts, sg, n = _blend_inputs(dev, N, W, H, deg, seed)
+    P, cam, acam, D, sp, gb, ts, sg, n = _blend_inputs(dev, N, W, H, deg, seed, clamp=clamp)
     rgb, depth, fT, fidx = ops.rasterize_fwd(acam, sp, sg, ts)
     g = torch.Generator().manual_seed(seed)
     v_rgb = torch.randn(H, W, 3, generator=g, dtype=torch.float64)
@@ -111,6 +116,9 @@ def test_rasterize_bwd(dev, N, W, H, deg, seed):
                                     v_rgb.float().to(dev), v_d.float().to(dev), v_a.float().to(dev))
     v = ops.reduce_partials(acam, sp, gb, partials).cpu().double()
     f = splat_fields(sp)
+    if clamp:
+        n_cl = count_clamped(f, sg[:n].cpu().numpy(), ts.cpu().numpy(), cam)
+        assert n_cl >= 1000, n_cl
     leaves = {k: f[k].clone().requires_grad_(True) for k in ("xy", "conic", "opac", "rgb", "depth")}
     out = O.blend(leaves["xy"], leaves["conic"], leaves["opac"], leaves["rgb"], leaves["depth"],
                   sg[:n].cpu().numpy().astype(np.int64), ts.cpu().numpy().astype(np.int64), cam, want_margin=True)
@@ -162,11 +170,13 @@ def test_project_bwd(dev, N, W, H, deg, seed):
     assert torch.allclose(vxy.cpu().double(), v_splats[:, 0:2], atol=1e-6)
 
 
-def test_end_to_end_render_and_grads(dev):
-    """Whole pipeline against the fp64 oracle; statistical because fp32 flips a few decisions."""
+@pytest.mark.parametrize("clamp", [False, True])
+def test_end_to_end_render_and_grads(dev, clamp):
+    """Whole pipeline against the fp64 oracle; statistical because fp32 flips a few decisions.
+    clamp=True puts >= 10 % of the Gaussians at opacity logit 12 (alpha clamp regime, B.7)."""
     from touch_gs_amd import ops
     N, W, H, deg = 4000, 192, 112, 3
-    P, cam = scene(N, W, H, deg, 41)
+    P, cam = (clamp_scene(N, W, H, deg, 42, frac=5, grow=1.5) if clamp else scene(N, W, H, deg, 41))
     D = to_dev(P, dev)
     for t in D.values():
         t.requires_grad_(True)
@@ -175,6 +185,8 @@ def test_end_to_end_render_and_grads(dev):
     Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
     out, pr, gid, ts = O.render(Pg["means"], Pg["log_scales"], Pg["quats"], Pg["opac_logit"], Pg["sh"], cam, deg,
                                 want_margin=True)
+    if clamp:
+        assert count_clamped(pr, gid, ts, cam) >= 1000
     er = relerr(rgb.detach().cpu().numpy(), out["rgb"].detach().numpy(), floor=1e-2)
     ed = relerr(depth.detach().cpu().numpy(), out["depth_acc"].detach().numpy(), floor=1e-2)
     assert np.quantile(er, 0.99) < TOL and np.quantile(ed, 0.99) < TOL, (np.quantile(er, 0.99), np.quantile(ed, 0.99))
