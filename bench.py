@@ -27,6 +27,31 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E vendor peak (MI355X_MICROARCH.md); ~6290 measured copy ceiling
 
 
+CONFIGS = {  # BASELINE.json configs (SURVEY 8(d) seeds) + the clustered stress scene of DESIGN.md
+    "cfg2": dict(gaussians=100_000, width=800, height=800, seed=1235,
+                 label="configs[1]: 100k synthetic Gaussians, 800x800"),
+    "cfg3": dict(gaussians=1_000_000, width=1920, height=1080, seed=1236,
+                 label="configs[2]: 1M Gaussians, 1080p"),
+    "cfg5": dict(gaussians=5_000_000, width=3840, height=2160, seed=1238,
+                 label="configs[4] (per-GPU part): 5M Gaussians, SH degree 3, 4K"),
+    "clustered": dict(gaussians=1_000_000, width=1920, height=1080, seed=1236, clustered=True,
+                      label="stress: 1M Gaussians, 1080p, 80 % inside the central 10 % of the image"),
+}
+
+
+def survey_bytes(N, I, P, T, K):
+    """SURVEY.md section 8(d) compulsory-traffic model (the coverage contract's per-unit figures):
+    B_fwd = N(A+48+8+20) + I(12+24+8+44) + 24P + 16T,  B_bwd = 84 I + 28 P + (2A+40) N,
+    B_adam = 28 (A/4) N, split per kernel of this build.  SSIM is not part of 8(d): layout bytes."""
+    A = 44 + 12 * K
+    return {"project_bin_sort": N * (A + 48 + 8 + 20) + I * (12 + 24 + 8) + 16 * T,
+            "raster_fwd": 44 * I + 24 * P,
+            "ssim": P * (24 + 36 + 36 + 12 + 24),
+            "raster_bwd": 84 * I + 28 * P,
+            "project_bwd": (2 * A + 40) * N,
+            "adam": 28 * (A // 4) * N}
+
+
 def algorithmic_bytes(N, I, P, T, K):
     """Compulsory-traffic model of THIS build's data layout, bytes/step."""
     A = 44 + 12 * K                      # parameter bytes per Gaussian
@@ -82,7 +107,7 @@ def valu_utilisation(kern_ms, N, W, H, deg):
     return None
 
 
-def cpu_baseline(N, W, H, deg, seed, frac=None):
+def cpu_baseline(N, W, H, deg, seed, frac=None, clustered=False):
     """Build's own scalar C restatement (oracle/ref_raster.c, fp32, OpenMP over tiles) timed on the
     host cores: full projection / binning / projection-backward, compositing fwd+bwd on the first
     1/frac of the tiles and extrapolated.  The reference's rasterizer source is unavailable."""
@@ -92,7 +117,11 @@ def cpu_baseline(N, W, H, deg, seed, frac=None):
     R = RefC("f32")
     if frac is None:  # ~10-30 s of CPU work: whole image on a many-core host, a band of tiles otherwise
         frac = max(1, 64 // max(R.num_threads(), 1))
-    P, c = O.synthetic_scene(N, W, H, deg, seed, dtype=torch.float32)
+    if clustered:   # the oracle's generator restates the iid recipe only: take the product's scene tensors
+        from touch_gs_amd.scene import synthetic_gaussians
+        P, c = synthetic_gaussians(N, W, H, deg, seed, clustered=True)
+    else:
+        P, c = O.synthetic_scene(N, W, H, deg, seed, dtype=torch.float32)
     n = lambda t: t.numpy()
     cam = R.cam_block(O.orbit_viewmat(0, 8).numpy(), c["fx"], c["fy"], c["cx"], c["cy"])
     t0 = time.perf_counter()
@@ -128,14 +157,27 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--gaussians", type=int, default=1_000_000)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg3",
+                    help="workload: cfg3 = the configuration BASELINE.json's metric is quoted on (default)")
+    ap.add_argument("--gaussians", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--views", type=int, default=8)
-    ap.add_argument("--seed", type=int, default=1236)  # cfg3 seed of SURVEY 8(d)
+    ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    preset = CONFIGS[args.config]
+    custom = []
+    for k in ("gaussians", "width", "height", "seed"):
+        if getattr(args, k) is None:
+            setattr(args, k, preset[k])
+        elif getattr(args, k) != preset[k]:
+            custom.append(f"{k}={getattr(args, k)}")
+    clustered = bool(preset.get("clustered"))
+    workload = preset["label"] if not custom else f"custom ({', '.join(custom)}; base {args.config})"
+    workload += (", full Touch-GS train loop (RGB L1/SSIM + tactile depth/uncertainty loss), "
+                 "one view per rank per iter")
 
     from touch_gs_amd import ops, parallel
     from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
@@ -151,12 +193,13 @@ def main():
     K = (deg + 1) ** 2
 
     # ---- setup (untimed): scene, replicas, views, intersection capacity ----
-    P, intr = synthetic_gaussians(N, W, H, deg, args.seed)
+    P, intr = synthetic_gaussians(N, W, H, deg, args.seed, clustered=clustered)
     params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
     cfg = ModelConfig(sh_degree=deg, sh_degree_interval=0, depth_loss_mult=0.2,
                       depth_loss_type="DEPTH_UNCERTAINTY_WEIGHTED_LOSS", uncertainty_weight=1.0)
     model = DepthGaussianSplattingModel(cfg, params)
-    views = [make_view(N, W, H, deg, args.seed, dev, view=v, n_views=args.views) for v in range(args.views)]
+    views = [make_view(N, W, H, deg, args.seed, dev, view=v, n_views=args.views, clustered=clustered)
+             for v in range(args.views)]
     for v in views:
         v.valid_count()
     n_isect = []
@@ -170,7 +213,7 @@ def main():
     torch.cuda.empty_cache()
 
     def step(i):
-        model.train_step(views[dp.views_for_step(i, len(views))], dp if dp.world > 1 else None)
+        model.train_step(views[dp.views_for_step(i, len(views))], dp if dp.active else None)
 
     for i in range(args.warmup):
         step(i)
@@ -184,7 +227,11 @@ def main():
     dp.barrier()
     torch.cuda.synchronize()
     elapsed = dp.max_over_ranks(time.perf_counter() - t0)
-    model.budget.check()  # raises if any timed frame overflowed its intersection buffer
+    model.budget.check()  # raises if ANY timed frame overflowed its intersection buffer (sticky word)
+    replicas_identical = None
+    if dp.world > 1:
+        dp.assert_replicas_identical(model.params.flat)   # raises on divergence
+        replicas_identical = True
     ms_per_step = elapsed / args.steps * 1e3
     value = args.steps * dp.world / elapsed
 
@@ -245,31 +292,42 @@ def main():
         render_ms = (time.perf_counter() - r0) / rr * 1e3
 
         T = view.cam.num_tiles
-        ab = algorithmic_bytes(N, I, W * H, T, K)
+        longest = int((ts[1:] - ts[:-1]).max())
+        ab = algorithmic_bytes(N, I, W * H, T, K)   # this build's data layout
+        sb = survey_bytes(N, I, W * H, T, K)        # the contract's per-unit bytes
         dom = max(kern_ms, key=kern_ms.get)
-        achieved = ab[dom] / (kern_ms[dom] * 1e-3) / 1e9
+        achieved = sb[dom] / (kern_ms[dom] * 1e-3) / 1e9
+        achieved_layout = ab[dom] / (kern_ms[dom] * 1e-3) / 1e9
         step_bytes = sum(ab.values())
+        fwd_bwd_ms = sum(kern_ms[k] for k in names[:5] if k != "ssim")
+        fwd_bwd_bytes = sum(sb[k] for k in names[:5] if k != "ssim")
         out = {
-            "metric": "train iters/s (whole-job views/s) + render Mpix/s, 1M Gaussians @ 1080p",
+            "metric": "train iters/s (whole-job views/s) + render Mpix/s, 1M Gaussians @ 1080p"
+                      if args.config == "cfg3" and not custom else "train iters/s (whole-job views/s) + render Mpix/s",
             "value": round(value, 3), "unit": "iters/s",
             "n_gpus": dp.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "render_mpix_s": round(W * H / (render_ms * 1e-3) / 1e6, 1),
-            "config": {"workload": "configs[2]: 1M Gaussians, 1080p, full Touch-GS train loop "
-                                   "(RGB L1/SSIM + tactile depth/uncertainty loss), one view per rank per iter",
+            "config": {"workload": workload, "name": args.config if not custom else "custom",
                        "gaussians": N, "width": W, "height": H, "sh_degree": deg, "views": args.views,
-                       "intersections": I, "tiles": T, "parallelism": f"dp{dp.world}",
+                       "intersections": I, "tiles": T, "longest_tile_list": longest, "parallelism": f"dp{dp.world}",
                        "depth_loss_type": cfg.depth_loss_type},
             "kernel_ms": {k: round(v, 4) for k, v in kern_ms.items()},
+            # dominant kernel: `achieved`/`frac` use SURVEY 8(d)'s algorithmic bytes (the contract);
+            # the *_layout figures use this build's own record sizes
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": measured_traffic(dom, N, W, H, deg),
-                         "algorithmic_bytes": ab[dom]},
+                         "traffic": measured_traffic(dom, N, W, H, deg) if args.config == "cfg3" and not custom else None,
+                         "algorithmic_bytes": sb[dom], "bytes_model": "SURVEY 8(d)",
+                         "achieved_layout": round(achieved_layout, 1), "frac_layout": round(achieved_layout / HBM_PEAK_GBS, 4),
+                         "layout_bytes": ab[dom]},
             "step_roofline": {"algorithmic_bytes": step_bytes,
                               "achieved_GBs": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                               "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                              "fwd_bwd_ms": round(sum(kern_ms[k] for k in names[:5] if k != "ssim"), 4)},
+                              "fwd_bwd_ms": round(fwd_bwd_ms, 4),
+                              "fwd_bwd_survey_bytes": fwd_bwd_bytes,
+                              "fwd_bwd_frac_of_hbm_peak": round(fwd_bwd_bytes / (fwd_bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
         out["valu_roofline"] = valu_utilisation(kern_ms, N, W, H, deg)
         if dp.world > 1:
@@ -277,11 +335,15 @@ def main():
                                   if model._color_all is not None else "all-reduce flat gradient buffer",
                                   "payload_bytes_per_rank_per_step": int(dp.bytes_per_step),
                                   "dense_all_reduce_bytes": int(model.params.grad.numel() * 4)}
+            out["dp_exchange"]["replicas_identical"] = replicas_identical
             if comm:
                 out["dp_exchange"].update(comm)
         if dp.world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(N, W, H, deg, args.seed)
+                out["cpu_baseline"] = cpu_baseline(N, W, H, deg, args.seed, clustered=clustered)
+                # the CPU port times forward+backward only (no SSIM / Adam): the GPU figure in the SAME unit
+                out["cpu_baseline"]["gpu_same_unit"] = {"value": round(1e3 / fwd_bwd_ms, 2),
+                                                        "unit": out["cpu_baseline"]["unit"]}
             except Exception as ex:  # the oracle is test infrastructure; never fail the bench on it
                 out["cpu_baseline"] = {"value": None, "error": repr(ex)}
         print(json.dumps(out), flush=True)

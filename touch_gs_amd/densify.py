@@ -68,7 +68,7 @@ class DensityController:
     @torch.no_grad()
     def sync(self, dp) -> None:
         """C2: make the statistics identical on all ranks (sum, sum, max)."""
-        if dp is None or dp.world == 1:
+        if dp is None or not dp.active:
             return
         import torch.distributed as dist
         dist.all_reduce(self.grad_norm_sum, op=dist.ReduceOp.SUM)

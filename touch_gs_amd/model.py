@@ -88,6 +88,7 @@ class DepthGaussianSplattingModel:
     def populate_modules(self):
         self.optimizer = FusedAdam(self.params, self.config.lrs())
         self.budget = ops.IntersectBudget()
+        self._sync_budget = ops.IntersectBudget()   # render / eval path when `budget` is sync-free
         self.fuse_adam = True   # single-process steps use the fused K8+K9 kernel when it applies
         self.dp_factored_sh = True   # data-parallel steps exchange colour gradients, not SH rows
         self._color_block = self._color_all = None
@@ -108,8 +109,11 @@ class DepthGaussianSplattingModel:
         """Camera -> {rgb, depth, accumulation} (differentiable; autograd path)."""
         p = self.params
         deg = self.active_sh_degree() if sh_degree is None else sh_degree
+        # the autograd / eval path has no replay logic: it always bins with a synchronous budget (a
+        # sync-free training budget would turn an eval view that needs more pairs into background)
+        budget = self.budget if self.budget.sync else self._sync_budget
         rgb, depth_acc, alpha, radii = ops.render(p.means, p.log_scales, p.quats, p.opac_logit, p.sh,
-                                                  cam, deg, budget=self.budget)
+                                                  cam, deg, budget=budget)
         depth = depth_acc / torch.clamp(alpha, min=1e-10)
         return dict(rgb=rgb, depth=depth[..., None], accumulation=alpha[..., None],
                     depth_acc=depth_acc, alpha=alpha, radii=radii)
@@ -189,7 +193,7 @@ class DepthGaussianSplattingModel:
         H, W = cam.H, cam.W
         splats, radii, group_base, tile_start, sorted_gid, status = ops.project_bin_sort(
             cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, self.budget, want_radii=want_v_xy)
-        guard = status if self.budget.speculative else None   # overflowed frame => optimizer kernels are no-ops
+        guard = None if self.budget.sync else status   # overflowed frame => optimizer kernels are no-ops
         rgb, depth_acc, fT, fidx = ops.rasterize_fwd(cam, splats, sorted_gid, tile_start)
         v_img, ssim_sum = None, None
         if c.ssim_lambda > 0:
@@ -316,7 +320,7 @@ class DepthGaussianSplattingModel:
 
     def train_step(self, view: View, dp=None) -> None:
         """One optimizer iteration on one view (per rank).  ``dp``: a parallel.GradSync or None."""
-        distributed = dp is not None and dp.world > 1
+        distributed = dp is not None and dp.active
         opt = self.optimizer
         deg = self.active_sh_degree()
         graphs = getattr(self, "_graphs", None)

@@ -60,7 +60,11 @@ class IntersectBudget:
         self.sticky = None       # device int32[1], allocated on first use
 
     def sticky_word(self, device):
-        if not self.speculative:
+        """Persistent overflow word of every budget that does not read the status back (``sync=False``):
+        an overflowing frame sets it, later frames start overflowed (empty lists) and the guarded
+        optimizer kernels do nothing -- an undersized buffer can never feed garbage partials to Adam,
+        and :meth:`check` sees an overflow of ANY earlier frame, not only of the last one."""
+        if self.sync:
             return None
         if self.sticky is None:
             self.sticky = torch.zeros(1, dtype=torch.int32, device=device)
@@ -72,13 +76,17 @@ class IntersectBudget:
         return self.capacity
 
     def check(self):
-        """Read the last frame's status; raises if it overflowed.  Returns #intersections."""
+        """Read the last frame's status (and the sticky word, which remembers an overflow of any
+        earlier frame of a ``sync=False`` budget); raises on overflow.  Returns #intersections."""
         if self.last_status is None:
             return None
         n, ovf = self.last_status.tolist()
         self.last_n = n
+        if self.sticky is not None and int(self.sticky.item()) != 0:
+            ovf = 1
         if ovf:
-            raise RuntimeError(f"intersection capacity {self.capacity} too small: frame needed {n}")
+            raise RuntimeError(f"intersection capacity {self.capacity} too small: a frame needed more "
+                               f"(last frame: {n}); every frame since the overflow was dropped")
         return n
 
 

@@ -24,7 +24,11 @@ def init_from_env(backend: Optional[str] = None) -> "GradSync":
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # TGS_DP_FORCE_COLLECTIVES=1: form the process group and issue every collective even with ONE
+    # rank, so that the RCCL code path (all_gather_into_tensor / all_reduce on the side stream) can be
+    # exercised on a single-GPU box.
+    force = os.environ.get("TGS_DP_FORCE_COLLECTIVES", "") not in ("", "0")
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -35,7 +39,7 @@ def init_from_env(backend: Optional[str] = None) -> "GradSync":
             local = local % torch.cuda.device_count()
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    return GradSync(rank, world, local)
+    return GradSync(rank, world, local, force_collectives=force)
 
 
 class GradSync:
@@ -50,16 +54,19 @@ class GradSync:
     ``gather_color_reduce_geom_and_step`` is the default of the trainer (see its docstring).
     """
 
-    def __init__(self, rank: int = 0, world: int = 1, local_rank: int = 0, n_chunks: int = 8):
+    def __init__(self, rank: int = 0, world: int = 1, local_rank: int = 0, n_chunks: int = 8,
+                 force_collectives: bool = False):
         self.rank, self.world, self.local_rank = rank, world, local_rank
         self.n_chunks = n_chunks
+        # collectives are issued when there is more than one rank -- or when forced (1-rank RCCL test)
+        self.active = world > 1 or (force_collectives and dist.is_initialized())
         self.bytes_per_step = 0
         self._comm_stream = None
         self.timing = False        # record events around the collectives of the factored step
         self._comm_events = None
 
     def all_reduce_(self, flat_grad: torch.Tensor) -> float:
-        if self.world > 1:
+        if self.active:
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
             self.bytes_per_step = flat_grad.numel() * flat_grad.element_size()
         return 1.0 / self.world
@@ -83,7 +90,7 @@ class GradSync:
         scale = 1.0 / self.world
         if begin_step is not None:
             begin_step()
-        if self.world == 1:
+        if not self.active:
             step_range(0, flat_grad.numel(), 1.0)
             return
         ranges = self.chunk_ranges(flat_grad.numel(), self.n_chunks)
@@ -126,14 +133,14 @@ class GradSync:
         scale = 1.0 / self.world
         if begin_step is not None:
             begin_step()
-        gather = (lambda: v_color_all.copy_(v_color.view(1, -1))) if self.world == 1 else \
+        gather = (lambda: v_color_all.copy_(v_color.view(1, -1))) if not self.active else \
                  (lambda: dist.all_gather_into_tensor(v_color_all.view(-1), v_color)) if dist.get_backend() == "nccl" else \
                  (lambda: dist.all_gather(list(v_color_all.view(self.world, -1).unbind(0)), v_color))
         self.bytes_per_step = 4 * (v_color.numel() * self.world + geom_grad.numel())
-        if self.world == 1 or not geom_grad.is_cuda:
+        if not self.active or not geom_grad.is_cuda:
             gather()
             step_sh(v_color_all, scale)
-            if self.world > 1:
+            if self.active:
                 dist.all_reduce(geom_grad, op=dist.ReduceOp.SUM)
             step_geom(0, geom_grad.numel(), scale)
             return
@@ -176,11 +183,11 @@ class GradSync:
                 "all_reduce_busbw_GBs": round(geom_bytes * 2 * (n - 1) / n / tr / 1e9, 1)}
 
     def barrier(self):
-        if self.world > 1:
+        if self.active:
             dist.barrier()
 
     def max_over_ranks(self, value: float) -> float:
-        if self.world == 1:
+        if not self.active:
             return value
         dev = torch.device("cuda", self.local_rank) if (dist.get_backend() == "nccl") else torch.device("cpu")
         t = torch.tensor([value], dtype=torch.float64, device=dev)
@@ -194,7 +201,7 @@ class GradSync:
 
     def assert_replicas_identical(self, flat_params: torch.Tensor):
         """Cheap divergence check: max over ranks of a checksum must equal the local one."""
-        if self.world == 1:
+        if not self.active:
             return
         s = flat_params.double().sum().reshape(1)
         lo, hi = s.clone(), s.clone()

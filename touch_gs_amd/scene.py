@@ -17,9 +17,15 @@ from .camera import Camera
 SH_C0 = 0.28209479177387814
 
 
-def synthetic_gaussians(N: int, W: int, H: int, deg: int, seed: int) -> Tuple[Dict[str, torch.Tensor], dict]:
+def synthetic_gaussians(N: int, W: int, H: int, deg: int, seed: int,
+                        clustered: bool = False) -> Tuple[Dict[str, torch.Tensor], dict]:
     """z~U(2,6); x,y fill 1.1x the frustum; log-scales ~ N(log(7/fx), 0.6^2); quats ~ N(0,1)^4;
-    opacity logits ~ U(-2,2); SH dc = (U(0,1)-0.5)/C0, higher bands ~ N(0, 0.05^2)."""
+    opacity logits ~ U(-2,2); SH dc = (U(0,1)-0.5)/C0, higher bands ~ N(0, 0.05^2).
+
+    ``clustered`` (stress scene, not a BASELINE config): 80 % of the Gaussians are squeezed into the
+    central 10 % of the image (x, y scaled by sqrt(0.1) of the frustum) -- the object-centric shape
+    of the reference's scenes (one object on a table, scripts/train_bunny_real.sh), which puts
+    thousands of Gaussians into a few tiles.  Same random draws as the uniform scene."""
     g = torch.Generator().manual_seed(seed)
     t30 = math.tan(math.radians(30.0))
     fx = fy = (W / 2) / t30
@@ -28,6 +34,11 @@ def synthetic_gaussians(N: int, W: int, H: int, deg: int, seed: int) -> Tuple[Di
     z = 2 + 4 * u(N)
     x = (2 * u(N) - 1) * 1.1 * z * t30
     y = (2 * u(N) - 1) * 1.1 * z * (H / W) * t30
+    if clustered:
+        inner = (torch.arange(N) % 5) != 0          # 80 %
+        k = math.sqrt(0.1) / 1.1
+        x = torch.where(inner, x * k, x)
+        y = torch.where(inner, y * k, y)
     means = torch.stack([x, y, z], 1)
     log_scales = math.log(7.0 / fx) + 0.6 * n(N, 3)
     quats = n(N, 4)
@@ -67,12 +78,13 @@ def supervision_maps(W: int, H: int, seed: int):
     return unc, masked
 
 
-def make_view(N: int, W: int, H: int, deg: int, seed: int, device, view: int = 0, n_views: int = 8):
+def make_view(N: int, W: int, H: int, deg: int, seed: int, device, view: int = 0, n_views: int = 8,
+              clustered: bool = False):
     """Ground truth for a view = render of the *other* scene S(.., seed+1000) through this library
     (GT RGB, GT depth), plus the synthetic uncertainty / mask maps."""
     from . import ops
     from .model import View
-    P, intr = synthetic_gaussians(N, W, H, deg, seed + 1000)
+    P, intr = synthetic_gaussians(N, W, H, deg, seed + 1000, clustered=clustered)
     cam = make_camera(intr, view, n_views)
     D = {k: v.to(device).contiguous() for k, v in P.items()}
     with torch.no_grad():
