@@ -523,11 +523,12 @@ dp.n_chunks = 3
 def train(factored, sync):
     m = fresh()
     m.dp_factored_sh = factored
+    m.fuse_adam = False
     for step in range(3):
         m.train_step(views[step % 2], sync)
     torch.cuda.synchronize()
     return m
-ref = train(True, None)                             # single-process fused step, no collectives
+ref = train(True, None)                             # single process: K8 -> flat gradient -> Adam, no collectives
 a = train(True, dp)                                 # all_gather_into_tensor + all_reduce over RCCL
 b = train(False, dp)                                # chunked all_reduce of the flat buffer over RCCL
 assert a._color_all is not None and dp.bytes_per_step > 0

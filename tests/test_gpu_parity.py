@@ -100,7 +100,7 @@ def test_rasterize_fwd(dev, N, W, H, deg, seed, clamp):
 
 
 @pytest.mark.parametrize("N,W,H,deg,seed,clamp", [(2000, 128, 80, 3, 21, False), (500, 50, 35, 0, 22, False),
-                                                   (2000, 128, 80, 3, 23, True), (600, 64, 64, 1, 24, True)])
+                                                   (2000, 128, 80, 3, 23, True), (2500, 64, 64, 1, 24, True)])
 def test_rasterize_bwd(dev, N, W, H, deg, seed, clamp):
     """clamp=True: a third of the Gaussians have opacity > 0.999 and e^2 larger axes, so that
     thousands of (pixel, Gaussian) pairs sit ON the alpha = 0.999 clamp, whose gradient App. B.7
@@ -173,10 +173,10 @@ def test_project_bwd(dev, N, W, H, deg, seed):
 @pytest.mark.parametrize("clamp", [False, True])
 def test_end_to_end_render_and_grads(dev, clamp):
     """Whole pipeline against the fp64 oracle; statistical because fp32 flips a few decisions.
-    clamp=True puts >= 10 % of the Gaussians at opacity logit 12 (alpha clamp regime, B.7)."""
+    clamp=True puts 25 % of the Gaussians at opacity logit 12 (alpha clamp regime, B.7)."""
     from touch_gs_amd import ops
     N, W, H, deg = 4000, 192, 112, 3
-    P, cam = (clamp_scene(N, W, H, deg, 42, frac=5, grow=1.5) if clamp else scene(N, W, H, deg, 41))
+    P, cam = (clamp_scene(N, W, H, deg, 42, frac=4, grow=2.0) if clamp else scene(N, W, H, deg, 41))
     D = to_dev(P, dev)
     for t in D.values():
         t.requires_grad_(True)

@@ -24,6 +24,7 @@ def main():
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC",
                                os.path.join(HERE, "contrib_probe.hip"), "-o", so])
     lib = C.CDLL(so)
+    lib.probe_contrib.argtypes = [C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 5
     name = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
     N, W, H, deg, seed = CFG[name]
     dev = torch.device("cuda:0")
@@ -32,7 +33,7 @@ def main():
     cam = make_camera(intr, 0, 8)
     sp, _, gb, ts, sg, st = ops.project_bin_sort(cam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], deg)
     ctr = torch.zeros(16, dtype=torch.int64, device=dev)
-    rc = lib.probe_contrib(W, H, C.c_float(cam.pix_center), ptr(sp), ptr(sg), ptr(ts), ptr(ctr),
+    rc = lib.probe_contrib(W, H, float(cam.pix_center), ptr(sp), ptr(sg), ptr(ts), ptr(ctr),
                            C.c_void_p(torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     c = ctr.tolist()

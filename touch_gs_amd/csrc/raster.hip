@@ -22,9 +22,9 @@
 //    10 sums per Gaussian (v_rgb, v_depth and the six pixel-coordinate moments of
 //    q = alpha * v_alpha); the 64-lane sums go through LDS: every lane scatters its 10 values
 //    into a padded [10][68] image, lane (part, c) adds 16 lane contributions of value c read as
-//    four ds_read_b128, two ds_bpermute steps combine the four parts and value i lands in slot i
-//    of an LDS transpose buffer (17 VALU + 11 LDS instructions; a multiplexed DPP butterfly
-//    needs 37 VALU and the kernel is VALU bound); at the end of the batch lane j converts Gaussian j's moments into (v_xy, v_conic, v_opacity) and stores
+//    four ds_read_b128, two lane-swap folds (v_permlane16/32_swap) combine the four parts and value i lands in slot i
+//    of an LDS transpose buffer (15 adds + two 3-instruction lane-swap folds + 11 LDS instructions; a multiplexed DPP
+//    butterfly needs 37 VALU and the kernel is VALU bound); at the end of the batch lane j converts Gaussian j's moments into (v_xy, v_conic, v_opacity) and stores
 //    one 48-B partial record.  There are NO float atomics: cross-tile accumulation is a segmented
 //    sum in K8 (deterministic, and it avoids cross-XCD memory-side atomics).
 //  * blockIdx -> tile mapping gives each XCD a contiguous band of tiles so the gathered splat
@@ -41,6 +41,20 @@ constexpr float LOG2_255 = 7.994353436858858f;   // alpha >= 1/255  <=>  s <= lo
 __device__ __forceinline__ int xcd_tile(int b, int T) {
   const int q = (T + 7) >> 3;          // tiles per XCD band
   return (b & 7) * q + (b >> 3);       // may be >= T (padded grid)
+}
+
+// v[l] + v[l ^ 16] and v[l] + v[l ^ 32] with the gfx950 lane-swap instructions (3 VALU each: a
+// copy, v_permlane{16,32}_swap_b32 and the add) instead of ds_bpermute + per-iteration index
+// arithmetic.  permlane16_swap exchanges the odd rows of its first operand with the even rows of the
+// second, permlane32_swap the upper half of the first with the lower half of the second.
+typedef unsigned tgs_u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float fold_xor16(float v) {
+  const tgs_u2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float fold_xor32(float v) {
+  const tgs_u2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
 
 struct LossK {
@@ -423,8 +437,8 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
         const float4 r0 = ld4(red_rd), r1 = ld4(red_rd + 4), r2 = ld4(red_rd + 8), r3 = ld4(red_rd + 12);
         float O = ((r0.x + r0.y) + (r0.z + r0.w)) + ((r1.x + r1.y) + (r1.z + r1.w)) +
                   (((r2.x + r2.y) + (r2.z + r2.w)) + ((r3.x + r3.y) + (r3.z + r3.w)));
-        O += __shfl_xor(O, 16);
-        O += __shfl_xor(O, 32);
+        O = fold_xor16(O);
+        O = fold_xor32(O);
         if (lane < 16) reinterpret_cast<float*>(sums)[j * 16 + lane] = O;
         __builtin_amdgcn_wave_barrier();
       }
