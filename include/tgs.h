@@ -86,6 +86,7 @@ const char* tgs_last_error(void);
 int tgs_num_groups(int N);                 /* ceil(N/TGS_GROUP) */
 int tgs_num_tiles(int W, int H);           /* ceil(W/16)*ceil(H/16) */
 int tgs_tile_order_len(int W, int H);      /* tiles rounded up to a multiple of 8 (one entry per K6/K7 block) */
+int tgs_tile_counter_len(int W, int H);    /* int32 entries of the tile_cursor scratch: per-XCD counter rows + sub-list starts */
 /* Bytes of scratch tgs_bin_sort needs for a given intersection capacity. */
 size_t tgs_sort_scratch_bytes(int64_t capacity);
 
@@ -129,7 +130,7 @@ int tgs_sh_bwd(int N, int sh_deg, int sh_stride, const float* dirs, const float*
  *                       the optimizer entry points this lets a caller read the status words late,
  *                       without a per-frame host sync: after an overflow nothing touches the model
  *                       until the caller has cleared the word, grown the buffers and replayed.
- * tmp: tile_cursor[T], scratch (tgs_sort_scratch_bytes(capacity)). */
+ * tmp: tile_cursor[tgs_tile_counter_len(W,H)], scratch (tgs_sort_scratch_bytes(capacity)). */
 int tgs_bin_sort(const TgsCamera* cam /*[host]*/, int N, float* splats, int32_t* group_base,
                  int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
                  int32_t* tile_order, int64_t capacity, void* scratch, int32_t* status,

@@ -294,6 +294,27 @@ def test_edge_cases(dev):
     assert relerr(rgb.cpu().numpy(), out["rgb"].numpy(), floor=1e-2)[clear].max() < TOL
 
 
+@pytest.mark.parametrize("N,lo,hi", [(300, 128, 512), (700, 512, 1024), (1500, 1024, 2048), (3000, 2048, 4096),
+                                       (5200, 4096, 16384)])
+def test_sort_classes(dev, N, lo, hi):
+    """Every list-length class of the per-tile sort (register-resident wave sort with 8 / 16 / 32 / 64
+    keys per lane, then the LDS workgroup sort): order bit-exact vs the oracle, incl. depth ties."""
+    from touch_gs_amd import ops
+    P, cam = scene(N, 32, 32, 0, 90 + N)
+    P["means"][:] = torch.tensor([0.0, 0.0, 4.0], dtype=torch.float64) + 0.01 * torch.randn(N, 3, dtype=torch.float64)
+    P["means"][::7, 2] = 4.0          # exact depth ties: order must fall back to the Gaussian id
+    P["log_scales"][:] = -6.0
+    D = to_dev(P, dev)
+    acam = amd_cam(cam)
+    sp = ops.project_fwd(acam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], 0)
+    gb, ts, sg, st = ops.bin_sort(acam, sp)
+    f = splat_fields(sp)
+    gid, tstart = O.bin_and_sort(f["rect"], f["hits"] > 0, f["depth"], cam)
+    n = st.tolist()[0]
+    assert lo < np.diff(tstart).max() <= hi, np.diff(tstart).max()
+    assert n == len(gid) and np.array_equal(sg[:n].cpu().numpy().astype(np.int64), gid)
+
+
 def test_sort_fallback_global(dev):
     """> 16384 Gaussians in one tile exercises the global-memory sort fallback."""
     from touch_gs_amd import ops

@@ -42,6 +42,7 @@ SIGNATURES = {
     "tgs_num_groups": (C.c_int, [_I]),
     "tgs_num_tiles": (C.c_int, [_I, _I]),
     "tgs_tile_order_len": (C.c_int, [_I, _I]),
+    "tgs_tile_counter_len": (C.c_int, [_I, _I]),
     "tgs_sort_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "tgs_project_fwd": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "tgs_sh_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P]),

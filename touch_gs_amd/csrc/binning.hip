@@ -46,37 +46,44 @@ __global__ __launch_bounds__(TGS_GROUP) void k_tile_count(
   const int total = group_load_scan(cam, N, splats, S, my_off);
   const int g = blockIdx.x * TGS_GROUP + threadIdx.x;
   if (g < N) splats[(size_t)g * TGS_SPLAT_FLOATS + 11] = __int_as_float(my_off);
-  group_count_tiles(S, cam.TW, total, group_base, tile_count, rank, status, capacity, sticky);
+  group_count_tiles(S, cam.TW, cam.TW * cam.TH, total, group_base, tile_count, rank, status, capacity, sticky);
 }
 
-// K4: exclusive scan of tile counts -> tile_start[T+1] (single workgroup; T is a few 10^4).
-// Thread t owns the contiguous chunk [t*C, (t+1)*C), C = ceil(T/1024): one serial pass over its
-// chunk, one workgroup scan of the 1024 chunk totals, one pass to write -- two barriers in all.
+// K4: exclusive scan of the [8][T] per-XCD tile counters in tile-major order -> tile_start[T+1] and
+// sub_start[8][T] (start of XCD x's sub-list inside tile t's list).  Workgroup b of the first
+// NB = ceil(T/1024) owns tiles [1024 b, 1024 b + 1024): thread = tile, 8 coalesced counter loads, a
+// workgroup scan of the tile totals, then the workgroup publishes its AGGREGATE (not its prefix) and
+// sums the aggregates of the lower workgroups itself -- a one-step look-back, no chain, ~2 global
+// round trips in all (the single-workgroup version took 14 us for 8160 counters, 54 us for 8 x 8160).
 // On capacity overflow every list is made empty so that downstream kernels touch nothing.
 //
-// Blocks 1..8 (launched only when a tile_order buffer is given) build the visiting order of the
-// compositing kernels: block b of K6/K7 runs on XCD b % 8 and owns tile tile_order[b]; every XCD keeps
-// its contiguous band of tiles (so the splat records neighbouring tiles share stay in its L2) but
-// visits it longest list first.  With ~2 tiles per resident wave slot the spatial order leaves the
-// last slots running alone for a whole tile; longest-first shortens that tail (K6 -3 %, K7 -4 %,
+// Workgroups NB..NB+7 (launched only when a tile_order buffer is given) build the visiting order of
+// the compositing kernels: block b of K6/K7 runs on XCD b % 8 and owns tile tile_order[b]; every XCD
+// keeps its contiguous band of tiles (so the splat records neighbouring tiles share stay in its L2)
+// but visits it longest list first.  With ~2 tiles per resident wave slot the spatial order leaves
+// the last slots running alone for a whole tile; longest-first shortens that tail (K6 -3 %, K7 -4 %,
 // alternating same-box runs after clock warm-up).
-__global__ __launch_bounds__(1024) void k_scan_tiles(int T, const int32_t* __restrict__ tile_count,
+__global__ __launch_bounds__(1024) void k_scan_tiles(int T, int NB, int32_t* __restrict__ tile_count,
                                                      int32_t* __restrict__ tile_start,
                                                      const int32_t* __restrict__ status,
                                                      int32_t* __restrict__ tile_order) {
   __shared__ int wave_tot[16];
+  __shared__ int s_base;
   __shared__ unsigned long long okeys[8192];   // one XCD band: <= ceil(255*255/8) = 8129 tiles
   const int tid = threadIdx.x;
-  if (blockIdx.x > 0) {
-    const int x = blockIdx.x - 1;
+  if ((int)blockIdx.x >= NB) {
+    const int x = blockIdx.x - NB;
     const int per = (T + 7) >> 3;
     const int t0 = x * per, len = max(0, min(per, T - t0));
     int np2 = 2;
     while (np2 < per) np2 <<= 1;
     // ascending on (~n, tile) = descending list length, ties by tile id; pads sort to the end
-    for (int i = tid; i < np2; i += 1024)
-      okeys[i] = i < len ? ((unsigned long long)(~(unsigned)tile_count[t0 + i]) << 32) | (unsigned)(t0 + i)
-                         : ~0ull;
+    for (int i = tid; i < np2; i += 1024) {
+      unsigned n = 0;
+      if (i < len)
+        for (int c = 0; c < TGS_XCC; c++) n += (unsigned)tile_count[c * T + t0 + i];
+      okeys[i] = i < len ? ((unsigned long long)(~n) << 32) | (unsigned)(t0 + i) : ~0ull;
+    }
     __syncthreads();
     for (int k = 2; k <= np2; k <<= 1) {
       for (int j = k >> 1; j > 0; j >>= 1) {
@@ -95,16 +102,21 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int T, const int32_t* __res
     return;
   }
   const bool overflow = status[1] != 0;
-  const int C = (T + 1023) / 1024;
-  const int lo = min(tid * C, T), hi = min(lo + C, T);
+  int32_t* __restrict__ sub_start = tile_count + TGS_XCC * T;
+  int32_t* __restrict__ agg = sub_start + TGS_XCC * T;     // [NB] aggregate + 1 of every scan workgroup, 0 = not yet
+  const int b = blockIdx.x, t = b * 1024 + tid;
+  int c[TGS_XCC];
   int sum = 0;
-  if (!overflow)
-    for (int i = lo; i < hi; i++) sum += tile_count[i];
+#pragma unroll
+  for (int x = 0; x < TGS_XCC; x++) {
+    c[x] = (t < T && !overflow) ? tile_count[x * T + t] : 0;
+    sum += c[x];
+  }
   int incl = sum;
 #pragma unroll
   for (int o = 1; o < TGS_WAVE; o <<= 1) {
-    const int t = __shfl_up(incl, o);
-    if ((tid & 63) >= o) incl += t;
+    const int v = __shfl_up(incl, o);
+    if ((tid & 63) >= o) incl += v;
   }
   if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
   __syncthreads();
@@ -114,20 +126,43 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int T, const int32_t* __res
     if (w < (tid >> 6)) wbase += wave_tot[w];
     tot += wave_tot[w];
   }
-  int run = wbase + incl - sum;
-  for (int i = lo; i < hi; i++) {
-    tile_start[i] = run;
-    run += overflow ? 0 : tile_count[i];
+  if (tid == 0) __hip_atomic_store(&agg[b], tot + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  {   // longest list of the frame: lets the long-list sort launches return immediately when unused
+    const int wmax = wave_max_i(sum);
+    if ((tid & 63) == 0 && wmax > 0) atomicMax(agg + TGS_SCAN_WGS, wmax);
   }
-  if (tid == 0) tile_start[T] = tot;
+  // look-back: sum the aggregates of workgroups 0 .. b-1 (NB <= 64: one wave)
+  if (tid < TGS_WAVE) {
+    int v = 0;
+    if (tid < b) {
+      int a;
+      do { a = __hip_atomic_load(&agg[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while (a == 0);
+      v = a - 1;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (tid == 0) s_base = v;
+  }
+  __syncthreads();
+  int run = s_base + wbase + incl - sum;
+  if (t < T) {
+    tile_start[t] = run;
+#pragma unroll
+    for (int x = 0; x < TGS_XCC; x++) {
+      sub_start[x * T + t] = run;
+      run += c[x];
+    }
+  }
+  if (b == NB - 1 && tid == 0) tile_start[T] = s_base + tot;
 }
 
 // K3b: scatter (gid, depth bits) into the tile bins.  slot = tile_start + arrival rank.
 __global__ __launch_bounds__(TGS_GROUP) void k_fill_bins(
     CamK cam, int N, const float* __restrict__ splats, const int32_t* __restrict__ group_base,
-    const int32_t* __restrict__ tile_start, const int32_t* __restrict__ rank,
+    const int32_t* __restrict__ sub_start, const int32_t* __restrict__ rank,
     uint2* __restrict__ pairs, const int32_t* __restrict__ status) {
   if (status[1]) return;
+  const int T = cam.TW * cam.TH;
   __shared__ GroupScan S;
   int my_off;
   const int total = group_load_scan(cam, N, splats, S, my_off);
@@ -137,7 +172,8 @@ __global__ __launch_bounds__(TGS_GROUP) void k_fill_bins(
   for (int i = threadIdx.x; i < total; i += TGS_GROUP) {
     int j, tile;
     group_pair(S, cam.TW, i, j, tile);
-    const int slot = tile_start[tile] + rank[base + i];
+    const unsigned r = (unsigned)rank[base + i];   // sub-list (XCC) id << 29 | rank inside it
+    const int slot = sub_start[(r >> 29) * T + tile] + (int)(r & 0x1fffffffu);
     pairs[slot] = make_uint2((unsigned)(g0 + j), S.depth_bits[j]);  // u64 = depth<<32 | gid
   }
 }
@@ -148,53 +184,192 @@ __device__ __forceinline__ int next_pow2(int n) {
   return p;
 }
 
-// K5: per-tile bitonic sort of (depth bits, gid) in LDS; writes the sorted Gaussian ids.
-// One workgroup per tile; tiles whose list length is outside (LO, CAP] belong to another class.
-template <int CAP, int THREADS, int LO>
-__global__ __launch_bounds__(THREADS) void k_sort_tiles_lds(
-    int T, const int32_t* __restrict__ tile_start, const unsigned long long* __restrict__ pairs,
-    int32_t* __restrict__ sorted_gid) {
-  __shared__ unsigned long long keys[CAP];
-  const int tid = threadIdx.x;
-  // grid-stride over tiles: the rare long-list classes are launched with a small grid so that an
-  // empty class costs ~2 us instead of a full grid of 128-KB-LDS workgroups
-  for (int tile = blockIdx.x; tile < T; tile += gridDim.x) {
-  const int s = tile_start[tile];
-  const int n = tile_start[tile + 1] - s;
-  if (n <= LO || n > CAP) continue;
-  if (n == 1) {
-    if (tid == 0) sorted_gid[s] = (int)(pairs[s] & 0xffffffffull);
-    continue;
-  }
-  __syncthreads();  // keys[] reuse across iterations
-  const int np2 = next_pow2(n);
-  for (int i = tid; i < np2; i += THREADS) keys[i] = (i < n) ? pairs[s + i] : ~0ull;
-  __syncthreads();
-  for (int k = 2; k <= np2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < (np2 >> 1); i += THREADS) {
-        const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
-        const int hi = lo | j;
-        const bool up = (lo & k) == 0;
-        const unsigned long long a = keys[lo], b = keys[hi];
-        if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
-      }
-      __syncthreads();
-    }
-  }
-  for (int i = tid; i < n; i += THREADS) sorted_gid[s + i] = (int)(keys[i] & 0xffffffffull);
+// ---------------------------------------------------------------------------------------------
+// K5: per-tile sort of (depth bits, gid), register resident: ONE wave64 sorts one tile's list.
+// ---------------------------------------------------------------------------------------------
+// The first version of this kernel ran the bitonic network of a 256-thread workgroup in LDS: 45
+// stages x 8 KB of ds_read_b64 / ds_write_b64 per 512-element list -- ~3 GB of LDS traffic per cfg3
+// frame, i.e. LDS-bandwidth bound (63 us, 38 % bank-conflict cycles).  Here every lane keeps E keys
+// (virtual index e = lane * E + r) in VGPRs: the stages with partner distance j < E are
+// register-to-register, the others exchange with lane ^ (j / E) through DPP (quad_perm, row_ror:8,
+// bank-masked row shifts) or the gfx950 lane-swap instructions -- no LDS, no barriers, and the
+// global loads stay coalesced.  E = 8 / 16 covers lists <= 512 / 1024 (the common class),
+// E = 32 / 64 (lists <= 2048 / 4096: object-centric scenes) run from a second, small launch.
+typedef unsigned long long u64;
+typedef unsigned tgs_u2 __attribute__((ext_vector_type(2)));
+
+template <int CTRL, int BANK>
+__device__ __forceinline__ unsigned dpp_upd(unsigned old, unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xf, BANK, false);
+}
+
+// value of lane (l ^ D) for D = 1, 2, 4, 8, 16, 32
+template <int D>
+__device__ __forceinline__ unsigned lane_xor(unsigned v, int lane) {
+  if constexpr (D == 1) return dpp_upd<0xB1, 0xf>(v, v);          // quad_perm [1,0,3,2]
+  else if constexpr (D == 2) return dpp_upd<0x4E, 0xf>(v, v);     // quad_perm [2,3,0,1]
+  else if constexpr (D == 4) {                                    // banks 0,2 <- lane+4; banks 1,3 <- lane-4
+    const unsigned t = dpp_upd<0x104, 0x5>(v, v);                 // row_shl:4
+    return dpp_upd<0x114, 0xA>(t, v);                             // row_shr:4
+  } else if constexpr (D == 8) return dpp_upd<0x128, 0xf>(v, v);  // row_ror:8
+  else if constexpr (D == 16) {
+    const tgs_u2 r = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // x = rows {0,0,2,2}, y = rows {1,1,3,3}
+    return (lane & 16) ? r.x : r.y;
+  } else {
+    const tgs_u2 r = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // x = {lo,lo}, y = {hi,hi}
+    return (lane & 32) ? r.x : r.y;
   }
 }
 
-// Rare long lists: one launch covers both remaining classes.  (LO, CAP] sorts in 128 KB of LDS like
-// the common class; anything longer runs the same network in global memory on a power-of-two
-// padded copy at fb[2*s ...) (next_pow2(n) < 2n, so per-tile regions never overlap).
+template <int D>
+__device__ __forceinline__ u64 lane_xor64(u64 v, int lane) {
+  return ((u64)lane_xor<D>((unsigned)(v >> 32), lane) << 32) | lane_xor<D>((unsigned)v, lane);
+}
+
+// one cross-lane stage: every key meets the same register of lane ^ D; the lower lane of a pair
+// keeps the minimum when the pair sorts upwards
+template <int E, int D>
+__device__ __forceinline__ void cross_stage(u64 (&k)[E], int lane, bool up) {
+  const bool keep_min = (((lane & D) == 0) == up);
+#pragma unroll
+  for (int r = 0; r < E; r++) {
+    const u64 p = lane_xor64<D>(k[r], lane);
+    k[r] = ((p < k[r]) == keep_min) ? p : k[r];
+  }
+}
+
+// register-to-register stage of distance J inside every lane; UPMASK < 0: direction `up` for all
+// registers, else the direction of register r is ((r & UPMASK) == 0)
+template <int E, int J, int UPMASK>
+__device__ __forceinline__ void local_stage(u64 (&k)[E], bool up) {
+#pragma unroll
+  for (int r = 0; r < E; r++) {
+    if ((r & J) == 0) {
+      const bool u = UPMASK < 0 ? up : ((r & UPMASK) == 0);
+      const u64 a = k[r], b = k[r | J];
+      const bool sw = (a > b) == u;
+      k[r] = sw ? b : a;
+      k[r | J] = sw ? a : b;
+    }
+  }
+}
+
+template <int E, int J, int UPMASK>
+__device__ __forceinline__ void local_tail(u64 (&k)[E], bool up) {   // stages J, J/2, ..., 1
+  if constexpr (J >= 1) {
+    local_stage<E, J, UPMASK>(k, up);
+    local_tail<E, J / 2, UPMASK>(k, up);
+  }
+}
+
+// levels KK = 2 .. E: the direction bit of a pair is a bit of the register index (KK < E) or the
+// lowest lane bit (KK == E)
+template <int E, int KK>
+__device__ __forceinline__ void local_levels(u64 (&k)[E], int lane) {
+  if constexpr (KK <= E) {
+    if constexpr (KK < E) local_tail<E, KK / 2, KK>(k, true);
+    else local_tail<E, E / 2, -1>(k, (lane & 1) == 0);
+    local_levels<E, KK * 2>(k, lane);
+  }
+}
+
+// One cross-WAVE stage (partner thread = tid ^ d, d >= 64) of a multi-wave workgroup: the keys
+// travel through LDS in register-major order (conflict-free ds_write_b64 / ds_read_b64).
+template <int E>
+__device__ __forceinline__ void cross_wave_stage(u64 (&k)[E], int tid, int d, bool up, u64* __restrict__ lds, int NT) {
+  const bool keep_min = (((tid & d) == 0) == up);
+#pragma unroll
+  for (int r = 0; r < E; r++) lds[r * NT + tid] = k[r];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < E; r++) {
+    const u64 p = lds[r * NT + (tid ^ d)];
+    k[r] = ((p < k[r]) == keep_min) ? p : k[r];
+  }
+  __syncthreads();
+}
+
+// Sorts one tile's list with W waves x 64 lanes x E keys (n <= 64 W E).  W == 1 needs no LDS and no
+// barriers; for W > 1 only the stages whose partner lives in another wave (log2 W (log2 W + 1) / 2
+// of them) go through LDS.
+template <int E, int W>
+__device__ __forceinline__ void sort_tile_regs(const u64* __restrict__ pairs, int32_t* __restrict__ sorted_gid,
+                                               int s, int n, int tid, u64* __restrict__ lds) {
+  constexpr int NT = TGS_WAVE * W;
+  const int lane = tid & (TGS_WAVE - 1);
+  u64 k[E];
+#pragma unroll
+  for (int r = 0; r < E; r++) {        // coalesced load; the initial order is irrelevant
+    const int i = r * NT + tid;
+    k[r] = i < n ? pairs[s + i] : ~0ull;
+  }
+  local_levels<E, 2>(k, lane);
+  constexpr int LV = W == 1 ? 6 : (W == 4 ? 8 : 10);   // log2(64 W)
+#pragma unroll 1
+  for (int lv = 1; lv <= LV; lv++) {   // levels KK = 2E .. 64WE: direction = bit lv of the thread id
+    const bool up = ((tid >> lv) & 1) == 0;
+    if constexpr (W > 1)
+      for (int d = 1 << (lv - 1); d >= TGS_WAVE; d >>= 1) cross_wave_stage<E>(k, tid, d, up, lds, NT);
+    if (lv >= 6) cross_stage<E, 32>(k, lane, up);
+    if (lv >= 5) cross_stage<E, 16>(k, lane, up);
+    if (lv >= 4) cross_stage<E, 8>(k, lane, up);
+    if (lv >= 3) cross_stage<E, 4>(k, lane, up);
+    if (lv >= 2) cross_stage<E, 2>(k, lane, up);
+    cross_stage<E, 1>(k, lane, up);
+    local_tail<E, E / 2, -1>(k, up);
+  }
+  // sorted order: e = tid * E + r
+#pragma unroll
+  for (int r = 0; r < E; r++) {
+    const int e = tid * E + r;
+    if (e < n) sorted_gid[s + e] = (int)(k[r] & 0xffffffffull);
+  }
+}
+
+// common classes: lists <= 512 (8 keys per lane) and <= 1024 (16 keys per lane); one wave per tile
+__global__ __launch_bounds__(TGS_WAVE) void k_sort_tiles_wave(
+    int T, const int32_t* __restrict__ tile_start, const u64* __restrict__ pairs,
+    int32_t* __restrict__ sorted_gid) {
+  const int tile = blockIdx.x;
+  const int s = tile_start[tile];
+  const int n = tile_start[tile + 1] - s;
+  const int lane = threadIdx.x;
+  if (n <= 0 || n > 1024) return;
+  if (n == 1) {
+    if (lane == 0) sorted_gid[s] = (int)(pairs[s] & 0xffffffffull);
+    return;
+  }
+  if (n <= 512) sort_tile_regs<8, 1>(pairs, sorted_gid, s, n, lane, nullptr);
+  else sort_tile_regs<16, 1>(pairs, sorted_gid, s, n, lane, nullptr);
+}
+
+// long lists (object-centric scenes): (1024, 4096] with 4 waves, (4096, 16384] with 16 waves, 16 keys
+// per lane, grid-stride over the tiles.  `max_list` (written by k_scan_tiles) lets the launch return
+// at once when the frame has no list of its class.
+template <int W, int LO>
+__global__ __launch_bounds__(TGS_WAVE * W) void k_sort_tiles_wg(
+    int T, const int32_t* __restrict__ tile_start, const u64* __restrict__ pairs,
+    int32_t* __restrict__ sorted_gid, const int32_t* __restrict__ max_list) {
+  __shared__ u64 wg_keys[TGS_WAVE * W * 16];   // 16 keys x 64 W threads (32 KB / 128 KB)
+  if (*max_list <= LO) return;
+  for (int tile = blockIdx.x; tile < T; tile += gridDim.x) {
+    const int s = tile_start[tile];
+    const int n = tile_start[tile + 1] - s;
+    if (n <= LO || n > TGS_WAVE * W * 16) continue;
+    sort_tile_regs<16, W>(pairs, sorted_gid, s, n, threadIdx.x, wg_keys);
+  }
+}
+
+// Lists beyond the register-resident classes (> LO = 16384): the bitonic network of a 1024-thread
+// workgroup in global memory, on a power-of-two padded copy at fb[2*s ...) (next_pow2(n) < 2n, so
+// per-tile regions never overlap).  (CAP: lists up to CAP would run in LDS; unused, CAP = 1.)
 template <int CAP, int LO>
 __global__ __launch_bounds__(1024) void k_sort_tiles_long(
     int T, const int32_t* __restrict__ tile_start, const unsigned long long* __restrict__ pairs,
-    unsigned long long* __restrict__ fb, int32_t* __restrict__ sorted_gid) {
+    unsigned long long* __restrict__ fb, int32_t* __restrict__ sorted_gid, const int32_t* __restrict__ max_list) {
   __shared__ unsigned long long lds_keys[CAP];
   const int tid = threadIdx.x;
+  if (*max_list <= LO) return;
   for (int tile = blockIdx.x; tile < T; tile += gridDim.x) {
     const int s = tile_start[tile];
     const int n = tile_start[tile + 1] - s;
@@ -222,8 +397,9 @@ __global__ __launch_bounds__(1024) void k_sort_tiles_long(
   }
 }
 
-constexpr int SORT_CAP_A = 2048;   // 16 KB LDS, 256 threads
-constexpr int SORT_CAP_B = 16384;  // 128 KB LDS, 1024 threads; longer lists sort in global memory
+constexpr int SORT_CAP_WAVE = 1024;  // one wave, 8 / 16 keys per lane
+constexpr int SORT_CAP_WG4 = 4096;   // 4 waves x 16 keys per lane
+constexpr int SORT_CAP_WG16 = 16384; // 16 waves x 16 keys per lane; longer lists sort in global memory
 
 }  // namespace
 
@@ -232,6 +408,7 @@ extern "C" int tgs_num_tiles(int W, int H) {
   return ((W + TGS_BLOCK - 1) / TGS_BLOCK) * ((H + TGS_BLOCK - 1) / TGS_BLOCK);
 }
 extern "C" int tgs_tile_order_len(int W, int H) { return ((tgs_num_tiles(W, H) + 7) / 8) * 8; }
+extern "C" int tgs_tile_counter_len(int W, int H) { return tgs_counter_len(tgs_num_tiles(W, H)); }
 // scratch layout: pairs u64[cap] | fallback u64[2*cap] | rank i32[cap]
 extern "C" size_t tgs_sort_scratch_bytes(int64_t capacity) {
   if (capacity < 0) capacity = 0;
@@ -245,19 +422,25 @@ int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* gro
   const int T = k.TW * k.TH;
   const int G = tgs_num_groups(N);
   const BinScratch sc = carve_scratch(scratch, capacity);
-  hipLaunchKernelGGL(k_scan_tiles, dim3(tile_order ? 9 : 1), dim3(1024), 0, s, T, tile_cursor, tile_start,
-                     status, tile_order);
+  const int NB = (T + 1023) / 1024;   // <= 64 (image sides are limited to 255 tiles)
+  hipLaunchKernelGGL(k_scan_tiles, dim3(NB + (tile_order ? 8 : 0)), dim3(1024), 0, s, T, NB, tile_cursor,
+                     tile_start, status, tile_order);
   TGS_CHECK_LAUNCH();
   if (G > 0) {
     hipLaunchKernelGGL(k_fill_bins, dim3(G), dim3(TGS_GROUP), 0, s, k, N, splats, group_base,
-                       tile_start, sc.rank, (uint2*)sc.pairs, status);
+                       tile_cursor + TGS_XCC * T, sc.rank, (uint2*)sc.pairs, status);
     TGS_CHECK_LAUNCH();
     const int small_grid = T < 256 ? T : 256;
-    hipLaunchKernelGGL((k_sort_tiles_lds<SORT_CAP_A, 256, 0>), dim3(T), dim3(256), 0, s, T,
-                       tile_start, sc.pairs, sorted_gid);
+    const int big_grid = T < 2048 ? T : 2048;
+    const int32_t* max_list = tile_cursor + 2 * TGS_XCC * T + TGS_SCAN_WGS;
+    hipLaunchKernelGGL(k_sort_tiles_wave, dim3(T), dim3(TGS_WAVE), 0, s, T, tile_start, sc.pairs, sorted_gid);
     TGS_CHECK_LAUNCH();
-    hipLaunchKernelGGL((k_sort_tiles_long<SORT_CAP_B, SORT_CAP_A>), dim3(small_grid), dim3(1024), 0,
-                       s, T, tile_start, sc.pairs, sc.fb, sorted_gid);
+    hipLaunchKernelGGL((k_sort_tiles_wg<4, SORT_CAP_WAVE>), dim3(big_grid), dim3(TGS_WAVE * 4), 0, s, T, tile_start, sc.pairs, sorted_gid, max_list);
+    TGS_CHECK_LAUNCH();
+    hipLaunchKernelGGL((k_sort_tiles_wg<16, SORT_CAP_WG4>), dim3(small_grid), dim3(TGS_WAVE * 16), 0, s, T, tile_start, sc.pairs, sorted_gid, max_list);
+    TGS_CHECK_LAUNCH();
+    hipLaunchKernelGGL((k_sort_tiles_long<1, SORT_CAP_WG16>), dim3(small_grid), dim3(1024), 0,
+                       s, T, tile_start, sc.pairs, sc.fb, sorted_gid, max_list);
     TGS_CHECK_LAUNCH();
   }
   return TGS_OK;
@@ -278,7 +461,7 @@ extern "C" int tgs_bin_sort(const TgsCamera* cam, int N, float* splats, int32_t*
   const int G = tgs_num_groups(N);
   hipStream_t s = (hipStream_t)stream;
   const BinScratch sc = carve_scratch(scratch, capacity);
-  hipLaunchKernelGGL(k_clear_counters, dim3((max(T, 2) + 255) / 256), dim3(256), 0, s, tile_cursor, T, status,
+  hipLaunchKernelGGL(k_clear_counters, dim3((max(TGS_XCC * T, 2) + 255) / 256), dim3(256), 0, s, tile_cursor, T, status,
                      sticky_overflow);
   TGS_CHECK_LAUNCH();
   if (G > 0) {

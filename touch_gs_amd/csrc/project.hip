@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_project_fwd(
       float* o = splats + (size_t)g * TGS_SPLAT_FLOATS;
       st4(o + 8, make_float4(c1, c2, __uint_as_float(rect), __int_as_float(my_off)));
     }
-    group_count_tiles(S, cam.TW, total, group_base, tile_count, rank, status, capacity, sticky);
+    group_count_tiles(S, cam.TW, cam.TW * cam.TH, total, group_base, tile_count, rank, status, capacity, sticky);
   }
 }
 
@@ -970,7 +970,7 @@ extern "C" int tgs_project_bin_sort(const TgsCamera* cam, int N, const float* me
   const int T = k.TW * k.TH;
   hipStream_t s = (hipStream_t)stream;
   const BinScratch sc = carve_scratch(scratch, capacity);
-  hipLaunchKernelGGL(k_clear_counters, dim3((max(T, 2) + 255) / 256), dim3(256), 0, s, tile_cursor, T, status,
+  hipLaunchKernelGGL(k_clear_counters, dim3((max(TGS_XCC * T, 2) + 255) / 256), dim3(256), 0, s, tile_cursor, T, status,
                      sticky_overflow);
   TGS_CHECK_LAUNCH();
   if (N > 0) {

@@ -23,7 +23,23 @@ int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* gro
                    int32_t* tile_order, int64_t capacity, void* scratch, int32_t* status,
                    hipStream_t s);
 
+// Per-tile intersection counters are kept once per XCD (row x of an [8][T] array, x = the XCC the
+// counting workgroup runs on): the 8 L2s of an MI355X are kept coherent by ownership migration, so a
+// counter line that all XCDs increment bounces between them -- with private rows every atomic stays
+// in its own L2 (and the hot tiles of an object-centric scene are spread over 8 lines instead of 1).
+// A tile's list is the concatenation of its 8 sub-lists (the per-tile sort orders it anyway).
+// counter buffer layout: count[8][T] | sub_start[8][T] | scan aggregates[64] | longest list[1] (+pad)
+#define TGS_XCC 8
+#define TGS_SCAN_WGS 64
+static inline int tgs_counter_len(int T) { return 2 * TGS_XCC * T + TGS_SCAN_WGS + 4; }
+
 #ifdef __HIPCC__
+__device__ __forceinline__ int xcc_id() {
+  // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4); any value in [0, 8) gives correct results, the true
+  // XCC id gives the locality
+  return (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & (TGS_XCC - 1));
+}
+
 struct GroupScan {
   int off[TGS_GROUP + 1];  // exclusive scan of tiles_hit inside the group
   int x0[TGS_GROUP], y0[TGS_GROUP], w[TGS_GROUP];
@@ -70,7 +86,8 @@ static __global__ __launch_bounds__(256) void k_clear_counters(int32_t* __restri
                                                         int32_t* __restrict__ status,
                                                         const int32_t* __restrict__ sticky) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < T) tile_cursor[i] = 0;
+  if (i < TGS_XCC * T) tile_cursor[i] = 0;
+  if (i < TGS_SCAN_WGS + 4) tile_cursor[2 * TGS_XCC * T + i] = 0;   // look-back flags of k_scan_tiles, longest list
   if (i == 0) status[0] = 0;
   if (i == 1) status[1] = sticky ? (*sticky != 0) : 0;
 }
@@ -93,7 +110,7 @@ __device__ __forceinline__ void group_pair(const GroupScan& S, int TW, int i, in
 // Allocates the group's contiguous pair range and counts its intersections per tile; every pair
 // remembers its arrival rank inside its tile.  Call after group_scan_store + __syncthreads-free
 // (this function synchronises internally).
-__device__ __forceinline__ void group_count_tiles(GroupScan& S, int TW, int total,
+__device__ __forceinline__ void group_count_tiles(GroupScan& S, int TW, int T, int total,
                                                   int32_t* __restrict__ group_base,
                                                   int32_t* __restrict__ tile_count,
                                                   int32_t* __restrict__ rank,
@@ -112,11 +129,13 @@ __device__ __forceinline__ void group_count_tiles(GroupScan& S, int TW, int tota
   __syncthreads();
   const long long base = S.base;
   const bool fits = base + total <= capacity;
+  const int x = xcc_id();
+  int32_t* __restrict__ my_count = tile_count + (size_t)x * T;
   for (int i = tid; i < total; i += TGS_GROUP) {
     int j, tile;
     group_pair(S, TW, i, j, tile);
-    const int r = atomicAdd(&tile_count[tile], 1);
-    if (fits) rank[base + i] = r;
+    const int r = atomicAdd(&my_count[tile], 1);
+    if (fits) rank[base + i] = (int32_t)((unsigned)r | ((unsigned)x << 29));   // rank inside sub-list x of the tile (capacity < 2^29 pairs per sub-list)
   }
 }
 #endif  // __HIPCC__

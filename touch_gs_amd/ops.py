@@ -122,8 +122,9 @@ def bin_sort(cam: Camera, splats, budget: Optional[IntersectBudget] = None):
     cs = cam.c_struct()
     group_base = torch.empty(max(G, 1), dtype=torch.int32, device=dev)
     tile_start = torch.empty(T + 1, dtype=torch.int32, device=dev)
-    counters = torch.empty(T + 2, dtype=torch.int32, device=dev)   # tile counters | status
-    tile_cursor, status = counters[:T], counters[T:]
+    nc = lib.tgs_tile_counter_len(cam.W, cam.H)
+    counters = torch.empty(nc + 2, dtype=torch.int32, device=dev)   # per-XCD tile counters + sub-list starts | status
+    tile_cursor, status = counters[:nc], counters[nc:]
     # block -> tile schedule of K6 / K7 (longest list first inside each XCD's band); it rides on the
     # tile_start tensor object so that the (tile_start, sorted_gid) pair keeps its meaning for callers
     tile_order = torch.empty((T + 7) // 8 * 8, dtype=torch.int32, device=dev)
@@ -162,8 +163,9 @@ def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_d
     radii = torch.empty(N, dtype=torch.int32, device=dev) if want_radii else None
     group_base = torch.empty(max(G, 1), dtype=torch.int32, device=dev)
     tile_start = torch.empty(T + 1, dtype=torch.int32, device=dev)
-    counters = torch.empty(T + 2, dtype=torch.int32, device=dev)   # tile counters | status
-    tile_cursor, status = counters[:T], counters[T:]
+    nc = lib.tgs_tile_counter_len(cam.W, cam.H)
+    counters = torch.empty(nc + 2, dtype=torch.int32, device=dev)   # per-XCD tile counters + sub-list starts | status
+    tile_cursor, status = counters[:nc], counters[nc:]
     # block -> tile schedule of K6 / K7 (longest list first inside each XCD's band); it rides on the
     # tile_start tensor object so that the (tile_start, sorted_gid) pair keeps its meaning for callers
     tile_order = torch.empty((T + 7) // 8 * 8, dtype=torch.int32, device=dev)
