@@ -74,9 +74,10 @@ typedef struct TgsAdamSpec {
   float lr_means, lr_scales, lr_quats, lr_opac, lr_sh_dc, lr_sh_rest;
   float beta1, beta2, eps;
   float bias_corr1, bias_corr2;   /* 1-beta1^t, 1-beta2^t */
-  const float* device_bias_corr;  /* NULL, or device {bias_corr1, bias_corr2} read by the kernel at
-                                     run time instead of the two host fields: lets a captured
-                                     hipGraph of the step be replayed with each step's values */
+  const float* device_bias_corr;  /* NULL, or device {bias_corr1, bias_corr2, lr_means} read by the
+                                     kernel at run time instead of the three host fields: lets a
+                                     captured hipGraph of the step be replayed with each step's
+                                     values (lr_means follows an exponential decay schedule) */
 } TgsAdamSpec;
 
 int tgs_version(void);

@@ -1,6 +1,7 @@
 """CPU tests: the C-ABI library loads and exports every symbol include/tgs.h declares; argument
 validation (no GPU work is launched); host-side logic (layouts, split rule, cameras, DP)."""
 import ctypes as C
+import math
 import os
 import re
 import subprocess
@@ -245,3 +246,54 @@ def test_data_parallel_gloo_world2(tmp_path):
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "GLOO_OK 4012" in r.stdout  # bytes of the last exchanged buffer (1003 floats)
+
+
+def test_position_lr_schedule():
+    """Splatfacto's exponential decay of the position learning rate: 1.6e-4 at step
+    0, 1.6e-6 at max_steps and after, geometric in between; None keeps it constant."""
+    from touch_gs_amd.model import ModelConfig
+    c = ModelConfig()
+    assert abs(c.lr_means_at(0) - 1.6e-4) < 1e-12 and abs(c.lr_means_at(30000) - 1.6e-6) < 1e-12
+    assert abs(c.lr_means_at(15000) - 1.6e-5) < 1e-10 and c.lr_means_at(10 ** 6) == c.lr_means_at(30000)
+    assert ModelConfig(lr_means_final=None).lr_means_at(12345) == 1.6e-4
+
+
+def test_densify_screen_size_rules_cpu():
+    """Refinement decisions on a hand-made population (CPU tensors; refine() is plain torch):
+    hot + large screen radius -> split only before stop_screen_size_at; "too big" culls (scale or
+    screen size) only after the first opacity-reset interval."""
+    from touch_gs_amd.densify import DensifyConfig, DensityController
+    from touch_gs_amd.optim import FusedAdam, GaussianParams
+    N, K = 8, 1
+    def population():
+        gp = GaussianParams.allocate(N, K, "cpu")
+        gp.quats[:, 0] = 1.0
+        gp.log_scales[:] = math.log(0.001)           # small in world units
+        gp.opac_logit[:] = 2.0
+        gp.opac_logit[7] = -8.0                      # transparent -> always culled
+        gp.log_scales[6] = math.log(0.8)             # above cull_scale_thresh
+        return gp, FusedAdam(gp, dict(means=1e-4, log_scales=1e-3, quats=1e-3, opac_logit=1e-2, sh_dc=1e-3, sh_rest=1e-4))
+    cfg = DensifyConfig(warmup_length=0, refine_every=10, reset_alpha_every=3, stop_screen_size_at=100)
+    def stats(dc):
+        dc.vis_count[:] = 1.0
+        dc.grad_norm_sum[:] = 0.0
+        dc.grad_norm_sum[[0, 1, 2]] = 1.0            # hot: 0 (small), 1 (large on screen), 2 (very large on screen)
+        dc.max_radius[1] = 0.06                      # > split_screen_size
+        dc.max_radius[2] = 0.2                       # > cull_screen_size
+        dc.max_radius[3] = 0.2                       # cold but huge on screen
+    # (a) early (step 20 <= refine_every * reset_alpha_every = 30): no "too big" culls yet
+    gp, opt = population()
+    dc = DensityController(cfg, N, "cpu"); stats(dc)
+    _, _, info = dc.refine(gp, opt, 20)
+    assert info["culled"] == 1 and info["cloned"] == 1 and info["split"] == 2      # 0 cloned; 1, 2 split (screen size)
+    assert info["after"] == N - 1 - 2 + 1 + 2 * 2
+    # (b) after the first reset interval, still in the screen-size phase: scale and screen-size culls
+    gp, opt = population()
+    dc = DensityController(cfg, N, "cpu"); stats(dc)
+    _, _, info = dc.refine(gp, opt, 50)
+    assert info["culled"] == 4 and info["cloned"] == 1 and info["split"] == 1      # culled: 7, 6, 2, 3; split: 1
+    # (c) past stop_screen_size_at: the screen radius no longer matters
+    gp, opt = population()
+    dc = DensityController(cfg, N, "cpu"); stats(dc)
+    _, _, info = dc.refine(gp, opt, 150)
+    assert info["culled"] == 2 and info["cloned"] == 3 and info["split"] == 0      # culled: 7, 6; clones: 0, 1, 2

@@ -205,6 +205,7 @@ assert model._color_all is not None and dense._color_all is None
 # reference: one process, gradients of the two views averaged by hand, plain optimizer.step
 ref = fresh()
 for step in range(3):
+    ref.optimizer.lrs["means"] = ref.config.lr_means_at(step)     # the schedule train_step applies
     g = torch.zeros_like(ref.params.grad)
     for r in range(2):
         ref.forward_backward(views[(step * 2 + r) % 4])
@@ -468,6 +469,38 @@ def test_trainer_on_disk_dataset_in_reference_format(dev, tmp_path):
     ev = json.load(open(os.path.join(run, "eval.json")))
     assert {"psnr", "ssim", "depth_mse", "supervised_depth_mse"} <= set(ev["results"])
     assert len(os.listdir(tmp_path / "renders" / "rgb")) == 1 and len(os.listdir(tmp_path / "renders" / "depth")) == 1
+    # uncertainty (a variance) scales with the square of the pose factor
+    assert torch.allclose(sc.views[0].uncertainty, v0.uncertainty * sc.scale ** 2, atol=1e-3 * sc.scale ** 2 + 1e-7)
+
+    # the reference's run_eval step (experiment_utils/run_eval.py:37-57) with IS_REAL_WORLD exported
+    # (scripts/train_bunny_real.sh:54): <exp>/<exp>_<k>.json newest first, gt_* keys, render dump
+    from touch_gs_amd import run_eval
+    for d in ("realsense_depths", "touch_depth"):
+        os.makedirs(root / d)
+    for i in range(6):
+        v = make_view(N, W, H, deg, 11, dev, view=i, n_views=6)
+        d_m = v.depth.cpu().numpy().astype(np.float64)
+        plumbing.write_png16(str(root / "realsense_depths" / f"{i}.png"), plumbing.to_uint16_mm(d_m))
+        obj = np.zeros_like(d_m); obj[16:48, 24:72] = d_m[16:48, 24:72]
+        plumbing.write_png16(str(root / "touch_depth" / f"{i}.png"), plumbing.to_uint16_mm(obj))
+    old = os.environ.get("IS_REAL_WORLD")
+    os.environ["IS_REAL_WORLD"] = "True"
+    cwd = os.getcwd()
+    try:
+        os.chdir(tmp_path)
+        done = run_eval.main(["--input_dir", os.path.dirname(run), "--output_dir", str(tmp_path / "experiments"),
+                              "--exp_name", "disk_exp", "--past_n_trials", "1"])
+    finally:
+        os.chdir(cwd)
+        if old is None:
+            os.environ.pop("IS_REAL_WORLD")
+        else:
+            os.environ["IS_REAL_WORLD"] = old
+    assert [os.path.basename(p) for p in done] == ["disk_exp_1.json"]
+    res = json.load(open(done[0]))["results"]
+    assert {"psnr", "ssim", "lpips", "depth_mse", "supervised_depth_mse", "gt_depth_mse", "gt_object_depth_mse"} <= set(res)
+    assert abs(res["psnr"] - ev["results"]["psnr"]) < 1e-3 and res["gt_depth_mse"] > 0
+    assert len(os.listdir(tmp_path / "disk_exp_renders" / "rgb")) == 1
 
 
 @pytest.mark.parametrize("capacity", [0, 3000])
@@ -580,3 +613,39 @@ def test_bench_two_gpus_rccl(dev, tmp_path):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0
     assert line["dp_exchange"]["all_gather_busbw_GBs"] > 0 and line["dp_exchange"]["replicas_identical"] is True
+
+
+def test_nerfstudio_adapter_core_trains(dev):
+    """The nerfstudio adapter's core (everything DepthGSNerfstudioModel delegates to): six Splatfacto
+    parameter groups as nn.Parameters, differentiable render, loss from a nerfstudio-shaped batch
+    ([H,W,1] depth / uncertainty); a nerfstudio-style iteration -- loss.backward() + per-group Adam --
+    reduces the loss, and the loss equals the core model's on the same view."""
+    import types
+    from touch_gs_amd.nerfstudio_plugin import PARAM_GROUP_LRS, AutogradGaussians
+    from touch_gs_amd.scene import make_view, synthetic_gaussians
+    N, W, H, deg = 3000, 128, 80, 2
+    view = make_view(N, W, H, deg, 5, dev)
+    P, _ = synthetic_gaussians(N, W, H, deg, 99)
+    cfg = types.SimpleNamespace(sh_degree=deg, ssim_lambda=0.2, depth_loss_mult=0.2,
+                                depth_loss_type="DEPTH_UNCERTAINTY_WEIGHTED_LOSS", uncertainty_weight=1.0)
+    ag = AutogradGaussians(cfg, P["means"], torch.rand(N, 3), device=dev)
+    groups = ag.param_groups()
+    assert set(groups) == set(PARAM_GROUP_LRS) and all(isinstance(v[0], torch.nn.Parameter) for v in groups.values())
+    opts = {k: torch.optim.Adam(v, lr=PARAM_GROUP_LRS[k] * 20, eps=1e-15) for k, v in groups.items()}
+    batch = {"image": view.rgb, "depth_image": view.depth[..., None], "uncertainty": view.uncertainty[..., None]}
+    losses = []
+    for it in range(12):
+        out = ag.render(view.cam)
+        ld = ag.loss_dict(out, batch)
+        assert set(ld) == {"main_loss", "depth_loss"} and ld["depth_loss"].ndim == 0
+        loss = sum(ld.values())
+        for o in opts.values():
+            o.zero_grad()
+        loss.backward()
+        assert all(p[0].grad is not None and torch.isfinite(p[0].grad).all() for p in groups.values())
+        for o in opts.values():
+            o.step()
+        losses.append(float(loss))
+    assert losses[-1] < 0.9 * losses[0], losses
+    m = ag.metrics_dict(ag.render(view.cam), batch)
+    assert "psnr" in m and "depth_mse" in m

@@ -10,7 +10,7 @@ struct AdamK {
   unsigned row_step;                                      // (4 * grid stride) mod sh_row
   float lr_means, lr_scales, lr_quats, lr_opac, lr_dc, lr_rest;
   float b1, b2, eps, ibc1, isq_bc2, gscale;
-  const float* dyn;   // device {bias_corr1, bias_corr2} of the current step, or NULL
+  const float* dyn;   // device {bias_corr1, bias_corr2, lr_means} of the current step, or NULL
   const int32_t* guard;  // status word of the frame's binning ({n, overflow}), or NULL: overflow => no-op
 };
 
@@ -39,12 +39,13 @@ static inline AdamK make_adamk(int N, int sh_stride, const TgsAdamSpec* spec, fl
 }
 
 #ifdef __HIPCC__
-// Bias corrections kept in device memory (a captured hipGraph of the step is replayed with the
+// Bias corrections and the scheduled position learning rate kept in device memory (a captured hipGraph of the step is replayed with the
 // current step's values): same IEEE division / square root as make_adamk does on the host.
 __device__ __forceinline__ AdamK adam_resolve(AdamK a) {
   if (a.dyn) {
     a.ibc1 = 1.0f / a.dyn[0];
     a.isq_bc2 = 1.0f / sqrtf(a.dyn[1]);
+    a.lr_means = a.dyn[2];   // the scheduled (exponentially decayed) position learning rate
   }
   return a;
 }

@@ -8,6 +8,14 @@ Depth / uncertainty: 16-bit PNG in millimetres (x 1e-3 -> metres; legacy/datapar
 Seed points: points_touch.npy [M,3], points_colors.npy [M,3] in 0..255
 (utils/create_point_cloud_from_touches.py:243-244).  Poses are centred and scaled by 1/max|t|
 and depths by the same factor (legacy/dataparser_tactile.py:222-235,306,310).
+
+Real-world evaluation (the reference exports IS_REAL_WORLD=True before run_eval,
+scripts/train_bunny_real.sh:54, and its aggregator then averages results.gt_depth_mse /
+gt_object_depth_mse, experiment_utils/get_results.py:47-51): with ``real_world`` set (default: the
+IS_REAL_WORLD environment variable) every view also carries the sensor's depth
+``realsense_depths/<n>.png`` (the output of the pipeline's first step) as ground truth and the
+touched region ``touch_depth/<n>.png > 0`` as object mask.  The fork that computes the two numbers
+is absent; this definition (MSE over measured pixels / over measured object pixels) is the build's.
 """
 from __future__ import annotations
 
@@ -30,8 +38,12 @@ def _read_rgb(path: str) -> np.ndarray:
 
 class Scene:
     def __init__(self, root: str, train_split_fraction: float = 0.9, device="cuda", scale_poses: bool = True,
-                 depth_unit_scale_factor: float = 1e-3):
+                 depth_unit_scale_factor: float = 1e-3, real_world: Optional[bool] = None,
+                 gt_depth_dir: str = "realsense_depths", object_mask_dir: str = "touch_depth"):
         self.root = root
+        if real_world is None:
+            real_world = os.environ.get("IS_REAL_WORLD", "").lower() in ("1", "true", "yes")
+        self.real_world = real_world
         with open(os.path.join(root, "transforms.json")) as f:
             meta = json.load(f)
         frames = sorted(meta["frames"], key=lambda fr: fr["file_path"])
@@ -53,11 +65,27 @@ class Scene:
                 depth = torch.from_numpy(from_uint16_mm(read_png16(os.path.join(root, fr["depth_file_path"])))
                                          .astype(np.float32) * (depth_unit_scale_factor * 1e3) * self.scale)
             if "uncertainty_file_path" in fr:
+                # the map is a variance of the depth in metres (utils/fuse_touch_vision.py:76-202): in the
+                # scaled scene frame it scales with the square of the depth factor, so that the
+                # residual^2 / (uncertainty_weight * U + eps) term keeps its meaning whatever the scene size
                 unc = torch.from_numpy(from_uint16_mm(read_png16(os.path.join(root, fr["uncertainty_file_path"])))
-                                       .astype(np.float32))
-            self.views.append(View(cam=cam, rgb=torch.from_numpy(rgb).to(device).contiguous(),
-                                   depth=None if depth is None else depth.to(device).contiguous(),
-                                   uncertainty=None if unc is None else unc.to(device).contiguous()))
+                                       .astype(np.float32) * (depth_unit_scale_factor * 1e3 * self.scale) ** 2)
+            view = View(cam=cam, rgb=torch.from_numpy(rgb).to(device).contiguous(),
+                        depth=None if depth is None else depth.to(device).contiguous(),
+                        uncertainty=None if unc is None else unc.to(device).contiguous())
+            if real_world:
+                stem = os.path.splitext(os.path.basename(fr["file_path"]))[0]
+                gt_path = os.path.join(root, gt_depth_dir, stem + ".png")
+                if os.path.exists(gt_path):
+                    from .prepare import resize_bilinear
+                    gt = resize_bilinear(from_uint16_mm(read_png16(gt_path)), H, W).astype(np.float32)
+                    view.gt_depth = (torch.from_numpy(gt) * (depth_unit_scale_factor * 1e3) * self.scale).to(device)
+                    m_path = os.path.join(root, object_mask_dir, stem + ".png")
+                    if os.path.exists(m_path):
+                        m = read_png16(m_path) > 0
+                        if m.shape == (H, W):
+                            view.object_mask = torch.from_numpy(m).to(device)
+            self.views.append(view)
         names = [fr["file_path"] for fr in frames]
         self.names = names
         self.i_train, self.i_eval = get_train_eval_split_fraction(names, train_split_fraction)

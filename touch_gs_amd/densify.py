@@ -34,6 +34,14 @@ class DensifyConfig:
     cull_scale_thresh: float = 0.5
     reset_alpha_every: int = 30
     stop_split_at: int = 15000
+    # screen-size criteria of Splatfacto (UNVERIFIED-PRIOR): until
+    # ``stop_screen_size_at`` a Gaussian whose largest normalised screen radius (radius / max(W, H)
+    # over the views since the last refinement) exceeds ``split_screen_size`` is split when its
+    # gradient is high, and one above ``cull_screen_size`` is culled; "too big" culls (world scale
+    # or screen size) start after the first opacity-reset interval
+    cull_screen_size: float = 0.15
+    split_screen_size: float = 0.05
+    stop_screen_size_at: int = 4000
     max_gaussians: int = 5_000_000
 
 
@@ -85,14 +93,23 @@ class DensityController:
         scale_max = torch.exp(params.log_scales).max(dim=-1).values
         hot = (avg_grad > c.densify_grad_thresh) & (self.vis_count > 0)
         do_densify = step < c.stop_split_at
-        split = hot & (scale_max > c.densify_size_thresh) & do_densify
-        clone = hot & (scale_max <= c.densify_size_thresh) & do_densify
+        big = scale_max > c.densify_size_thresh
+        screen_phase = step < c.stop_screen_size_at
+        if screen_phase:
+            big = big | (self.max_radius > c.split_screen_size)
+        split = hot & big & do_densify
+        clone = hot & ~big & do_densify
         budget = c.max_gaussians - N
         if budget <= 0:
             split &= False
             clone &= False
         opac = torch.sigmoid(params.opac_logit)
-        cull = (opac < c.cull_alpha_thresh) | (scale_max > c.cull_scale_thresh)
+        cull = opac < c.cull_alpha_thresh
+        if step > c.refine_every * c.reset_alpha_every:
+            too_big = scale_max > c.cull_scale_thresh
+            if screen_phase:
+                too_big = too_big | (self.max_radius > c.cull_screen_size)
+            cull = cull | too_big
         keep = ~cull & ~split  # split parents are replaced by their samples
         names = GaussianParams.NAMES
         cur = {k: getattr(params, k) for k in names}

@@ -44,11 +44,22 @@ class ModelConfig:
     background_color: tuple = (0.0, 0.0, 0.0)
     # Adam learning rates per group (Splatfacto defaults)
     lr_means: float = 1.6e-4
+    # Splatfacto's position learning rate decays exponentially 1.6e-4 -> 1.6e-6 over the run
+    # (UNVERIFIED-PRIOR); lr_means_final = None keeps it constant
+    lr_means_final: Optional[float] = 1.6e-6
+    lr_means_max_steps: int = 30000
     lr_scales: float = 5e-3
     lr_quats: float = 1e-3
     lr_opac: float = 5e-2
     lr_sh_dc: float = 2.5e-3
     lr_sh_rest: float = 1.25e-4
+
+    def lr_means_at(self, step: int) -> float:
+        """ExponentialDecay schedule: lr_init * (lr_final / lr_init) ** min(step / max_steps, 1)."""
+        if self.lr_means_final is None or self.lr_means_max_steps <= 0:
+            return self.lr_means
+        t = min(max(step, 0) / self.lr_means_max_steps, 1.0)
+        return float(math.exp(math.log(self.lr_means) * (1 - t) + math.log(self.lr_means_final) * t))
 
     def lrs(self) -> Dict[str, float]:
         return dict(means=self.lr_means, log_scales=self.lr_scales, quats=self.lr_quats,
@@ -68,6 +79,11 @@ class View:
     depth: Optional[torch.Tensor] = None   # [H,W]
     uncertainty: Optional[torch.Tensor] = None  # [H,W]
     n_valid_depth: Optional[int] = None    # cached count of depth>0 (dataset constant)
+    # evaluation only (IS_REAL_WORLD runs, reference scripts/train_bunny_real.sh:54): the sensor's
+    # ground-truth depth and the object mask behind results.gt_depth_mse / gt_object_depth_mse
+    # (experiment_utils/get_results.py:47-51)
+    gt_depth: Optional[torch.Tensor] = None     # [H,W], 0 = no measurement
+    object_mask: Optional[torch.Tensor] = None  # [H,W] bool
 
     def valid_count(self) -> int:
         if self.n_valid_depth is None:
@@ -127,7 +143,8 @@ class DepthGaussianSplattingModel:
         cnt = m.sum()
         dhat = depth_acc / torch.clamp(alpha, min=1e-10)
         r2 = (dhat - view.depth) ** 2
-        if c.depth_loss_type == "DEPTH_UNCERTAINTY_WEIGHTED_LOSS":
+        # a view without an uncertainty map is supervised with the SIMPLE form (same rule as loss_spec)
+        if c.depth_loss_type == "DEPTH_UNCERTAINTY_WEIGHTED_LOSS" and view.uncertainty is not None:
             r2 = r2 / (c.uncertainty_weight * view.uncertainty + c.depth_eps)
         return torch.where(m, r2, torch.zeros_like(r2)).sum() / torch.clamp(cnt, min=1)
 
@@ -165,6 +182,13 @@ class DepthGaussianSplattingModel:
             d = outputs["depth"][..., 0]
             metrics["depth_mse"] = float(((d - view.depth)[valid] ** 2).mean()) if valid.any() else 0.0
             metrics["supervised_depth_mse"] = metrics["depth_mse"]
+        if view.gt_depth is not None:   # keys the reference's aggregator averages when present
+            d = outputs["depth"][..., 0]
+            valid = view.gt_depth > 0
+            metrics["gt_depth_mse"] = float(((d - view.gt_depth)[valid] ** 2).mean()) if valid.any() else 0.0
+            if view.object_mask is not None:
+                obj = valid & view.object_mask
+                metrics["gt_object_depth_mse"] = float(((d - view.gt_depth)[obj] ** 2).mean()) if obj.any() else 0.0
         images = {"img": torch.cat([view.rgb, outputs["rgb"]], dim=1),
                   "depth": outputs["depth"], "accumulation": outputs["accumulation"]}
         return metrics, images
@@ -322,6 +346,7 @@ class DepthGaussianSplattingModel:
         """One optimizer iteration on one view (per rank).  ``dp``: a parallel.GradSync or None."""
         distributed = dp is not None and dp.active
         opt = self.optimizer
+        opt.lrs["means"] = self.config.lr_means_at(self.step)   # scheduled position learning rate
         deg = self.active_sh_degree()
         graphs = getattr(self, "_graphs", None)
         if graphs and not distributed and getattr(self, "density", None) is None:

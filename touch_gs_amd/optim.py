@@ -104,13 +104,13 @@ class FusedAdam:
         return s
 
     def upload_bias_corr(self):
-        """Write the current step's {1-beta1^t, 1-beta2^t} to the device scalars (stream ordered,
-        no host sync): called once per step before a captured step graph is replayed."""
+        """Write the current step's {1-beta1^t, 1-beta2^t, lr_means} to the device scalars (stream
+        ordered, no host sync): called once per step before a captured step graph is replayed."""
         if self._dyn is None:
-            self._dyn = torch.ones(2, dtype=torch.float32, device=self.p.flat.device)
-        vals = (C.c_float * 2)(1.0 - self.betas[0] ** self.t, 1.0 - self.betas[1] ** self.t)
+            self._dyn = torch.ones(4, dtype=torch.float32, device=self.p.flat.device)
+        vals = (C.c_float * 3)(1.0 - self.betas[0] ** self.t, 1.0 - self.betas[1] ** self.t, self.lrs["means"])
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        check(_lib.load().tgs_store_small(ptr(self._dyn), vals, 2, stream), "tgs_store_small")
+        check(_lib.load().tgs_store_small(ptr(self._dyn), vals, 3, stream), "tgs_store_small")
 
     def begin_step(self):
         """Advance the step counter once per optimizer iteration (before step_range calls)."""

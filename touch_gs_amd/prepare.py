@@ -1,7 +1,8 @@
 """Directory-level data preparation: what ``scripts/train_<scene>.sh`` does before ``ns-train``
-(reference scripts/train_bunny_real.sh:16-48), step for step and with the reference's directory and
+(reference scripts/train_bunny_real.sh:10-48), step for step and with the reference's directory and
 flag names, on top of the array-level functions in :mod:`touch_gs_amd.plumbing`.
 
+    python -m touch_gs_amd.prepare read_realsense_depth --base_repo_path SCENE
     python -m touch_gs_amd.prepare read_touch_depths --base_repo_path SCENE
     python -m touch_gs_amd.prepare fuse_touch_vision --root_dir SCENE --aligning_depths realsense_depths \\
         --touch_depth touch_depth --zoe_depth_path zoe_depth --use_uncertainty --vision_output_dir vision \\
@@ -12,13 +13,14 @@ flag names, on top of the array-level functions in :mod:`touch_gs_amd.plumbing`.
         --touch_var_dir touch_var --image_dir imgs --transform_json_path transforms.json --train_split 0.08
 
 On-disk contract (all depth-like images are uint16 PNGs in millimetres):
+  realsense_depth/<name>.npy (mm) -> realsense_depths/<name>.png  (utils/read_realsense_depth.py:113-139)
   imgs/<n>.png, gpis_depth/Image<n>.npy, gpis_var/Image<n>.npy  (utils/read_touch_depths.py:24-45)
   touch_depth/<n>.png, touch_var/<n>.png                        (utils/read_touch_depths.py:55-56)
   <vision_output_dir>/, <vision_output_dir>_baseline/, <fused_output_dir>/, <fused_output_dir>_uncertainty/
                                                                 (utils/fuse_touch_vision.py:229-234,372-386)
   points_touch.npy, points_colors.npy                           (utils/create_point_cloud_from_touches.py:243-244)
-CPU / NumPy like the reference's own plumbing; monocular depth (ZoeDepth) and the RealSense
-conversion are inputs here (pretrained weights / sensor dumps are not part of the hot path).
+CPU / NumPy like the reference's own plumbing; monocular depth (ZoeDepth, pretrained weights) is an
+input here.
 """
 from __future__ import annotations
 
@@ -56,6 +58,25 @@ def resize_bilinear(a: np.ndarray, height: int, width: int) -> np.ndarray:
 
 
 # ------------------------------------------------------------------------------------------------
+def read_realsense_depth(base_repo_path: str, old_intrinsics=(360, 360, 243, 137.8),
+                         new_intrinsics=(1297, 1304, 620.91, 238.28), new_size=(1280, 720)) -> int:
+    """realsense_depth/<name>.npy (millimetres, sensor intrinsics) -> realsense_depths/<name>.png:
+    metres, re-sampled on the training camera's pixel grid, stored as uint16 mm (reference
+    utils/read_realsense_depth.py:113-139; the first step of scripts/train_bunny_real.sh:10).
+    Returns the number of depth images."""
+    src, dst = os.path.join(base_repo_path, "realsense_depth"), os.path.join(base_repo_path, "realsense_depths")
+    os.makedirs(dst, exist_ok=True)
+    n = 0
+    for name in sorted(os.listdir(src)):
+        if ".npy" not in name:
+            continue
+        d = np.load(os.path.join(src, name)) / 1000.0
+        d = P.convert_intrinsics(d, old_intrinsics, new_intrinsics, new_size)
+        P.write_png16(os.path.join(dst, name.split(".")[0] + ".png"), (d * 1000).astype(np.uint16))
+        n += 1
+    return n
+
+
 def read_touch_depths(base_repo_path: str) -> int:
     """gpis_depth/Image<n>.npy + gpis_var/Image<n>.npy -> touch_depth/<n>.png + touch_var/<n>.png for
     every imgs/<n>.png (reference utils/read_touch_depths.py:24-56).  Returns the number of images."""
@@ -156,6 +177,8 @@ def create_point_cloud_from_touches(root_dir: str, image_dir: str, touch_depth_d
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     sub = ap.add_subparsers(dest="step", required=True)
+    s = sub.add_parser("read_realsense_depth")
+    s.add_argument("--base_repo_path", required=True)
     s = sub.add_parser("read_touch_depths")
     s.add_argument("--base_repo_path", required=True)
     s = sub.add_parser("fuse_touch_vision")
@@ -176,7 +199,9 @@ def main(argv=None):
     s.add_argument("--seed", type=int, default=None)
     s.add_argument("--viz", action="store_true", help="accepted for compatibility; there is no viewer here")
     a = ap.parse_args(argv)
-    if a.step == "read_touch_depths":
+    if a.step == "read_realsense_depth":
+        print("wrote", read_realsense_depth(a.base_repo_path), "realsense depth images")
+    elif a.step == "read_touch_depths":
         print("wrote", read_touch_depths(a.base_repo_path), "touch depth / variance images")
     elif a.step == "fuse_touch_vision":
         print("fused", fuse_touch_vision(a.root_dir, a.aligning_depths, a.touch_depth, a.zoe_depth_path,
