@@ -221,16 +221,26 @@ int tgs_project_bwd_adam(const TgsCamera* cam /*[host]*/, int N, int sh_stride, 
  *                                order from v_color_all[world][3N+4] (the all-gathered blocks).
  *                                The means inside `params` must still be the ones the forward
  *                                pass used (step the geometry segments with tgs_adam_step
- *                                afterwards).  Requires 3*sh_stride % 4 == 0. */
+ *                                afterwards).  Requires 3*sh_stride % 4 == 0.
+ *   Sync-free intersection budget under data parallelism: with `skip_if_overflow` (the frame's
+ *   status word) tgs_project_bwd_color does nothing on an overflowed frame except setting the pad of
+ *   its block to 1; after the all-gather tgs_dp_agree_overflow writes status_out = {0, any pad != 0}
+ *   (identical on every rank) and raises the caller's sticky word, and the optimizer entry points
+ *   take status_out as their `skip_if_overflow`. */
 int tgs_project_bwd_color(const TgsCamera* cam /*[host]*/, int N, const float* means,
                           const float* log_scales, const float* quats, const float* opac_logit,
                           const float* sh, int sh_stride, int sh_deg, const float* splats,
                           const int32_t* group_base, const float* partials, float* v_means,
                           float* v_log_scales, float* v_quats, float* v_opac_logit, float* v_color,
-                          float* v_xy, void* stream);
+                          float* v_xy, const int32_t* skip_if_overflow /*status[2] of the frame, or NULL*/,
+                          void* stream);
+int tgs_dp_agree_overflow(int world, int N, const float* v_color_all, int32_t* status_out,
+                          int32_t* sticky_overflow /*may be NULL*/, void* stream);
 int tgs_adam_step_sh_gathered(int world, int N, int sh_stride, int sh_deg, float* params,
                               const float* v_color_all, float* exp_avg, float* exp_avg_sq,
-                              const TgsAdamSpec* spec /*[host]*/, float grad_scale, void* stream);
+                              const TgsAdamSpec* spec /*[host]*/, float grad_scale,
+                              const int32_t* skip_if_overflow /*status_out of tgs_dp_agree_overflow, or NULL*/,
+                              void* stream);
 
 /* Stores n <= 8 host floats into device memory; the values travel as launch arguments, so the call is
  * stream ordered without any host staging buffer.  Used to refresh TgsAdamSpec.device_bias_corr

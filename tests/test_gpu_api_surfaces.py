@@ -217,6 +217,24 @@ d = (ref.params.flat - model.params.flat).abs().max().item()
 d2 = (ref.params.flat - dense.params.flat).abs().max().item()
 assert d < 1e-6 and d2 < 1e-6, (d, d2)
 dp.barrier()
+# sync-free intersection budget under data parallelism: a forced overflow (capacity far too small) is
+# agreed across the ranks on the device, noticed by both at the same step and replayed; the result is
+# bit-identical to the synchronous budget and the replicas stay identical
+def run_budget(speculative):
+    m = fresh()
+    if speculative:
+        m.enable_speculative_budget(capacity=3000, max_in_flight=2)
+    for step in range(7):
+        m.train_step(views[dp.views_for_step(step, 4)], dp)
+    m.flush()
+    torch.cuda.synchronize()
+    return m
+spec, base = run_budget(True), run_budget(False)
+assert spec.speculative_replays > 0 and spec.step == base.step == 7 and spec.optimizer.t == base.optimizer.t == 7
+assert torch.equal(spec.params.flat, base.params.flat), (spec.params.flat - base.params.flat).abs().max().item()
+assert torch.equal(spec.optimizer.exp_avg_sq, base.optimizer.exp_avg_sq)
+dp.assert_replicas_identical(spec.params.flat)
+dp.barrier()
 # densification under data parallelism: statistics are reduced (sum, sum, max) and the split sampler
 # is seeded from the step, so both replicas refine identically
 from touch_gs_amd.densify import DensifyConfig

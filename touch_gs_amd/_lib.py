@@ -55,8 +55,9 @@ SIGNATURES = {
     "tgs_reduce_partials": (C.c_int, [_I, _P, _P, C.POINTER(TgsCamera), _P, _P, _P]),
     "tgs_project_bwd": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I] + [_P] * 12),
     "tgs_project_bwd_adam": (C.c_int, [C.POINTER(TgsCamera), _I, _I, _I, _P, _P, _P, C.POINTER(TgsAdamSpec), _P, _P, _P, _P, _P, _P]),
-    "tgs_project_bwd_color": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I] + [_P] * 10),
-    "tgs_adam_step_sh_gathered": (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _P, C.POINTER(TgsAdamSpec), C.c_float, _P]),
+    "tgs_project_bwd_color": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I] + [_P] * 11),
+    "tgs_dp_agree_overflow": (C.c_int, [_I, _I, _P, _P, _P, _P]),
+    "tgs_adam_step_sh_gathered": (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _P, C.POINTER(TgsAdamSpec), C.c_float, _P, _P]),
     "tgs_store_small": (C.c_int, [_P, C.POINTER(C.c_float), _I, _P]),
     "tgs_adam_step": (C.c_int, [_I, _I, _P, _P, _P, _P, C.POINTER(TgsAdamSpec), C.c_float, C.c_int64, C.c_int64, _P, _P]),
     "tgs_ssim_fwd_bwd": (C.c_int, [_I, _I, _P, _P, C.c_float, _P, _P, _P, _P]),

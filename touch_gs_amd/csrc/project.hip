@@ -383,7 +383,10 @@ __global__ __launch_bounds__(256) void k_project_bwd(
     float* __restrict__ v_xy, const int32_t* __restrict__ guard) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= N) return;
-  if (guard && guard[1]) return;   // overflowed frame: the pair index space is not backed by memory
+  if (guard && guard[1]) {  // overflowed frame: the pair index space is not backed by memory
+    if (v_color && g == 0) v_color[3 * (size_t)N + 3] = 1.f;   // tell the other ranks (tgs_dp_agree_overflow)
+    return;
+  }
   if (v_color && g == 0) {  // trailer of the colour-gradient block: this view's camera position
     v_color[3 * (size_t)N] = cam.campos[0]; v_color[3 * (size_t)N + 1] = cam.campos[1];
     v_color[3 * (size_t)N + 2] = cam.campos[2]; v_color[3 * (size_t)N + 3] = 0.f;
@@ -498,7 +501,11 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
     float* __restrict__ v_opac_logit, float* __restrict__ v_sh, float* __restrict__ v_xy,
     AdamK ad_in, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq) {
   // overflowed frame: the pair index space is not backed by memory and the step must not touch the model
-  if (ad_in.guard && ad_in.guard[1]) return;
+  if (ad_in.guard && ad_in.guard[1]) {
+    // colour mode (v_sh is the rank's colour-gradient block): the pad slot carries the overflow flag
+    if (COLOR_ONLY && blockIdx.x == 0 && threadIdx.x == 0) v_sh[3 * (size_t)N + 3] = 1.f;
+    return;
+  }
   const AdamK ad = FUSE_ADAM ? adam_resolve(ad_in) : ad_in;
   constexpr int K = (DEG + 1) * (DEG + 1);   // active bases; sh_stride == KS here
   static_assert(KS >= K && (3 * KS) % 4 == 0, "storage must hold the active degree in whole float4s");
@@ -701,6 +708,7 @@ __global__ __launch_bounds__(256) void k_adam_sh_gathered(
     int world, int N, int sh_stride, const float* __restrict__ means,
     float* __restrict__ sh, const float* __restrict__ v_color_all, AdamK ad_in,
     float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq) {
+  if (ad_in.guard && ad_in.guard[1]) return;   // a rank's frame overflowed (tgs_dp_agree_overflow): no update
   const AdamK ad = adam_resolve(ad_in);
   constexpr int K = (DEG + 1) * (DEG + 1);
   const int ROW = 3 * sh_stride, RS = ROW + 4, F4 = ROW / 4;
@@ -1036,7 +1044,7 @@ extern "C" int tgs_project_bwd_color(const TgsCamera* cam, int N, const float* m
                                      int sh_deg, const float* splats, const int32_t* group_base,
                                      const float* partials, float* v_means, float* v_log_scales,
                                      float* v_quats, float* v_opac_logit, float* v_color,
-                                     float* v_xy, void* stream) {
+                                     float* v_xy, const int32_t* skip_if_overflow, void* stream) {
   TGS_CHECK_ARG(camera_ok(cam), "bad camera");
   if (N <= 0) return TGS_OK;
   TGS_CHECK_ARG(means && log_scales && quats && opac_logit && sh && splats && group_base && partials,
@@ -1049,6 +1057,7 @@ extern "C" int tgs_project_bwd_color(const TgsCamera* cam, int N, const float* m
   hipStream_t s = (hipStream_t)stream;
   if (lds_k8_ok(sh_deg, sh_stride)) {
     AdamK none{};
+    none.guard = skip_if_overflow;
     const size_t lds_bytes = 256 * (size_t)(3 * sh_stride + 4) * sizeof(float);
 #define LAUNCH_C(D, KS)                                                                          \
   hipLaunchKernelGGL((k_project_bwd_lds<D, KS, false, true>), grid, block, lds_bytes, s, k, N,   \
@@ -1065,7 +1074,7 @@ extern "C" int tgs_project_bwd_color(const TgsCamera* cam, int N, const float* m
   hipLaunchKernelGGL(k_project_bwd<D>, grid, block, 0, s, k, N, means, log_scales, quats,        \
                      opac_logit, sh, sh_stride, splats, group_base, partials,                    \
                      (const float*)nullptr, v_means, v_log_scales, v_quats, v_opac_logit,        \
-                     (float*)nullptr, v_color, v_xy, (const int32_t*)nullptr)
+                     (float*)nullptr, v_color, v_xy, skip_if_overflow)
   switch (sh_deg) {
     case 0: LAUNCH(0); break;
     case 1: LAUNCH(1); break;
@@ -1077,16 +1086,41 @@ extern "C" int tgs_project_bwd_color(const TgsCamera* cam, int N, const float* m
   return TGS_OK;
 }
 
+// Sync-free intersection budget under data parallelism: every rank's colour-gradient block carries
+// its frame's overflow flag in the pad slot; after the all-gather each rank derives the SAME verdict.
+static __global__ void k_dp_agree_overflow(int world, size_t blk, const float* __restrict__ v_color_all,
+                                           int32_t* __restrict__ status_out, int32_t* __restrict__ sticky) {
+  int any = 0;
+  for (int r = threadIdx.x; r < world; r += TGS_WAVE) any |= v_color_all[r * blk + blk - 1] != 0.f;
+  any = __ballot(any) != 0ull;
+  if (threadIdx.x == 0) {
+    status_out[0] = 0;
+    status_out[1] = any;
+    if (any && sticky) *sticky = 1;
+  }
+}
+
+extern "C" int tgs_dp_agree_overflow(int world, int N, const float* v_color_all, int32_t* status_out,
+                                     int32_t* sticky_overflow, void* stream) {
+  TGS_CHECK_ARG(world >= 1 && N >= 0, "bad size");
+  TGS_CHECK_ARG(v_color_all && status_out, "null pointer");
+  hipLaunchKernelGGL(k_dp_agree_overflow, dim3(1), dim3(TGS_WAVE), 0, (hipStream_t)stream, world,
+                     3 * (size_t)N + 4, v_color_all, status_out, sticky_overflow);
+  TGS_CHECK_LAUNCH();
+  return TGS_OK;
+}
+
 extern "C" int tgs_adam_step_sh_gathered(int world, int N, int sh_stride, int sh_deg, float* params,
                                          const float* v_color_all, float* exp_avg,
                                          float* exp_avg_sq, const TgsAdamSpec* spec,
-                                         float grad_scale, void* stream) {
+                                         float grad_scale, const int32_t* skip_if_overflow, void* stream) {
   TGS_CHECK_ARG(world >= 1 && N >= 0, "bad size");
   if (N == 0) return TGS_OK;
   TGS_CHECK_ARG(params && v_color_all && exp_avg && exp_avg_sq && spec, "null pointer");
   TGS_CHECK_ARG(sh_deg >= 0 && sh_deg <= 3 && sh_stride >= (sh_deg + 1) * (sh_deg + 1), "bad SH degree / stride");
   TGS_CHECK_ARG((3 * sh_stride) % 4 == 0, "SH row (3*sh_stride floats) must be a multiple of 16 bytes");
-  const AdamK a = make_adamk(N, sh_stride, spec, grad_scale);
+  AdamK a = make_adamk(N, sh_stride, spec, grad_scale);
+  a.guard = skip_if_overflow;
   const dim3 grid((N + 255) / 256), block(256);
   const size_t lds_bytes = 256 * (size_t)(3 * sh_stride + 4) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;

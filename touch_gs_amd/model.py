@@ -230,7 +230,7 @@ class DepthGaussianSplattingModel:
                                                     begin=begin_step, guard=guard)
         elif color_block is not None:   # data-parallel: geometry gradients + colour-gradient block
             v_xy = ops.project_bwd_color(cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, splats,
-                                         group_base, partials, p.grad_views()[:4], color_block, want_v_xy)
+                                         group_base, partials, p.grad_views()[:4], color_block, want_v_xy, guard=guard)
         else:
             v_xy = ops.project_bwd(cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, splats,
                                    group_base, partials, out=p.grad_views(), want_v_xy=want_v_xy, guard=guard)[5]
@@ -254,9 +254,13 @@ class DepthGaussianSplattingModel:
 
     # -- sync-free intersection budget ---------------------------------------------------------
     def enable_speculative_budget(self, capacity: int = 0, max_in_flight: int = 4) -> None:
-        """Train without the per-step read-back of the intersection count (single process, no
-        densification).  Every step's status word is copied to pinned host memory asynchronously and
-        looked at a few steps later.  Correctness does not depend on guessing the capacity right: a
+        """Train without the per-step read-back of the intersection count (no densification).  Every
+        step's status word is copied to pinned host memory asynchronously and looked at a few steps
+        later.  Data parallel (factored exchange only): the ranks agree on the overflow verdict on the
+        device (the flag rides in the pad of the all-gathered colour block, ops.dp_agree_overflow), the
+        optimizer kernels of ALL ranks are no-ops from the overflowing step on, and every rank inspects
+        the verdict of step s - max_in_flight exactly at step s -- so all ranks notice at the same
+        step and replay the same steps (the collectives stay matched).  Correctness does not depend on guessing the capacity right: a
         frame that overflows sets a sticky device word that empties every later frame and turns the
         guarded optimizer kernels into no-ops, so when the host notices it clears the word, grows the
         buffers, rewinds its step counters and replays the affected views -- the model ends up exactly
@@ -267,37 +271,47 @@ class DepthGaussianSplattingModel:
         self._pending = collections.deque()
         self._max_in_flight = max_in_flight
         self._pinned = []
+        self._dp_status = None      # device {0, any rank overflowed} of the last data-parallel step
+        self._dp = None
 
-    def _speculative_track(self, view: View) -> None:
-        host = self._pinned.pop() if self._pinned else torch.empty(2, dtype=torch.int32).pin_memory()
-        host.copy_(self.last["status"], non_blocking=True)
+    def _speculative_track(self, view: View, distributed: bool = False) -> None:
+        host = self._pinned.pop() if self._pinned else torch.empty(4, dtype=torch.int32).pin_memory()
+        host[:2].copy_(self.last["status"], non_blocking=True)
+        # data parallel: the verdict is the agreed flag, not this rank's own
+        host[2:].copy_(self._dp_status if distributed else self.last["status"], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self._pending.append((view, host, ev))
-        self._speculative_poll(block=len(self._pending) > self._max_in_flight)
+        if distributed:   # deterministic: every rank looks at step s - max_in_flight exactly at step s
+            if len(self._pending) > self._max_in_flight:
+                self._speculative_poll(block=True, only_one=True)
+        else:
+            self._speculative_poll(block=len(self._pending) > self._max_in_flight)
 
-    def _speculative_poll(self, block: bool = False, drain: bool = False) -> None:
-        while self._pending and (drain or block or self._pending[0][2].query()):
+    def _speculative_poll(self, block: bool = False, drain: bool = False, only_one: bool = False) -> None:
+        while self._pending and (drain or block or (not only_one and self._dp is None and self._pending[0][2].query())):
             view, host, ev = self._pending[0]
             ev.synchronize()
             block = False
-            if int(host[1]) == 0:
+            if int(host[3]) == 0:
                 self._pending.popleft()
                 self._pinned.append(host)
+                if only_one:
+                    return
                 continue
             # overflow: this step and everything enqueued after it did nothing on the device
             torch.cuda.synchronize()
             redo = list(self._pending)
             self._pending.clear()
-            need = max(int(h[0]) for _, h, _ in redo)
-            self.budget.capacity = int(need * self.budget.growth) + 1024
+            need = max(int(h[0]) for _, h, _ in redo)      # this rank's own largest frame
+            self.budget.capacity = max(self.budget.capacity, int(need * self.budget.growth) + 1024)
             self.budget.sticky.zero_()
             self.optimizer.t -= len(redo)
             self.step -= len(redo)
             self.speculative_replays = getattr(self, "speculative_replays", 0) + len(redo)
             for v, h, _ in redo:
                 self._pinned.append(h)
-                self.train_step(v)
+                self.train_step(v, self._dp)
 
     def flush(self) -> None:
         """Wait for every enqueued step and settle pending overflow checks (call before reading
@@ -363,8 +377,10 @@ class DepthGaussianSplattingModel:
         fuse = (not distributed) and self.fuse_adam and opt.can_fuse_with_backward(deg)
         factored = distributed and self.dp_factored_sh and opt.can_gather_sh()
         density = getattr(self, "density", None)
-        if self.budget.speculative and (distributed or density is not None):
-            raise RuntimeError("the speculative intersection budget is for single-process training without densification")
+        if self.budget.speculative and (density is not None or (distributed and not factored)):
+            raise RuntimeError("the speculative intersection budget does not combine with densification or with the "
+                               "dense (flat all-reduce) data-parallel exchange")
+        self._dp = dp if distributed else None
         block = None
         if factored:
             n = 3 * self.params.N + 4
@@ -377,17 +393,27 @@ class DepthGaussianSplattingModel:
         if density is not None:
             density.accumulate(self.last["v_xy"], self.last["radii"], view.cam.W, view.cam.H)
         if factored:
+            dguard = None
+            if self.budget.speculative:   # agree the overflow verdict across ranks before anything touches the model
+                if self._dp_status is None:
+                    self._dp_status = torch.zeros(2, dtype=torch.int32, device=self.params.flat.device)
+                dguard = self._dp_status
+
+            def step_sh(allc, scale):
+                if dguard is not None:
+                    ops.dp_agree_overflow(dp.world, self.params.N, allc, dguard, self.budget.sticky)
+                opt.step_sh_gathered(dp.world, deg, allc, scale, guard=dguard)
+
             dp.gather_color_reduce_geom_and_step(
-                self.params.grad[:opt.geom_end()], block, self._color_all,
-                lambda allc, scale: opt.step_sh_gathered(dp.world, deg, allc, scale),
-                opt.step_range, opt.begin_step)
+                self.params.grad[:opt.geom_end()], block, self._color_all, step_sh,
+                lambda b, e, scale: opt.step_range(b, e, scale, guard=dguard), opt.begin_step)
         elif distributed:
             dp.reduce_and_step(self.params.grad, self.optimizer.step_range, self.optimizer.begin_step)
         elif not fuse:
             self.optimizer.step(guard=self.last["guard"])
         self.step += 1
-        if self.budget.speculative and not distributed and density is None:
-            self._speculative_track(view)
+        if self.budget.speculative and density is None:
+            self._speculative_track(view, distributed)
         if density is not None and density.due(self.step):
             self.params, self.optimizer, self.last_refine = density.refine(self.params, self.optimizer, self.step, dp)
             self.budget = ops.IntersectBudget()  # the intersection count changes with N

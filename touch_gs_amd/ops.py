@@ -278,7 +278,7 @@ def project_bwd(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_deg, s
 
 
 def project_bwd_color(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_deg, splats, group_base,
-                      partials, out, v_color, want_v_xy=False):
+                      partials, out, v_color, want_v_xy=False, guard=None):
     """K8 of the data-parallel step (tgs_project_bwd_color): geometry gradients into ``out`` =
     (v_means, v_log_scales, v_quats, v_opac_logit) and, instead of the SH gradient, the block
     ``v_color`` [3N+4] = clamp-gated colour gradients | camera position | pad.  -> v_xy or None."""
@@ -292,8 +292,16 @@ def project_bwd_color(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_
     check(lib.tgs_project_bwd_color(C.byref(cs), N, ptr(means), ptr(log_scales), ptr(quats), ptr(opac_logit),
                                     ptr(sh), sh.shape[1], sh_deg, ptr(splats), ptr(group_base), ptr(partials),
                                     ptr(v_means), ptr(v_ls), ptr(v_q), ptr(v_ol), ptr(v_color), ptr(v_xy),
-                                    _stream()), "tgs_project_bwd_color")
+                                    ptr(guard), _stream()), "tgs_project_bwd_color")
     return v_xy
+
+
+def dp_agree_overflow(world: int, N: int, v_color_all, status_out, sticky=None):
+    """After the all-gather of the colour blocks: status_out = {0, any rank's frame overflowed}
+    (identical on every rank); raises ``sticky`` too.  (tgs_dp_agree_overflow)"""
+    check(_lib.load().tgs_dp_agree_overflow(world, N, ptr(v_color_all), ptr(status_out), ptr(sticky), _stream()),
+          "tgs_dp_agree_overflow")
+    return status_out
 
 
 # ------------------------------------------------------------------------------------------------

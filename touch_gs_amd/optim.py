@@ -158,9 +158,10 @@ class FusedAdam:
         """First flat element of the SH segment (= number of geometry elements incl. padding)."""
         return layout(self.p.N, self.p.K)["sh"][0]
 
-    def step_sh_gathered(self, world: int, sh_deg: int, v_color_all: torch.Tensor, grad_scale: float):
+    def step_sh_gathered(self, world: int, sh_deg: int, v_color_all: torch.Tensor, grad_scale: float, guard=None):
         """Adam on the SH segment from the all-gathered colour-gradient blocks [world, 3N+4] of the
-        current step (call before the geometry segments are stepped: it reads the means)."""
+        current step (call before the geometry segments are stepped: it reads the means).
+        ``guard``: the status word written by ops.dp_agree_overflow (no-op if any rank overflowed)."""
         lib = _lib.load()
         if v_color_all.numel() != world * (3 * self.p.N + 4):
             raise ValueError("v_color_all must hold world blocks of 3N+4 floats")
@@ -168,7 +169,7 @@ class FusedAdam:
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(lib.tgs_adam_step_sh_gathered(world, self.p.N, self.p.K, sh_deg, ptr(self.p.flat), ptr(v_color_all),
                                             ptr(self.exp_avg), ptr(self.exp_avg_sq), C.byref(s),
-                                            C.c_float(grad_scale), stream), "tgs_adam_step_sh_gathered")
+                                            C.c_float(grad_scale), ptr(guard), stream), "tgs_adam_step_sh_gathered")
 
     def state_dict(self):
         return dict(t=self.t, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lrs=self.lrs)

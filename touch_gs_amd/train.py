@@ -143,8 +143,10 @@ def main(argv=None):
         os.makedirs(run_dir, exist_ok=True)
         with open(os.path.join(run_dir, "config.json"), "w") as f:
             json.dump(dict(vars(args), model=dataclasses.asdict(cfg), world_size=dp.world), f, indent=2)
-    if dp.world == 1 and not args.densify and not args.sync_budget:
-        model.enable_speculative_budget()     # no per-step host sync; overflow is detected late and replayed
+    if not args.densify and not args.sync_budget and (dp.world == 1 or model.optimizer.can_gather_sh()):
+        # no per-step host sync; an overflow is detected late and replayed (data parallel: the ranks
+        # agree on it on the device and replay the same steps)
+        model.enable_speculative_budget()
     train_views = [views[i] for i in i_train]
     eval_views = [views[i] for i in i_eval] or train_views[:1]
     t0 = time.time()
