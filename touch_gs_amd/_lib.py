@@ -5,7 +5,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtgs_hip.so")
+# TGS_LIB_PATH: developer override for same-box A/B runs of two builds (tools/ab.py); the default is
+# the in-tree build
+LIB_PATH = os.environ.get("TGS_LIB_PATH") or os.path.join(_HERE, "lib", "libtgs_hip.so")
 
 SPLAT_FLOATS = 12
 PARTIAL_FLOATS = 12

@@ -69,8 +69,8 @@ struct LossK {
 // centre, in pixel-centre coordinates (pixel (i,j) of the tile sits at u = i - 7.5, v = j - 7.5).
 struct TileRec {
   float4 a;  // c0 c1 c2 c3
-  float4 b;  // c4 c5 L depth       L = -log2(opacity):  sigma >= 0  <=>  s >= L
-  float4 c;  // r g b mask(bits)
+  float4 b;  // c4 c5 depth r        (the ten floats the blend loops read are contiguous:
+  float4 c;  // g b - mask(bits)      ds_read_b128 x2 + ds_read_b64 off one base address)
 };
 
 __device__ __forceinline__ TileRec make_tile_rec(float4 r0, float4 r1, float4 r2, float tcx, float tcy) {
@@ -85,8 +85,8 @@ __device__ __forceinline__ TileRec make_tile_rec(float4 r0, float4 r1, float4 r2
   t.a.w = 0.5f * LOG2E * A;
   t.b.x = LOG2E * B;
   t.b.y = 0.5f * LOG2E * Cc;
-  t.b.z = L;
-  t.b.w = r0.z;
+  t.b.z = r0.z;
+  t.b.w = r1.w;
   // quadrant mask: does {alpha >= 1/255} = {s <= log2 255} reach any pixel centre of the 8x8
   // quadrant?  Exact test: minimise the convex quadratic s over the quadrant's rectangle of pixel
   // centres (interior point if the centre projects inside, else the best point on the 4 edges).
@@ -121,7 +121,7 @@ __device__ __forceinline__ TileRec make_tile_rec(float4 r0, float4 r1, float4 r2
       mask |= (best <= slack) ? (1u << k) : 0u;
     }
   }
-  t.c = make_float4(r1.w, r2.x, r2.y, __uint_as_float(mask));
+  t.c = make_float4(r2.x, r2.y, 0.f, __uint_as_float(mask));
   return t;
 }
 
@@ -235,8 +235,8 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
           float Tn; bool go;
           const float al = blend_step(s, T[k], smax[k], Tn, go);
           const float w = al * T[k];
-          Cr[k] = fmaf(w, qc.x, Cr[k]); Cg[k] = fmaf(w, qc.y, Cg[k]);
-          Cb[k] = fmaf(w, qc.z, Cb[k]); D[k] = fmaf(w, qb.w, D[k]);
+          Cr[k] = fmaf(w, qb.w, Cr[k]); Cg[k] = fmaf(w, qc.x, Cg[k]);
+          Cb[k] = fmaf(w, qc.y, Cb[k]); D[k] = fmaf(w, qb.z, D[k]);
           T[k] = go ? Tn : T[k];
           if (WANT_IDX) last[k] = go ? pos : last[k];
         }
@@ -408,8 +408,8 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
           const float w = al * T[k];
           acc[0] = fmaf(w, vCr[k], acc[0]); acc[1] = fmaf(w, vCg[k], acc[1]);
           acc[2] = fmaf(w, vCb[k], acc[2]); acc[3] = fmaf(w, vD[k], acc[3]);
-          float cv = qc.x * vCr[k];
-          cv = fmaf(qc.y, vCg[k], cv); cv = fmaf(qc.z, vCb[k], cv); cv = fmaf(qb.w, vD[k], cv);
+          float cv = qb.w * vCr[k];
+          cv = fmaf(qc.x, vCg[k], cv); cv = fmaf(qc.y, vCb[k], cv); cv = fmaf(qb.z, vD[k], cv);
           // q = opacity e^-sigma dL/dalpha, dL/dalpha = T cv + (X + Pv)/(1 - alpha)   (B.7).  With
           // z = w cv:  q = z + alpha/(1-alpha) (X + Pv + z)  -- exact when alpha is not clamped;
           // under the 0.999 clamp (opacity > 0.999 and sigma ~ 0) q is rescaled by e^-s / 0.999.
