@@ -2,127 +2,136 @@
 // padding), the (1-SSIM) term of the Splatfacto-style loss (1-l)*L1 + l*(1-SSIM) that the
 // reference's `depth-gaussian-splatting` method trains with.  gfx950.
 //
-// Two separable-convolution kernels over 16x16 output tiles with a 5-pixel halo staged in LDS:
+// Two separable-convolution kernels, row streaming:
 //   k_ssim_fwd : 5 windowed moments -> SSIM map; writes the three adjoint maps
-//                A = dm/dmu1 (total), B = dm/dE[x^2], C = dm/dE[xy] and a per-block sum of the map
+//                A = dm/dmu1 (total), B = dm/dE[x^2], C = dm/dE[xy] and a per-workgroup sum of the map
 //   k_ssim_bwd : v_img = weight * (G*A + 2*img*(G*B) + gt*(G*C))
-// Roofline: HBM (each image is read ~1.3x incl. halo; 9 adjoint planes written then read).
+// A workgroup owns a strip of 64 columns x SEG rows, thread = (column, channel).  Input rows are
+// staged 11 at a time in LDS exactly as they lie in memory (interleaved channels: coalesced loads,
+// conflict-free ds_read with lane stride 1 / 3); every thread filters its row horizontally from LDS
+// (11 taps) and keeps the last 11 horizontally-filtered rows in REGISTERS, so the vertical pass
+// costs no LDS traffic and no barrier -- the first version staged 26x26 halo tiles per 16x16
+// outputs (2.6x read amplification, 48 KB of LDS per workgroup, 3 workgroups per CU, 39-44 % LDS
+// bank-conflict cycles; 77 + 80 us at 1080p).  Read amplification here: 74/64 horizontally,
+// (SEG+10)/SEG vertically.  Roofline: HBM (9 adjoint planes written, then read).
 #include <math.h>
 #include "tgs_common.h"
 
 namespace {
 
-constexpr int WIN = 11, HALO = 5, TS = 16, EXT = TS + 2 * HALO;  // 26
+constexpr int WIN = 11, HALO = 5;
 struct Win { float g[WIN]; };
 
-// Register-blocked separable convolution: every thread produces OPT consecutive outputs along the
-// filter direction from a sliding window of OPT+10 inputs held in registers.  One workgroup owns a
-// 16x16 tile for ALL THREE channels, so that the interleaved [H,W,3] images are read as contiguous
-// 78-float row segments (a per-channel block would use 4 of every 12 bytes it fetches), and the
-// adjoints are stored interleaved per pixel ([H,W,3 ch,3 maps]) so the second kernel reads
-// contiguous 234-float row segments.
-constexpr int OPT = 4;
-constexpr int CG = TS / OPT;  // column / row groups per tile edge
-constexpr int HS = 20;        // row stride of the horizontally-filtered maps: 4*HS = 16 (mod 32), so the
-                              // four row groups of a 32-lane LDS access group hit disjoint banks
+constexpr int SW = 64;              // strip width (output columns per workgroup)
+constexpr int NTH = 3 * SW;         // threads: (column, channel)
+constexpr int RB = WIN;             // input rows per staged block = window height (phase p = row in block)
+#ifndef TGS_SSIM_NBLK
+#define TGS_SSIM_NBLK 4
+#endif
+constexpr int NBLK = TGS_SSIM_NBLK; // blocks per segment
+constexpr int SEG = RB * NBLK - 2 * HALO;   // 34 output rows per workgroup
 
-__global__ __launch_bounds__(256) void k_ssim_fwd(int W, int H, Win win,
+// Stages input rows [r0, r0 + RB) x columns [x0 - 5, x0 + SW + 5) of an interleaved [H, W, CH]
+// image into LDS (zero outside the image), in batches of 8 loads in flight per thread.
+template <int CH>
+struct RowBlock {
+  static constexpr int ROWF = (SW + 2 * HALO) * CH;             // floats per staged row
+  static constexpr int NIT = (RB * ROWF + NTH - 1) / NTH;
+  static __device__ __forceinline__ void stage(const float* __restrict__ src, float* __restrict__ lds,
+                                               int W, int H, int x0, int r0, int tid) {
+    constexpr int B = 8;
+#pragma unroll 1
+    for (int it0 = 0; it0 < NIT; it0 += B) {
+      float v[B];
+#pragma unroll
+      for (int u = 0; u < B; u++) {
+        const int i = tid + NTH * (it0 + u);
+        const int j = i / ROWF, e = i - j * ROWF;
+        const int gy = r0 + j, gxf = (x0 - HALO) * CH + e;
+        v[u] = 0.f;
+        if (i < RB * ROWF && gy >= 0 && gy < H && gxf >= 0 && gxf < W * CH) v[u] = src[(size_t)gy * W * CH + gxf];
+      }
+#pragma unroll
+      for (int u = 0; u < B; u++) {
+        const int i = tid + NTH * (it0 + u);
+        if (i < RB * ROWF) lds[i] = v[u];
+      }
+    }
+  }
+};
+
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_ssim_fwd(int W, int H, Win win,
                                                   const float* __restrict__ img,
                                                   const float* __restrict__ gt,
                                                   float* __restrict__ adj /*[H,W,3,3] or null*/,
-                                                  float* __restrict__ block_partials) {
-  __shared__ float sa[3][EXT][EXT + 1], sb[3][EXT][EXT + 1];
-  __shared__ float h[3][5][EXT][HS];
-  __shared__ float red[4];
-  const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+                                                  float* __restrict__ block_partials, int n_partials) {
+  constexpr int ROWF = RowBlock<3>::ROWF;
+  __shared__ float sa[RB * ROWF], sb[RB * ROWF];
+  __shared__ float red[NTH / TGS_WAVE];
   const int tid = threadIdx.x;
-  {
-    // all global loads of the halo tile are issued before the first LDS store (the loop is
-    // otherwise a chain of dependent load->store latencies)
-    constexpr int NIT = (EXT * EXT * 3 + 255) / 256;
-    float va[NIT], vb[NIT];
+  const int x0 = blockIdx.x * SW, ys = blockIdx.y * SEG;
+  const int gx = x0 + tid / 3, c = tid - (tid / 3) * 3;
+  const int ye = min(ys + SEG, H);
+  float w[RB][5];
 #pragma unroll
-    for (int it = 0; it < NIT; it++) {
-      const int i = tid + 256 * it;
-      const int ly = i / (EXT * 3), e = i - ly * (EXT * 3);
-      const int lx = e / 3, c = e - lx * 3;
-      const int gx = x0 + lx - HALO, gy = y0 + ly - HALO;
-      va[it] = 0.f; vb[it] = 0.f;
-      if (i < EXT * EXT * 3 && gx >= 0 && gx < W && gy >= 0 && gy < H) {
-        const size_t p = ((size_t)gy * W + gx) * 3 + c;
-        va[it] = img[p]; vb[it] = gt[p];
-      }
+  for (int p = 0; p < RB; p++)
+#pragma unroll
+    for (int q = 0; q < 5; q++) w[p][q] = 0.f;
+  float msum = 0.f;
+  for (int blk = 0; blk < NBLK; blk++) {
+    const int r0 = ys - HALO + blk * RB;          // first input row of this block
+    if (r0 - HALO >= ye) break;                   // no output row left (uniform)
+    __syncthreads();                              // previous block fully consumed
+    {
+      // no register prefetch of the next block: the window already holds 55 VGPRs per thread and
+      // the other resident workgroups of the CU cover the load latency
+      RowBlock<3>::stage(img, sa, W, H, x0, r0, tid);
+      RowBlock<3>::stage(gt, sb, W, H, x0, r0, tid);
     }
+    __syncthreads();
 #pragma unroll
-    for (int it = 0; it < NIT; it++) {
-      const int i = tid + 256 * it;
-      if (i < EXT * EXT * 3) {
-        const int ly = i / (EXT * 3), e = i - ly * (EXT * 3);
-        const int lx = e / 3, c = e - lx * 3;
-        sa[c][ly][lx] = va[it]; sb[c][ly][lx] = vb[it];
-      }
-    }
-  }
-  __syncthreads();
-  // horizontal pass; consecutive lanes take consecutive ROWS (row stride 27 is odd -> no conflicts)
-  for (int i = tid; i < 3 * EXT * CG; i += 256) {
-    const int c = i / (EXT * CG), r = i - c * (EXT * CG);
-    const int cg = r / EXT, ly = r - cg * EXT, lx0 = cg * OPT;
-    float a[OPT + WIN - 1], b[OPT + WIN - 1];
-#pragma unroll
-    for (int k = 0; k < OPT + WIN - 1; k++) { a[k] = sa[c][ly][lx0 + k]; b[k] = sb[c][ly][lx0 + k]; }
-#pragma unroll
-    for (int o = 0; o < OPT; o++) {
+    for (int p = 0; p < RB; p++) {
+      __builtin_amdgcn_sched_barrier(0);   // keep the 11 unrolled phases apart (register pressure)
+      // horizontal pass of input row r0 + p for (column, channel) = this thread
+      const float* ra = sa + p * ROWF + tid;
+      const float* rb = sb + p * ROWF + tid;
       float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
 #pragma unroll
       for (int k = 0; k < WIN; k++) {
-        const float g = win.g[k], ga = g * a[o + k], gb = g * b[o + k];
+        const float a = ra[3 * k], b = rb[3 * k];
+        const float ga = win.g[k] * a, gb = win.g[k] * b;
         m1 += ga; m2 += gb;
-        e11 = fmaf(ga, a[o + k], e11); e22 = fmaf(gb, b[o + k], e22); e12 = fmaf(ga, b[o + k], e12);
+        e11 = fmaf(ga, a, e11); e22 = fmaf(gb, b, e22); e12 = fmaf(ga, b, e12);
       }
-      h[c][0][ly][lx0 + o] = m1; h[c][1][ly][lx0 + o] = m2; h[c][2][ly][lx0 + o] = e11;
-      h[c][3][ly][lx0 + o] = e22; h[c][4][ly][lx0 + o] = e12;
-    }
-  }
-  __syncthreads();
-  float msum = 0.f;
-  if (tid < 3 * TS * CG) {
-    const int c = tid / (TS * CG), r = tid - c * (TS * CG);
-    const int lx = r & (TS - 1), ly0 = (r / TS) * OPT;
-    float out[5][OPT];
+      w[p][0] = m1; w[p][1] = m2; w[p][2] = e11; w[p][3] = e22; w[p][4] = e12;
+      // vertical pass: output row = r0 + p - 5; window slots (p+1 .. p+11) mod 11 = oldest .. newest
+      const int gy = r0 + p - HALO;
+      if (gy >= ys && gy < ye) {                  // uniform
+        float o[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < 5; q++) {
-      float col[OPT + WIN - 1];
+        for (int k = 0; k < WIN; k++) {
 #pragma unroll
-      for (int k = 0; k < OPT + WIN - 1; k++) col[k] = h[c][q][ly0 + k][lx];
-#pragma unroll
-      for (int o = 0; o < OPT; o++) {
-        float acc = 0.f;
-#pragma unroll
-        for (int k = 0; k < WIN; k++) acc = fmaf(win.g[k], col[o + k], acc);
-        out[q][o] = acc;
-      }
-    }
-    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-#pragma unroll
-    for (int o = 0; o < OPT; o++) {
-      const float mu1 = out[0][o], mu2 = out[1][o];
-      const float s11 = out[2][o] - mu1 * mu1, s22 = out[3][o] - mu2 * mu2, s12 = out[4][o] - mu1 * mu2;
-      const float n1 = 2.f * mu1 * mu2 + C1, n2 = 2.f * s12 + C2;
-      const float d1 = mu1 * mu1 + mu2 * mu2 + C1, d2 = s11 + s22 + C2;
-      const float id1 = 1.f / d1, id2 = 1.f / d2;
-      const float m = n1 * n2 * id1 * id2;
-      const int gx = x0 + lx, gy = y0 + ly0 + o;
-      if (gx < W && gy < H) {
-        msum += m;
-        if (adj) {
-          const float dm_ds12 = 2.f * n1 * id1 * id2;
-          const float dm_ds11 = -m * id2;
-          const float dm_dmu1 = 2.f * mu2 * n2 * id1 * id2 - m * 2.f * mu1 * id1;
-          float* o3 = adj + (((size_t)gy * W + gx) * 3 + c) * 3;
-          o3[0] = dm_dmu1 - 2.f * mu1 * dm_ds11 - mu2 * dm_ds12;
-          o3[1] = dm_ds11;
-          o3[2] = dm_ds12;
+          for (int q = 0; q < 5; q++) o[q] = fmaf(win.g[k], w[(p + 1 + k) % RB][q], o[q]);
+        }
+        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+        const float mu1 = o[0], mu2 = o[1];
+        const float s11 = o[2] - mu1 * mu1, s22 = o[3] - mu2 * mu2, s12 = o[4] - mu1 * mu2;
+        const float n1 = 2.f * mu1 * mu2 + C1, n2 = 2.f * s12 + C2;
+        const float d1 = mu1 * mu1 + mu2 * mu2 + C1, d2 = s11 + s22 + C2;
+        // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division: d1, d2 >= C1, C2 > 0
+        const float id1 = __builtin_amdgcn_rcpf(d1), id2 = __builtin_amdgcn_rcpf(d2);
+        const float m = n1 * n2 * id1 * id2;
+        if (gx < W) {
+          msum += m;
+          if (adj) {
+            const float dm_ds12 = 2.f * n1 * id1 * id2;
+            const float dm_ds11 = -m * id2;
+            const float dm_dmu1 = 2.f * mu2 * n2 * id1 * id2 - m * 2.f * mu1 * id1;
+            float* o3 = adj + (((size_t)gy * W + gx) * 3 + c) * 3;
+            o3[0] = dm_dmu1 - 2.f * mu1 * dm_ds11 - mu2 * dm_ds12;
+            o3[1] = dm_ds11;
+            o3[2] = dm_ds12;
+          }
         }
       }
     }
@@ -130,79 +139,60 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int W, int H, Win win,
   const float tot = wave_sum(msum);
   if ((tid & 63) == 0) red[tid >> 6] = tot;
   __syncthreads();
-  if (tid == 0) block_partials[blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  const int wg = blockIdx.y * gridDim.x + blockIdx.x, nwg = gridDim.x * gridDim.y;
+  if (tid == 0) block_partials[wg] = red[0] + red[1] + red[2];
+  // the caller's buffer has one entry per 16x16 tile: the entries beyond the workgroup count are zero
+  for (int i = nwg + wg * NTH + tid; i < n_partials; i += nwg * NTH) block_partials[i] = 0.f;
 }
 
-__global__ __launch_bounds__(256) void k_ssim_bwd(int W, int H, Win win, float weight,
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_ssim_bwd(int W, int H, Win win, float weight,
                                                   const float* __restrict__ img,
                                                   const float* __restrict__ gt,
                                                   const float* __restrict__ adj,
                                                   float* __restrict__ v_img) {
-  __shared__ float s[9][EXT][EXT + 1];   // [c*3 + map]
-  __shared__ float h[9][EXT][HS];
-  const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+  constexpr int ROWF = RowBlock<9>::ROWF;
+  __shared__ float sadj[RB * ROWF];
   const int tid = threadIdx.x;
-  {
-    constexpr int NIT = (EXT * EXT * 9 + 255) / 256;
-    float vv[NIT];
+  const int x0 = blockIdx.x * SW, ys = blockIdx.y * SEG;
+  const int gx = x0 + tid / 3;
+  const int ye = min(ys + SEG, H);
+  float w[RB][3];
 #pragma unroll
-    for (int it = 0; it < NIT; it++) {
-      const int i = tid + 256 * it;
-      const int ly = i / (EXT * 9), e = i - ly * (EXT * 9);
-      const int lx = e / 9, q = e - lx * 9;
-      const int gx = x0 + lx - HALO, gy = y0 + ly - HALO;
-      vv[it] = 0.f;
-      if (i < EXT * EXT * 9 && gx >= 0 && gx < W && gy >= 0 && gy < H) vv[it] = adj[((size_t)gy * W + gx) * 9 + q];
+  for (int p = 0; p < RB; p++) { w[p][0] = 0.f; w[p][1] = 0.f; w[p][2] = 0.f; }
+  for (int blk = 0; blk < NBLK; blk++) {
+    const int r0 = ys - HALO + blk * RB;
+    if (r0 - HALO >= ye) break;
+    __syncthreads();
+    {
+      RowBlock<9>::stage(adj, sadj, W, H, x0, r0, tid);
     }
+    __syncthreads();
 #pragma unroll
-    for (int it = 0; it < NIT; it++) {
-      const int i = tid + 256 * it;
-      if (i < EXT * EXT * 9) {
-        const int ly = i / (EXT * 9), e = i - ly * (EXT * 9);
-        const int lx = e / 9, q = e - lx * 9;
-        s[q][ly][lx] = vv[it];
+    for (int p = 0; p < RB; p++) {
+      __builtin_amdgcn_sched_barrier(0);
+      const float* r = sadj + p * ROWF + 3 * tid;     // (pixel, channel) -> its three adjoint maps
+      float h0 = 0.f, h1 = 0.f, h2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < WIN; k++) {
+        h0 = fmaf(win.g[k], r[9 * k], h0);
+        h1 = fmaf(win.g[k], r[9 * k + 1], h1);
+        h2 = fmaf(win.g[k], r[9 * k + 2], h2);
       }
-    }
-  }
-  __syncthreads();
-  for (int i = tid; i < 9 * EXT * CG; i += 256) {
-    const int q = i / (EXT * CG), r = i - q * (EXT * CG);
-    const int cg = r / EXT, ly = r - cg * EXT, lx0 = cg * OPT;
-    float a[OPT + WIN - 1];
+      w[p][0] = h0; w[p][1] = h1; w[p][2] = h2;
+      const int gy = r0 + p - HALO;
+      if (gy >= ys && gy < ye) {
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < OPT + WIN - 1; k++) a[k] = s[q][ly][lx0 + k];
-#pragma unroll
-    for (int o = 0; o < OPT; o++) {
-      float acc = 0.f;
-#pragma unroll
-      for (int k = 0; k < WIN; k++) acc = fmaf(win.g[k], a[o + k], acc);
-      h[q][ly][lx0 + o] = acc;
-    }
-  }
-  __syncthreads();
-  if (tid >= 3 * TS * CG) return;
-  const int c = tid / (TS * CG), r = tid - c * (TS * CG);
-  const int lx = r & (TS - 1), ly0 = (r / TS) * OPT;
-  float out[3][OPT];
-#pragma unroll
-  for (int q = 0; q < 3; q++) {
-    float col[OPT + WIN - 1];
-#pragma unroll
-    for (int k = 0; k < OPT + WIN - 1; k++) col[k] = h[c * 3 + q][ly0 + k][lx];
-#pragma unroll
-    for (int o = 0; o < OPT; o++) {
-      float acc = 0.f;
-#pragma unroll
-      for (int k = 0; k < WIN; k++) acc = fmaf(win.g[k], col[o + k], acc);
-      out[q][o] = acc;
-    }
-  }
-#pragma unroll
-  for (int o = 0; o < OPT; o++) {
-    const int gx = x0 + lx, gy = y0 + ly0 + o;
-    if (gx < W && gy < H) {
-      const size_t p = ((size_t)gy * W + gx) * 3 + c;
-      v_img[p] = weight * (out[0][o] + 2.f * img[p] * out[1][o] + gt[p] * out[2][o]);
+        for (int k = 0; k < WIN; k++) {
+          o0 = fmaf(win.g[k], w[(p + 1 + k) % RB][0], o0);
+          o1 = fmaf(win.g[k], w[(p + 1 + k) % RB][1], o1);
+          o2 = fmaf(win.g[k], w[(p + 1 + k) % RB][2], o2);
+        }
+        if (gx < W) {
+          const size_t pidx = (size_t)gy * W * 3 + (size_t)x0 * 3 + tid;
+          v_img[pidx] = weight * (o0 + 2.f * img[pidx] * o1 + gt[pidx] * o2);
+        }
+      }
     }
   }
 }
@@ -219,10 +209,13 @@ extern "C" int tgs_ssim_fwd_bwd(int W, int H, const float* img, const float* gt,
   double g[WIN], sum = 0.0;
   for (int i = 0; i < WIN; i++) { g[i] = exp(-(double)((i - HALO) * (i - HALO)) / (2.0 * 1.5 * 1.5)); sum += g[i]; }
   for (int i = 0; i < WIN; i++) win.g[i] = (float)(g[i] / sum);
-  const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, 1), block(256);
+  // block_partials has one entry per 16x16 tile (the buffer contract of include/tgs.h); the
+  // streaming kernels write one sum per workgroup (fewer) and zero the rest
+  const int n_partials = ((W + 15) / 16) * ((H + 15) / 16);
+  const dim3 grid((W + SW - 1) / SW, (H + SEG - 1) / SEG, 1), block(NTH);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_ssim_fwd, grid, block, 0, s, W, H, win, img, gt, v_img ? scratch : nullptr,
-                     block_partials);
+                     block_partials, n_partials);
   TGS_CHECK_LAUNCH();
   if (v_img) {
     hipLaunchKernelGGL(k_ssim_bwd, grid, block, 0, s, W, H, win, weight, img, gt, scratch, v_img);
