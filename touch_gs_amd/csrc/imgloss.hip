@@ -91,7 +91,6 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < RB; p++) {
-      __builtin_amdgcn_sched_barrier(0);   // keep the 11 unrolled phases apart (register pressure)
       // horizontal pass of input row r0 + p for (column, channel) = this thread
       const float* ra = sa + p * ROWF + tid;
       const float* rb = sb + p * ROWF + tid;
@@ -169,7 +168,6 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < RB; p++) {
-      __builtin_amdgcn_sched_barrier(0);
       const float* r = sadj + p * ROWF + 3 * tid;     // (pixel, channel) -> its three adjoint maps
       float h0 = 0.f, h1 = 0.f, h2 = 0.f;
 #pragma unroll
