@@ -293,16 +293,9 @@ __device__ __forceinline__ void cross_wave_stage(u64 (&k)[E], int tid, int d, bo
 // barriers; for W > 1 only the stages whose partner lives in another wave (log2 W (log2 W + 1) / 2
 // of them) go through LDS.
 template <int E, int W>
-__device__ __forceinline__ void sort_tile_regs(const u64* __restrict__ pairs, int32_t* __restrict__ sorted_gid,
-                                               int s, int n, int tid, u64* __restrict__ lds) {
+__device__ __forceinline__ void sort_regs(u64 (&k)[E], int tid, u64* __restrict__ lds) {
   constexpr int NT = TGS_WAVE * W;
   const int lane = tid & (TGS_WAVE - 1);
-  u64 k[E];
-#pragma unroll
-  for (int r = 0; r < E; r++) {        // coalesced load; the initial order is irrelevant
-    const int i = r * NT + tid;
-    k[r] = i < n ? pairs[s + i] : ~0ull;
-  }
   local_levels<E, 2>(k, lane);
   constexpr int LV = W == 1 ? 6 : (W == 4 ? 8 : 10);   // log2(64 W)
 #pragma unroll 1
@@ -318,6 +311,19 @@ __device__ __forceinline__ void sort_tile_regs(const u64* __restrict__ pairs, in
     cross_stage<E, 1>(k, lane, up);
     local_tail<E, E / 2, -1>(k, up);
   }
+}
+
+template <int E, int W>
+__device__ __forceinline__ void sort_tile_regs(const u64* __restrict__ pairs, int32_t* __restrict__ sorted_gid,
+                                               int s, int n, int tid, u64* __restrict__ lds) {
+  constexpr int NT = TGS_WAVE * W;
+  u64 k[E];
+#pragma unroll
+  for (int r = 0; r < E; r++) {        // coalesced load; the initial order is irrelevant
+    const int i = r * NT + tid;
+    k[r] = i < n ? pairs[s + i] : ~0ull;
+  }
+  sort_regs<E, W>(k, tid, lds);
   // sorted order: e = tid * E + r
 #pragma unroll
   for (int r = 0; r < E; r++) {
@@ -326,11 +332,37 @@ __device__ __forceinline__ void sort_tile_regs(const u64* __restrict__ pairs, in
   }
 }
 
+// Visiting order of the compositing kernels for XCD band x (<= 1024 tiles): tiles by descending list
+// length, ties by tile id -- the same register sort on (~length, tile) keys.
+__device__ __forceinline__ void band_order_regs(int T, int x, const int32_t* __restrict__ tile_start,
+                                                int32_t* __restrict__ tile_order, int lane) {
+  const int per = (T + 7) >> 3;
+  const int t0 = x * per, len = max(0, min(per, T - t0));
+  u64 k[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int i = r * TGS_WAVE + lane;
+    k[r] = i < len ? ((u64)(~(unsigned)(tile_start[t0 + i + 1] - tile_start[t0 + i])) << 32) | (unsigned)(t0 + i) : ~0ull;
+  }
+  sort_regs<16, 1>(k, lane, nullptr);
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int i = lane * 16 + r;
+    if (i < per) tile_order[i * 8 + x] = i < len ? (int)(k[r] & 0xffffffffull) : T;   // T = no tile
+  }
+}
+
 // common classes: lists <= 512 (8 keys per lane) and <= 1024 (16 keys per lane); one wave per tile
 __global__ __launch_bounds__(TGS_WAVE) void k_sort_tiles_wave(
     int T, const int32_t* __restrict__ tile_start, const u64* __restrict__ pairs,
-    int32_t* __restrict__ sorted_gid) {
-  const int tile = blockIdx.x;
+    int32_t* __restrict__ sorted_gid, int32_t* __restrict__ tile_order, int n_order) {
+  // the first n_order (0 or 8) blocks build the K6 / K7 schedule of one XCD band (<= 1024 tiles) each;
+  // they are the longest blocks of the launch, so they are dispatched first
+  if ((int)blockIdx.x < n_order) {
+    band_order_regs(T, blockIdx.x, tile_start, tile_order, threadIdx.x);
+    return;
+  }
+  const int tile = blockIdx.x - n_order;
   const int s = tile_start[tile];
   const int n = tile_start[tile + 1] - s;
   const int lane = threadIdx.x;
@@ -343,42 +375,48 @@ __global__ __launch_bounds__(TGS_WAVE) void k_sort_tiles_wave(
   else sort_tile_regs<16, 1>(pairs, sorted_gid, s, n, lane, nullptr);
 }
 
-// long lists (object-centric scenes): (1024, 4096] with 4 waves, (4096, 16384] with 16 waves, 16 keys
-// per lane, grid-stride over the tiles.  `max_list` (written by k_scan_tiles) lets the launch return
-// at once when the frame has no list of its class.
-template <int W, int LO>
-__global__ __launch_bounds__(TGS_WAVE * W) void k_sort_tiles_wg(
+// Rare list classes (`max_list`, written by k_scan_tiles, lets both launches return at once when the
+// frame has no list of their class; grid-stride over the tiles):
+//   k_sort_tiles_wg4   (1024, 4096]   4 waves x 16 keys per lane, 32 KB of LDS: several workgroups
+//                      per CU overlap each other's barriers (object-centric scenes live here);
+//   k_sort_tiles_huge  (4096, 16384]  16 waves x 16 keys per lane (128 KB of LDS), and beyond that a
+//                      bitonic network in global memory on a power-of-two padded copy at
+//                      fb[2*s ...) (next_pow2(n) < 2n, so per-tile regions never overlap).
+// (One merged 1024-thread launch was 26 us slower on the clustered scene: one workgroup per CU.)
+__global__ __launch_bounds__(TGS_WAVE * 4) void k_sort_tiles_wg4(
     int T, const int32_t* __restrict__ tile_start, const u64* __restrict__ pairs,
     int32_t* __restrict__ sorted_gid, const int32_t* __restrict__ max_list) {
-  __shared__ u64 wg_keys[TGS_WAVE * W * 16];   // 16 keys x 64 W threads (32 KB / 128 KB)
-  if (*max_list <= LO) return;
+  __shared__ u64 wg_keys[TGS_WAVE * 4 * 16];   // 16 keys x 256 threads
+  if (*max_list <= 1024) return;
   for (int tile = blockIdx.x; tile < T; tile += gridDim.x) {
     const int s = tile_start[tile];
     const int n = tile_start[tile + 1] - s;
-    if (n <= LO || n > TGS_WAVE * W * 16) continue;
-    sort_tile_regs<16, W>(pairs, sorted_gid, s, n, threadIdx.x, wg_keys);
+    if (n <= 1024 || n > 4096) continue;
+    __syncthreads();
+    sort_tile_regs<16, 4>(pairs, sorted_gid, s, n, threadIdx.x, wg_keys);
   }
 }
 
-// Lists beyond the register-resident classes (> LO = 16384): the bitonic network of a 1024-thread
-// workgroup in global memory, on a power-of-two padded copy at fb[2*s ...) (next_pow2(n) < 2n, so
-// per-tile regions never overlap).  (CAP: lists up to CAP would run in LDS; unused, CAP = 1.)
-template <int CAP, int LO>
-__global__ __launch_bounds__(1024) void k_sort_tiles_long(
-    int T, const int32_t* __restrict__ tile_start, const unsigned long long* __restrict__ pairs,
-    unsigned long long* __restrict__ fb, int32_t* __restrict__ sorted_gid, const int32_t* __restrict__ max_list) {
-  __shared__ unsigned long long lds_keys[CAP];
+__global__ __launch_bounds__(1024) void k_sort_tiles_huge(
+    int T, const int32_t* __restrict__ tile_start, const u64* __restrict__ pairs, u64* __restrict__ fb,
+    int32_t* __restrict__ sorted_gid, const int32_t* __restrict__ max_list) {
+  __shared__ u64 wg_keys[TGS_WAVE * 16 * 16];   // 128 KB: 16 keys x 1024 threads
+  if (*max_list <= 4096) return;
   const int tid = threadIdx.x;
-  if (*max_list <= LO) return;
   for (int tile = blockIdx.x; tile < T; tile += gridDim.x) {
     const int s = tile_start[tile];
     const int n = tile_start[tile + 1] - s;
-    if (n <= LO) continue;
+    if (n <= 4096) continue;
+    if (n <= 16384) {
+      __syncthreads();
+      sort_tile_regs<16, 16>(pairs, sorted_gid, s, n, tid, wg_keys);
+      continue;
+    }
     const int np2 = next_pow2(n);
-    const bool in_lds = n <= CAP;
-    unsigned long long* keys = in_lds ? lds_keys : fb + 2 * (size_t)s;
-    __syncthreads();  // lds_keys reuse across iterations
+    u64* keys = fb + 2 * (size_t)s;
+    __syncthreads();
     for (int i = tid; i < np2; i += 1024) keys[i] = (i < n) ? pairs[s + i] : ~0ull;
+    __threadfence_block();
     __syncthreads();
     for (int k = 2; k <= np2; k <<= 1) {
       for (int j = k >> 1; j > 0; j >>= 1) {
@@ -386,10 +424,10 @@ __global__ __launch_bounds__(1024) void k_sort_tiles_long(
           const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
           const int hi = lo | j;
           const bool up = (lo & k) == 0;
-          const unsigned long long a = keys[lo], b = keys[hi];
+          const u64 a = keys[lo], b = keys[hi];
           if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
         }
-        if (!in_lds) __threadfence_block();
+        __threadfence_block();
         __syncthreads();
       }
     }
@@ -397,11 +435,8 @@ __global__ __launch_bounds__(1024) void k_sort_tiles_long(
   }
 }
 
-constexpr int SORT_CAP_WAVE = 1024;  // one wave, 8 / 16 keys per lane
-constexpr int SORT_CAP_WG4 = 4096;   // 4 waves x 16 keys per lane
-constexpr int SORT_CAP_WG16 = 16384; // 16 waves x 16 keys per lane; longer lists sort in global memory
-
 }  // namespace
+
 
 extern "C" int tgs_num_groups(int N) { return (N + TGS_GROUP - 1) / TGS_GROUP; }
 extern "C" int tgs_num_tiles(int W, int H) {
@@ -423,24 +458,25 @@ int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* gro
   const int G = tgs_num_groups(N);
   const BinScratch sc = carve_scratch(scratch, capacity);
   const int NB = (T + 1023) / 1024;   // <= 64 (image sides are limited to 255 tiles)
-  hipLaunchKernelGGL(k_scan_tiles, dim3(NB + (tile_order ? 8 : 0)), dim3(1024), 0, s, T, NB, tile_cursor,
-                     tile_start, status, tile_order);
+  // K6 / K7 schedule: bands of <= 1024 tiles are ordered by 8 extra blocks of the wave-sort launch
+  // (register sort); larger images (and N = 0, which launches no sort) by 8 workgroups of the scan
+  const bool order_in_sort = tile_order && G > 0 && ((T + 7) >> 3) <= 1024;
+  hipLaunchKernelGGL(k_scan_tiles, dim3(NB + ((tile_order && !order_in_sort) ? 8 : 0)), dim3(1024), 0, s, T, NB,
+                     tile_cursor, tile_start, status, tile_order);
   TGS_CHECK_LAUNCH();
   if (G > 0) {
     hipLaunchKernelGGL(k_fill_bins, dim3(G), dim3(TGS_GROUP), 0, s, k, N, splats, group_base,
                        tile_cursor + TGS_XCC * T, sc.rank, (uint2*)sc.pairs, status);
     TGS_CHECK_LAUNCH();
-    const int small_grid = T < 256 ? T : 256;
-    const int big_grid = T < 2048 ? T : 2048;
     const int32_t* max_list = tile_cursor + 2 * TGS_XCC * T + TGS_SCAN_WGS;
-    hipLaunchKernelGGL(k_sort_tiles_wave, dim3(T), dim3(TGS_WAVE), 0, s, T, tile_start, sc.pairs, sorted_gid);
+    hipLaunchKernelGGL(k_sort_tiles_wave, dim3(T + (order_in_sort ? 8 : 0)), dim3(TGS_WAVE), 0, s, T, tile_start,
+                       sc.pairs, sorted_gid, tile_order, order_in_sort ? 8 : 0);
     TGS_CHECK_LAUNCH();
-    hipLaunchKernelGGL((k_sort_tiles_wg<4, SORT_CAP_WAVE>), dim3(big_grid), dim3(TGS_WAVE * 4), 0, s, T, tile_start, sc.pairs, sorted_gid, max_list);
+    hipLaunchKernelGGL(k_sort_tiles_wg4, dim3(T < 2048 ? T : 2048), dim3(TGS_WAVE * 4), 0, s, T, tile_start,
+                       sc.pairs, sorted_gid, max_list);
     TGS_CHECK_LAUNCH();
-    hipLaunchKernelGGL((k_sort_tiles_wg<16, SORT_CAP_WG4>), dim3(small_grid), dim3(TGS_WAVE * 16), 0, s, T, tile_start, sc.pairs, sorted_gid, max_list);
-    TGS_CHECK_LAUNCH();
-    hipLaunchKernelGGL((k_sort_tiles_long<1, SORT_CAP_WG16>), dim3(small_grid), dim3(1024), 0,
-                       s, T, tile_start, sc.pairs, sc.fb, sorted_gid, max_list);
+    hipLaunchKernelGGL(k_sort_tiles_huge, dim3(T < 256 ? T : 256), dim3(1024), 0, s, T, tile_start, sc.pairs,
+                       sc.fb, sorted_gid, max_list);
     TGS_CHECK_LAUNCH();
   }
   return TGS_OK;
