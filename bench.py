@@ -254,8 +254,9 @@ def main():
         acc = {k: [] for k in names}
         reps = min(args.steps, 20)
         p = params
-        for _ in range(reps):
-            e = [ev() for _ in range(7)]
+        all_ev = []
+        for _ in range(reps):     # enqueued back to back; ONE synchronisation after the last repetition, so
+            e = [ev() for _ in range(7)]   # that no kernel starts on an idle GPU behind a host round trip
             e[0].record()
             sp, _, gb, ts, sg, _ = ops.project_bin_sort(view.cam, p.means, p.log_scales, p.quats, p.opac_logit,
                                                         p.sh, deg, model.budget)
@@ -274,7 +275,9 @@ def main():
             e[6].record()
             model.optimizer.step()
             e7b = ev(); e7b.record()
-            torch.cuda.synchronize()
+            all_ev.append((e, e7b))
+        torch.cuda.synchronize()
+        for e, e7b in all_ev:
             for j, k in enumerate(names[:5]):
                 acc[k].append(e[j].elapsed_time(e[j + 1]))
             acc["adam"].append(e[6].elapsed_time(e7b))
