@@ -289,15 +289,16 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
   // The list is walked FRONT TO BACK exactly like the forward (same blend_step, hence the same
   // transmittance sequence and the same threshold decisions); the colour accumulated BEHIND a
   // Gaussian, which B.7 needs, is (final colour - prefix), both projected on the pixel's upstream
-  // gradient:  S.v = Cv_total - Pv.   Per-pixel state: T, Pv, smax.
-  float T[4] = {1.f, 1.f, 1.f, 1.f}, Pv[4] = {0.f, 0.f, 0.f, 0.f};
-  float smax[4], vCr[4], vCg[4], vCb[4], vD[4], X[4];  // X = T_final*(v_A - bg.v_C) - Cv_total
+  // gradient:  S.v = Cv_total - Pv.   Per-pixel state: T, XP = X + Pv, smax, with
+  // X = T_final*(v_A - bg.v_C) - Cv_total  (the running sum starts at X: one add less per slot).
+  float T[4] = {1.f, 1.f, 1.f, 1.f};
+  float smax[4], vCr[4], vCg[4], vCb[4], vD[4], XP[4];
   float l_l1 = 0.f, l_dep = 0.f;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int px = tx * TGS_BLOCK + 8 * (k & 1) + (lane & 7);
     const int py = ty * TGS_BLOCK + 8 * (k >> 1) + (lane >> 3);
-    smax[k] = -3.0e38f; vCr[k] = vCg[k] = vCb[k] = vD[k] = X[k] = 0.f;
+    smax[k] = -3.0e38f; vCr[k] = vCg[k] = vCb[k] = vD[k] = XP[k] = 0.f;
     if (px < cam.W && py < cam.H) {
       smax[k] = LOG2_255;
       const size_t p = (size_t)py * cam.W + px;
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
       // colour part of the output without the background term, projected on v
       const float cvtot = vCr[k] * (o0 - Tf * cam.bg[0]) + vCg[k] * (o1 - Tf * cam.bg[1]) +
                           vCb[k] * (o2 - Tf * cam.bg[2]) + vD[k] * od;
-      X[k] = Tf * (vA - bgdot) - cvtot;
+      XP[k] = Tf * (vA - bgdot) - cvtot;
     }
   }
   if (tile_loss) {
@@ -404,8 +405,9 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
           const float s = eval_s(qa, qb, pc, k);
           float Tn; bool go;
           const float al = blend_step(s, T[k], smax[k], Tn, go);   // 0 unless this Gaussian contributes
-          const float ra = __builtin_amdgcn_rcpf(1.f - al);
           const float w = al * T[k];
+          // alpha / (1 - alpha) = alpha T / T'  (T' = T (1 - alpha) is already there; w = 0 if skipped)
+          const float kap = w * __builtin_amdgcn_rcpf(Tn);
           acc[0] = fmaf(w, vCr[k], acc[0]); acc[1] = fmaf(w, vCg[k], acc[1]);
           acc[2] = fmaf(w, vCb[k], acc[2]); acc[3] = fmaf(w, vD[k], acc[3]);
           float cv = qb.w * vCr[k];
@@ -414,8 +416,8 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
           // z = w cv:  q = z + alpha/(1-alpha) (X + Pv + z)  -- exact when alpha is not clamped;
           // under the 0.999 clamp (opacity > 0.999 and sigma ~ 0) q is rescaled by e^-s / 0.999.
           const float z = w * cv;
-          Pv[k] += z;
-          float q = fmaf(al * ra, X[k] + Pv[k], z);    // = 0 automatically when al == 0
+          XP[k] += z;
+          float q = fmaf(kap, XP[k], z);               // = 0 automatically when al == 0
           q *= fmaxf(__builtin_amdgcn_exp2f(-s) * (1.0f / ALPHA_MAX), 1.0f);
           T[k] = fmaf(-al, T[k], T[k]);                // unchanged when al == 0
           acc[4] += q;
