@@ -29,6 +29,7 @@
 //    sum in K8 (deterministic, and it avoids cross-XCD memory-side atomics).
 //  * blockIdx -> tile mapping gives each XCD a contiguous band of tiles so the gathered splat
 //    records of neighbouring tiles stay in that XCD's 4 MB L2.
+#include <type_traits>
 #include "tgs_common.h"
 
 namespace {
@@ -159,8 +160,12 @@ __device__ __forceinline__ float eval_s(const float4& a, const float4& b, const 
 //          alpha >= 1/255 test).  The sigma < 0 skip of App. B.6 cannot trigger: K1 only emits
 //          positive-definite conics, for which sigma >= 0 up to rounding.
 //   returns the contributing alpha (0 if skipped or if this Gaussian stops the pixel).
+//   MAYCLAMP = false: the caller knows that no Gaussian of the batch has opacity > 0.999, so
+//          exp2(-s) = o e^-sigma <= 0.999 and min(0.999, .) is the identity -- bit-identical, one VALU less.
+template <bool MAYCLAMP = true>
 __device__ __forceinline__ float blend_step(float s, float& T, float& smax, float& Tnew, bool& go) {
-  const float al = fminf(ALPHA_MAX, __builtin_amdgcn_exp2f(-s));
+  const float e = __builtin_amdgcn_exp2f(-s);
+  const float al = MAYCLAMP ? fminf(ALPHA_MAX, e) : e;
   const bool ok = s <= smax;
   Tnew = fmaf(-al, T, T);
   go = ok & (Tnew > T_STOP);
@@ -387,6 +392,8 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
 #pragma unroll
     for (int k = 0; k < 4; k++)
       qm[k] = ((slot_live >> k) & 1u) ? __ballot((my_mask >> k) & 1u) : 0ull;
+    auto walk = [&](auto mayclamp) {
+    constexpr bool MAYCLAMP = decltype(mayclamp)::value;
     unsigned long long rem = qm[0] | qm[1] | qm[2] | qm[3];
     while (rem) {
       const int j = __builtin_ctzll(rem);
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
         if (m & (1u << k)) {  // wave-uniform
           const float s = eval_s(qa, qb, pc, k);
           float Tn; bool go;
-          const float al = blend_step(s, T[k], smax[k], Tn, go);   // 0 unless this Gaussian contributes
+          const float al = blend_step<MAYCLAMP>(s, T[k], smax[k], Tn, go);   // 0 unless this Gaussian contributes
           const float w = al * T[k];
           // alpha / (1 - alpha) = alpha T / T'  (T' = T (1 - alpha) is already there; w = 0 if skipped)
           const float kap = w * __builtin_amdgcn_rcpf(Tn);
@@ -418,7 +425,7 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
           const float z = w * cv;
           XP[k] += z;
           float q = fmaf(kap, XP[k], z);               // = 0 automatically when al == 0
-          q *= fmaxf(__builtin_amdgcn_exp2f(-s) * (1.0f / ALPHA_MAX), 1.0f);
+          if constexpr (MAYCLAMP) q *= fmaxf(__builtin_amdgcn_exp2f(-s) * (1.0f / ALPHA_MAX), 1.0f);
           T[k] = fmaf(-al, T[k], T[k]);                // unchanged when al == 0
           acc[4] += q;
           acc[5] = fmaf(q, pc.u[k & 1], acc[5]); acc[6] = fmaf(q, pc.v[k >> 1], acc[6]);
@@ -445,6 +452,12 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
         __builtin_amdgcn_wave_barrier();
       }
     }
+    };
+    // The 0.999 clamp can only bind for opacity > 0.999: batches without such a Gaussian (all of a
+    // typical scene) run a copy of the loop without the clamp (min) and its pass-through correction
+    // (3 VALU) -- a per-BATCH choice, so the Gaussian loop itself has no extra branch.
+    if (__ballot(lane < cnt && a0.w > ALPHA_MAX) != 0ull) walk(std::true_type{});
+    else walk(std::false_type{});
     __syncthreads();
     if (lane < cnt) {
       const float4 s0 = sums[lane * 4], s1 = sums[lane * 4 + 1], s2 = sums[lane * 4 + 2];
