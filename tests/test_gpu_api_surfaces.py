@@ -667,3 +667,34 @@ def test_nerfstudio_adapter_core_trains(dev):
     assert losses[-1] < 0.9 * losses[0], losses
     m = ag.metrics_dict(ag.render(view.cam), batch)
     assert "psnr" in m and "depth_mse" in m
+
+
+def test_spatial_sort_is_a_pure_relayout(dev):
+    """model.spatial_sort(): Morton order of parameters + Adam moments.  The render is unchanged and a
+    few train steps give the same model up to the permutation (only the order of exactly equal depths
+    inside a tile list can differ: ties break by Gaussian id)."""
+    from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
+    from touch_gs_amd.optim import GaussianParams
+    from touch_gs_amd.scene import make_view, synthetic_gaussians
+    N, W, H, deg = 20000, 320, 200, 3
+    views = [make_view(N, W, H, deg, 7, dev, view=v, n_views=4) for v in range(2)]
+    P, _ = synthetic_gaussians(N, W, H, deg, 99)
+    def fresh():
+        params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
+        return DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=0), params)
+    a, b = fresh(), fresh()
+    for step in range(2):            # some Adam state before the sort
+        a.train_step(views[step % 2]); b.train_step(views[step % 2])
+    perm = b.spatial_sort()
+    assert torch.equal(b.params.means, a.params.means[perm]) and torch.equal(b.optimizer.exp_avg_sq[:3 * N].view(N, 3),
+                                                                             a.optimizer.exp_avg_sq[:3 * N].view(N, 3)[perm])
+    # neighbours in memory are neighbours in space
+    d_sorted = (b.params.means[1:] - b.params.means[:-1]).norm(dim=1).median()
+    d_before = (a.params.means[1:] - a.params.means[:-1]).norm(dim=1).median()
+    assert d_sorted < 0.2 * d_before
+    ra, rb = a.get_outputs(views[0].cam), b.get_outputs(views[0].cam)
+    assert torch.allclose(ra["rgb"], rb["rgb"], atol=2e-6) and torch.allclose(ra["depth_acc"], rb["depth_acc"], atol=2e-5)
+    for step in range(2, 5):
+        a.train_step(views[step % 2]); b.train_step(views[step % 2])
+    d = (b.params.flat[:3 * N].view(N, 3) - a.params.flat[:3 * N].view(N, 3)[perm]).abs()
+    assert float(torch.quantile(d.flatten().float(), 0.999)) < 1e-5

@@ -53,10 +53,18 @@ def test_project_fwd(dev, N, W, H, deg, seed):
     assert relerr(f["rgb"], pr["rgb"], floor=1e-3).max() < TOL  # colour defined for every Gaussian
 
 
-@pytest.mark.parametrize("N,W,H,seed", [(3000, 160, 96, 5), (800, 50, 35, 6), (20000, 320, 200, 7)])
-def test_bin_sort_exact(dev, N, W, H, seed):
+@pytest.mark.parametrize("N,W,H,seed,morton", [(3000, 160, 96, 5, False), (800, 50, 35, 6, False),
+                                                 (20000, 320, 200, 7, False), (20000, 320, 200, 8, True),
+                                                 (100000, 800, 800, 9, True)])
+def test_bin_sort_exact(dev, N, W, H, seed, morton):
+    """morton=True: Gaussians in 3-D Morton order, so that a binning group's tile bounding box is
+    small and K3a takes the LDS-aggregated counting path (one global atomic per (group, tile))."""
     from touch_gs_amd import ops
+    from touch_gs_amd.optim import morton_order
     P, cam = scene(N, W, H, 0, seed)
+    if morton:
+        perm = morton_order(P["means"])
+        P = {k: v[perm].contiguous() for k, v in P.items()}
     _, sp, _ = _project(dev, P, cam, 0)
     gb, ts, sg, st = ops.bin_sort(amd_cam(cam), sp)
     f = splat_fields(sp)

@@ -26,6 +26,10 @@ dev = torch.device("cuda:0")
 P, _ = synthetic_gaussians(N, W, H, deg, seed, clustered=cl)
 p = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
 model = DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=0), p)
+import os
+if os.environ.get("TGS_AB_MORTON"):
+    model.spatial_sort()
+    p = model.params
 view = make_view(N, W, H, deg, seed, dev, clustered=cl)
 view.valid_count()
 b = ops.IntersectBudget()

@@ -33,6 +33,15 @@ int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* gro
 #define TGS_SCAN_WGS 64
 static inline int tgs_counter_len(int T) { return 2 * TGS_XCC * T + TGS_SCAN_WGS + 4; }
 
+// Aggregated counting (spatially ordered parameter buffers): when the tile bounding box of a group's
+// 256 Gaussians holds at most TGS_AGG_TILES tiles, its pairs are first counted per tile in an LDS
+// histogram (integer LDS atomics: 5.6 cycles per wave instruction, tools/ubench/lds_atomic.hip) and
+// the group then issues ONE returning global atomic per touched tile instead of one per pair.  With
+// Morton-ordered Gaussians a group touches ~50 tiles with ~20 pairs each; a group of a randomly
+// ordered buffer spans the whole image and takes the direct path.
+#define TGS_AGG_TILES 1024
+#define TGS_AGG_U 4            // pairs per thread kept in registers by the aggregated path (256 * 4 per group)
+
 #ifdef __HIPCC__
 __device__ __forceinline__ int xcc_id() {
   // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4); any value in [0, 8) gives correct results, the true
@@ -46,6 +55,8 @@ struct GroupScan {
   unsigned depth_bits[TGS_GROUP];
   int wave_tot[TGS_GROUP / TGS_WAVE];
   int base;
+  int wave_bbox[TGS_GROUP / TGS_WAVE][4];   // per wave: min x0, min y0, max x1, max y1 of its rects (tiles)
+  int hist[TGS_AGG_TILES];     // aggregated counting: pairs per tile of the bounding box, then their base rank
 };
 
 // Builds the in-group exclusive scan from each thread's (rect, depth).  Returns the group total.
@@ -60,6 +71,15 @@ __device__ __forceinline__ int group_scan_store(GroupScan& S, int hits, int x0, 
     if ((tid & (TGS_WAVE - 1)) >= o) incl += t;
   }
   if ((tid & (TGS_WAVE - 1)) == TGS_WAVE - 1) S.wave_tot[tid / TGS_WAVE] = incl;
+  {   // tile bounding box of the wave's rects (DPP reductions; same-address LDS atomics would serialise)
+    const bool any = hits > 0;
+    const int bx0 = wave_minmax_i<false>(any ? x0 : (1 << 30)), by0 = wave_minmax_i<false>(any ? y0 : (1 << 30));
+    const int bx1 = wave_minmax_i<true>(any ? x0 + w : 0), by1 = wave_minmax_i<true>(any ? y0 + hits / max(w, 1) : 0);
+    if ((tid & (TGS_WAVE - 1)) == 0) {
+      int* b = S.wave_bbox[tid / TGS_WAVE];
+      b[0] = bx0; b[1] = by0; b[2] = bx1; b[3] = by1;
+    }
+  }
   __syncthreads();
   int wbase = 0, total = 0;
 #pragma unroll
@@ -73,6 +93,22 @@ __device__ __forceinline__ int group_scan_store(GroupScan& S, int hits, int x0, 
   S.depth_bits[tid] = dbits;
   if (tid == 0) S.off[TGS_GROUP] = total;
   return total;
+}
+
+// pair i of the group -> (local Gaussian j, tile x, tile y)
+__device__ __forceinline__ void group_pair_xy(const GroupScan& S, int i, int& j, int& tx, int& ty) {
+  int lo = 0, hi = TGS_GROUP;
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    const int mid = (lo + hi) >> 1;
+    if (S.off[mid] <= i) lo = mid; else hi = mid;
+  }
+  j = lo;
+  const int k = i - S.off[lo];
+  const int w = S.w[lo];
+  const int ky = k / w;
+  tx = S.x0[lo] + (k - ky * w);
+  ty = S.y0[lo] + ky;
 }
 
 // Clears the per-tile counters and the status word.  A kernel rather than hipMemsetAsync: the call
@@ -131,7 +167,47 @@ __device__ __forceinline__ void group_count_tiles(GroupScan& S, int TW, int T, i
   const bool fits = base + total <= capacity;
   const int x = xcc_id();
   int32_t* __restrict__ my_count = tile_count + (size_t)x * T;
-  for (int i = tid; i < total; i += TGS_GROUP) {
+  int bx0 = 1 << 30, by0 = 1 << 30, bx1 = 0, by1 = 0;   // tile bounding box of the group's rects
+#pragma unroll
+  for (int wv = 0; wv < TGS_GROUP / TGS_WAVE; wv++) {
+    bx0 = min(bx0, S.wave_bbox[wv][0]); by0 = min(by0, S.wave_bbox[wv][1]);
+    bx1 = max(bx1, S.wave_bbox[wv][2]); by1 = max(by1, S.wave_bbox[wv][3]);
+  }
+  const int bw = bx1 - bx0, bh = by1 - by0;
+  const int area = bw * bh;
+  int first_direct = 0;
+  if (total > 0 && area <= TGS_AGG_TILES) {   // workgroup-uniform
+    for (int b = tid; b < area; b += TGS_GROUP) S.hist[b] = 0;
+    __syncthreads();
+    int lr[TGS_AGG_U], lb[TGS_AGG_U];
+#pragma unroll
+    for (int u = 0; u < TGS_AGG_U; u++) {
+      const int i = tid + u * TGS_GROUP;
+      lb[u] = -1; lr[u] = 0;
+      if (i < total) {
+        int j, tx, ty;
+        group_pair_xy(S, i, j, tx, ty);
+        lb[u] = (ty - by0) * bw + (tx - bx0);
+        lr[u] = atomicAdd(&S.hist[lb[u]], 1);                 // LDS: rank among the group's pairs of this tile
+      }
+    }
+    __syncthreads();
+    for (int b = tid; b < area; b += TGS_GROUP) {             // one global atomic per touched tile
+      const int c = S.hist[b];
+      if (c > 0) {
+        const int by = b / bw;
+        S.hist[b] = atomicAdd(&my_count[(by0 + by) * TW + bx0 + (b - by * bw)], c);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < TGS_AGG_U; u++) {
+      const int i = tid + u * TGS_GROUP;
+      if (lb[u] >= 0 && fits) rank[base + i] = (int32_t)((unsigned)(S.hist[lb[u]] + lr[u]) | ((unsigned)x << 29));
+    }
+    first_direct = TGS_AGG_U * TGS_GROUP;                     // pairs beyond 1024 per group (huge footprints)
+  }
+  for (int i = tid + first_direct; i < total; i += TGS_GROUP) {
     int j, tile;
     group_pair(S, TW, i, j, tile);
     const int r = atomicAdd(&my_count[tile], 1);

@@ -123,6 +123,24 @@ __device__ __forceinline__ float wave_sum(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// wave64 integer min / max through DPP (lanes a DPP step does not reach combine with their own value,
+// which is neutral); the result is wave-uniform.
+template <int CTRL, int ROW_MASK, bool MAX>
+__device__ __forceinline__ int dpp_minmax(int v) {
+  const int s = __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
+  return MAX ? max(v, s) : min(v, s);
+}
+template <bool MAX>
+__device__ __forceinline__ int wave_minmax_i(int v) {
+  v = dpp_minmax<0xB1, 0xf, MAX>(v);   // quad_perm [1,0,3,2]
+  v = dpp_minmax<0x4E, 0xf, MAX>(v);   // quad_perm [2,3,0,1]
+  v = dpp_minmax<0x141, 0xf, MAX>(v);  // row_half_mirror
+  v = dpp_minmax<0x140, 0xf, MAX>(v);  // row_mirror      -> every lane holds its row's result
+  v = dpp_minmax<0x142, 0xa, MAX>(v);  // row_bcast:15 into rows 1,3
+  v = dpp_minmax<0x143, 0xc, MAX>(v);  // row_bcast:31 into rows 2,3 -> lane 63 = result
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 __device__ __forceinline__ int wave_max_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));

@@ -53,6 +53,9 @@ class ModelConfig:
     lr_opac: float = 5e-2
     lr_sh_dc: float = 2.5e-3
     lr_sh_rest: float = 1.25e-4
+    # keep the Gaussians in 3-D Morton order (model.spatial_sort() after every densification); the
+    # trainer and bench.py switch it on, library users keep their own row order by default
+    spatial_sort: bool = False
 
     def lr_means_at(self, step: int) -> float:
         """ExponentialDecay schedule: lr_init * (lr_final / lr_init) ** min(step / max_steps, 1)."""
@@ -247,6 +250,25 @@ class DepthGaussianSplattingModel:
             main = main + c.ssim_lambda * (1 - ssim_sum.sum() / (3 * H * W))
         return {"main_loss": main, "depth_loss": t[1]}
 
+    def spatial_sort(self) -> torch.Tensor:
+        """Put the Gaussians (parameters, gradients, Adam moments, densification statistics) in 3-D
+        Morton order.  Purely a memory-layout choice -- the scene and every result are the same up to
+        the permutation -- that makes a binning group of 256 consecutive Gaussians project onto a few
+        dozen tiles: K1 then counts per (group, tile) in LDS and issues one global atomic per touched
+        tile instead of one per pair, and `k_fill_bins` writes runs instead of single 8-byte pairs.
+        Call at start-up and after densification (the trainer and bench.py do).  Returns the
+        permutation (new row i = old row perm[i])."""
+        from .optim import morton_order
+        perm = morton_order(self.params.means)
+        self.params.permute_(perm, self.optimizer.exp_avg, self.optimizer.exp_avg_sq)
+        density = getattr(self, "density", None)
+        if density is not None:
+            density.grad_norm_sum = density.grad_norm_sum[perm]
+            density.vis_count = density.vis_count[perm]
+            density.max_radius = density.max_radius[perm]
+        self._graphs = {}
+        return perm
+
     def enable_densification(self, cfg=None):
         """Turn on Splatfacto-style clone / split / cull refinement (touch_gs_amd.densify)."""
         from .densify import DensifyConfig, DensityController
@@ -417,6 +439,8 @@ class DepthGaussianSplattingModel:
         if density is not None and density.due(self.step):
             self.params, self.optimizer, self.last_refine = density.refine(self.params, self.optimizer, self.step, dp)
             self.budget = ops.IntersectBudget()  # the intersection count changes with N
+            if self.config.spatial_sort:
+                self.spatial_sort()              # the appended clones / splits go back to their neighbours
 
     # -- checkpoint -----------------------------------------------------------------------------
     def state_dict(self):

@@ -68,9 +68,37 @@ class GaussianParams:
     def tensors(self):
         return tuple(getattr(self, k) for k in self.NAMES)
 
+    @torch.no_grad()
+    def permute_(self, perm: torch.Tensor, *others: torch.Tensor) -> None:
+        """Reorder the Gaussians in place: row i becomes old row perm[i], in the parameter and gradient
+        buffers and in every flat buffer of the same layout passed in ``others`` (Adam moments)."""
+        for flat in (self.flat, self.grad) + tuple(others):
+            v = GaussianParams.views_of(flat, self.N, self.K)
+            for k in self.NAMES:
+                v[k].copy_(v[k][perm])
+
+
     def grad_views(self):
         """Pre-allocated gradient outputs for ops.project_bwd(out=...)."""
         return tuple(self.g[k] for k in self.NAMES)
+
+
+def morton_order(means: torch.Tensor, bits: int = 10) -> torch.Tensor:
+    """Permutation that sorts points along a 3-D Morton (Z-order) curve over their bounding box:
+    consecutive Gaussians are spatial neighbours from every viewpoint."""
+    m = means.detach().double()
+    lo, hi = m.min(0).values, m.max(0).values
+    q = ((m - lo) / (hi - lo).clamp_min(1e-12) * (2 ** bits - 1)).long().clamp_(0, 2 ** bits - 1)
+
+    def spread(x):   # 10 bits -> every third bit
+        x = (x | (x << 16)) & 0x030000FF
+        x = (x | (x << 8)) & 0x0300F00F
+        x = (x | (x << 4)) & 0x030C30C3
+        x = (x | (x << 2)) & 0x09249249
+        return x
+
+    code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    return torch.argsort(code, stable=True)
 
 
 class FusedAdam:

@@ -107,6 +107,8 @@ def main(argv=None):
     ap.add_argument("--output-dir", type=str, default="outputs")
     ap.add_argument("--load-checkpoint", type=str, default=None)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-spatial-sort", action="store_true",
+                    help="keep the Gaussians in their initial row order instead of 3-D Morton order")
     ap.add_argument("--densify", action="store_true", help="Splatfacto-style clone/split/cull refinement")
     ap.add_argument("--refine-every", type=int, default=100)
     ap.add_argument("--warmup-length", type=int, default=500)
@@ -131,8 +133,11 @@ def main(argv=None):
         params = init_params(args.num_gaussians, K, dev, scene.seed_points(), seed=args.seed)
         scene_name = os.path.basename(os.path.normpath(args.data))
     cfg = ModelConfig(sh_degree=args.sh_degree, depth_loss_mult=args.depth_loss_mult,
-                      depth_loss_type=args.depth_loss_type, uncertainty_weight=args.uncertainty_weight)
+                      depth_loss_type=args.depth_loss_type, uncertainty_weight=args.uncertainty_weight,
+                      spatial_sort=not args.no_spatial_sort)
     model = DepthGaussianSplattingModel(cfg, params)
+    if cfg.spatial_sort:
+        model.spatial_sort()
     if args.densify:
         from .densify import DensifyConfig
         model.enable_densification(DensifyConfig(refine_every=args.refine_every, warmup_length=args.warmup_length))
