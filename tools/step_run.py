@@ -11,6 +11,7 @@ P, _ = synthetic_gaussians(N, W, H, deg, 1236)
 params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
 model = DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=0), params)
 model.fuse_adam = (len(sys.argv) < 3 or sys.argv[2] != 'separate')
+model.spatial_sort()   # the framework's default layout (trainer, bench.py)
 view = make_view(N, W, H, deg, 1236, dev, view=0, n_views=8)
 view.valid_count()
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
