@@ -297,3 +297,29 @@ def test_densify_screen_size_rules_cpu():
     dc = DensityController(cfg, N, "cpu"); stats(dc)
     _, _, info = dc.refine(gp, opt, 150)
     assert info["culled"] == 2 and info["cloned"] == 3 and info["split"] == 0      # culled: 7, 6; clones: 0, 1, 2
+
+
+def test_morton_order_and_permute_cpu():
+    """optim.morton_order sorts along a 3-D Z-order curve (neighbours in memory are neighbours in space)
+    and GaussianParams.permute_ moves every segment of every flat buffer consistently."""
+    from touch_gs_amd.optim import FusedAdam, GaussianParams, morton_order
+    g = torch.Generator().manual_seed(0)
+    N, K = 4096, 4
+    gp = GaussianParams.allocate(N, K, "cpu")
+    gp.flat.copy_(torch.randn(gp.flat.shape, generator=g))
+    opt = FusedAdam(gp, dict(means=1e-4, log_scales=1e-3, quats=1e-3, opac_logit=1e-2, sh_dc=1e-3, sh_rest=1e-4))
+    opt.exp_avg.copy_(torch.randn(gp.flat.shape, generator=g))
+    before = {k: getattr(gp, k).clone() for k in GaussianParams.NAMES}
+    m_before = GaussianParams.views_of(opt.exp_avg.clone(), N, K)
+    perm = morton_order(gp.means)
+    assert sorted(perm.tolist()) == list(range(N))
+    gp.permute_(perm, opt.exp_avg)
+    for k in GaussianParams.NAMES:
+        assert torch.equal(getattr(gp, k), before[k][perm])
+        assert torch.equal(GaussianParams.views_of(opt.exp_avg, N, K)[k], m_before[k][perm])
+    d_sorted = (gp.means[1:] - gp.means[:-1]).norm(dim=1).median()
+    d_before = (before["means"][1:] - before["means"][:-1]).norm(dim=1).median()
+    assert d_sorted < 0.35 * d_before
+    # identical points, degenerate extents: still a permutation
+    same = torch.zeros(7, 3)
+    assert sorted(morton_order(same).tolist()) == list(range(7))
