@@ -55,13 +55,15 @@ def test_project_fwd(dev, N, W, H, deg, seed):
 
 @pytest.mark.parametrize("N,W,H,seed,morton", [(3000, 160, 96, 5, False), (800, 50, 35, 6, False),
                                                  (20000, 320, 200, 7, False), (20000, 320, 200, 8, True),
-                                                 (100000, 800, 800, 9, True)])
+                                                 (100000, 800, 800, 9, True), (6000, 320, 200, 10, "big")])
 def test_bin_sort_exact(dev, N, W, H, seed, morton):
     """morton=True: Gaussians in 3-D Morton order, so that a binning group's tile bounding box is
     small and K3a takes the LDS-aggregated counting path (one global atomic per (group, tile))."""
     from touch_gs_amd import ops
     from touch_gs_amd.optim import morton_order
     P, cam = scene(N, W, H, 0, seed)
+    if morton == "big":   # > 1024 pairs per group inside a small bounding box: aggregated + direct counting mixed
+        P["log_scales"] += 1.2
     if morton:
         perm = morton_order(P["means"])
         P = {k: v[perm].contiguous() for k, v in P.items()}
