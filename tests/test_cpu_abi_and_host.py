@@ -323,3 +323,23 @@ def test_morton_order_and_permute_cpu():
     # identical points, degenerate extents: still a permutation
     same = torch.zeros(7, 3)
     assert sorted(morton_order(same).tolist()) == list(range(7))
+
+
+def test_bench_byte_models_match_survey():
+    """bench.survey_bytes is SURVEY 8(d)'s compulsory-traffic model split per kernel: its forward and
+    backward sums must reproduce B_fwd = 312 N + 88 I + 24 P + 16 T and B_bwd = 84 I + 28 P + 512 N
+    (SH degree 3), e.g. 785 MB / 974 MB at the survey's cfg3 estimate."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    N, I, P, T, K = 1_000_000, 4_810_000, 1920 * 1080, 8160, 16
+    sb = bench.survey_bytes(N, I, P, T, K)
+    fwd = sb["project_bin_sort"] + sb["raster_fwd"]
+    bwd = sb["raster_bwd"] + sb["project_bwd"]
+    assert fwd == 312 * N + 88 * I + 24 * P + 16 * T and abs(fwd / 1e6 - 785) < 1
+    assert bwd == 84 * I + 28 * P + 512 * N and abs(bwd / 1e6 - 974) < 1
+    assert sb["adam"] == 1652 * N
+    assert set(bench.CONFIGS) >= {"cfg2", "cfg3", "cfg5", "clustered"} and bench.CONFIGS["cfg3"]["seed"] == 1236
+    ab = bench.algorithmic_bytes(N, I, P, T, K)
+    assert set(ab) == set(sb)
