@@ -633,6 +633,27 @@ def test_bench_two_gpus_rccl(dev, tmp_path):
     assert line["dp_exchange"]["all_gather_busbw_GBs"] > 0 and line["dp_exchange"]["replicas_identical"] is True
 
 
+def test_bench_two_ranks_share_one_gpu(dev):
+    """bench.py's N > 1 code path (rank rendezvous, per-rank views, barrier + max-over-ranks timing,
+    exchange report, replica check) on a ONE-GPU box: two ranks share cuda:0 and exchange over gloo
+    (TGS_DIST_BACKEND; RCCL refuses duplicate devices).  The driver launches the RCCL form of exactly
+    this command on the 8-GPU node."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TGS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29657", os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "4", "--warmup", "2", "--config", "cfg2", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines          # rank 0 prints ONE JSON line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["dp_exchange"]["replicas_identical"] is True
+    assert line["config"]["parallelism"] == "dp2"
+
+
 def test_nerfstudio_adapter_core_trains(dev):
     """The nerfstudio adapter's core (everything DepthGSNerfstudioModel delegates to): six Splatfacto
     parameter groups as nn.Parameters, differentiable render, loss from a nerfstudio-shaped batch
