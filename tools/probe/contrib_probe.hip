@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void k_probe(int W, int H, int TW, float pix_c
   __shared__ int anyflag[2][4];
   __shared__ unsigned long long tot[8];
   if (threadIdx.x < 8) tot[threadIdx.x] = 0;
-  unsigned long long c_pair_any = 0, c_after = 0;
+  unsigned long long c_pair_any = 0, c_after = 0, c_pair_reach = 0;
   for (int i = s; i < e; i++) {
     const float* r = splats + (size_t)sorted_gid[i] * 12;
     const float dx = r[0] - fx, dy = r[1] - fy;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void k_probe(int W, int H, int TW, float pix_c
           if (b_go & m) c_blk++;
         }
       for (int yy = 0; yy < 8; yy++) if (b_go & (0xFFull << (yy * 8))) c_row++;
-      anyflag[i & 1][k] = (b_go != 0ull) | ((b_alive != 0ull) << 1);
+      anyflag[i & 1][k] = (b_go != 0ull) | ((b_alive != 0ull) << 1) | ((b_reach != 0ull) << 2);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void k_probe(int W, int H, int TW, float pix_c
       for (int q = 0; q < 4; q++) a |= anyflag[i & 1][q];
       if (a & 1) c_pair_any++;
       if (!(a & 2)) c_after++;
+      if (a & 4) c_pair_reach++;   // alpha >= 1/255 at some pixel centre of the tile (alive or not)
     }
   }
   if (l == 0) {
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256) void k_probe(int W, int H, int TW, float pix_c
   if (threadIdx.x == 0) {
     atomicAdd(&ctr[0], (unsigned long long)(e - s));
     for (int j = 1; j < 8; j++) if (j != 5 && j != 6) atomicAdd(&ctr[j], tot[j]);
-    atomicAdd(&ctr[5], c_pair_any); atomicAdd(&ctr[6], c_after);
+    atomicAdd(&ctr[5], c_pair_any); atomicAdd(&ctr[6], c_after); atomicAdd(&ctr[10], c_pair_reach);
   }
 }
 

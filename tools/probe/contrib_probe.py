@@ -40,7 +40,8 @@ def main():
     out = dict(config=name, pairs=c[0], quad_pairs_reaching_live=c[1], pixel_pairs_contributing=c[2],
                pixel_pairs_reach_but_dead_in_live_quad=c[3], blocks4x4_with_contribution=c[4],
                pairs_with_any_contribution=c[5], pairs_after_tile_death=c[6], rows8_with_contribution=c[7],
-               quad_pairs_with_contribution=c[8], pixel_pairs_reaching=c[9])
+               quad_pairs_with_contribution=c[8], pixel_pairs_reaching=c[9],
+               pairs_reaching_some_pixel=c[10])
     out["lane_utilisation_quadrant_slots"] = c[2] / max(64 * c[1], 1)
     out["lane_utilisation_if_4x4_blocks"] = c[2] / max(16 * c[4], 1)
     out["lane_utilisation_if_8px_rows"] = c[2] / max(8 * c[7], 1)

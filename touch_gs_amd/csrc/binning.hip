@@ -19,10 +19,10 @@
 namespace {
 
 // Loads the group's rects from the splat records and builds the in-group scan.
-__device__ __forceinline__ int group_load_scan(const CamK& cam, int N,
+__device__ __forceinline__ int group_load_scan(const CamK& cam, int N, int group,
                                                const float* __restrict__ splats, GroupScan& S,
                                                int& my_off) {
-  const int g = blockIdx.x * TGS_GROUP + threadIdx.x;
+  const int g = group * TGS_GROUP + threadIdx.x;
   int hits = 0, x0 = 0, y0 = 0, w = 0;
   unsigned dbits = 0;
   if (g < N) {
@@ -43,8 +43,8 @@ __global__ __launch_bounds__(TGS_GROUP) void k_tile_count(
     long long capacity, int32_t* __restrict__ sticky) {
   __shared__ GroupScan S;
   int my_off;
-  const int total = group_load_scan(cam, N, splats, S, my_off);
-  const int g = blockIdx.x * TGS_GROUP + threadIdx.x;
+  const int total = group_load_scan(cam, N, tgs_group_id(), splats, S, my_off);
+  const int g = tgs_group_id() * TGS_GROUP + threadIdx.x;
   if (g < N) splats[(size_t)g * TGS_SPLAT_FLOATS + 11] = __int_as_float(my_off);
   group_count_tiles(S, cam.TW, cam.TW * cam.TH, total, group_base, tile_count, rank, status, capacity, sticky);
 }
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(TGS_GROUP) void k_fill_bins(
   const int T = cam.TW * cam.TH;
   __shared__ GroupScan S;
   int my_off;
-  const int total = group_load_scan(cam, N, splats, S, my_off);
+  const int total = group_load_scan(cam, N, blockIdx.x, splats, S, my_off);
   __syncthreads();
   const long long base = group_base[blockIdx.x];
   const int g0 = blockIdx.x * TGS_GROUP;

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void k_project_fwd(
     float* __restrict__ splats, int32_t* __restrict__ radii, int32_t* __restrict__ group_base,
     int32_t* __restrict__ tile_count, int32_t* __restrict__ rank, int32_t* __restrict__ status,
     long long capacity, int32_t* __restrict__ sticky) {
-  const int g = blockIdx.x * 256 + threadIdx.x;
+  const int g = tgs_group_id() * 256 + threadIdx.x;
   if constexpr (!FUSED) { if (g >= N) return; }
   unsigned rect = 0u;
   float tz = 0.f, c1 = 0.f, c2 = 0.f;

@@ -43,6 +43,9 @@ static inline int tgs_counter_len(int T) { return 2 * TGS_XCC * T + TGS_SCAN_WGS
 #define TGS_AGG_U 4            // pairs per thread kept in registers by the aggregated path (256 * 4 per group)
 
 #ifdef __HIPCC__
+// binning group of this workgroup in K1 / k_tile_count
+__device__ __forceinline__ int tgs_group_id() { return (int)blockIdx.x; }
+
 __device__ __forceinline__ int xcc_id() {
   // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4); any value in [0, 8) gives correct results, the true
   // XCC id gives the locality
@@ -156,7 +159,7 @@ __device__ __forceinline__ void group_count_tiles(GroupScan& S, int TW, int T, i
   if (tid == 0) {
     const int base = total ? atomicAdd(&status[0], total) : 0;
     S.base = base;
-    group_base[blockIdx.x] = base;
+    group_base[tgs_group_id()] = base;
     if ((long long)base + total > capacity) {
       status[1] = 1;
       if (sticky) *sticky = 1;
