@@ -166,6 +166,8 @@ def main():
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-color-prefetch", action="store_true",
+                    help="K1 always evaluates the SH rows itself (off: the previous step's optimizer kernel does)")
     ap.add_argument("--layout", choices=("morton", "asis"), default="morton",
                     help="memory order of the Gaussians: morton = model.spatial_sort() at start-up (the "
                          "framework's default layout), asis = the order the scene generator emits (random)")
@@ -216,7 +218,10 @@ def main():
     torch.cuda.empty_cache()
 
     def step(i):
-        model.train_step(views[dp.views_for_step(i, len(views))], dp if dp.active else None)
+        # single process: the view of the following step is known, so the optimizer kernel of this step
+        # also evaluates the colours the updated Gaussians show to it (colour prefetch; same results)
+        nxt = None if (dp.active or args.no_color_prefetch) else views[dp.views_for_step(i + 1, len(views))]
+        model.train_step(views[dp.views_for_step(i, len(views))], dp if dp.active else None, next_view=nxt)
 
     done = [0]
 

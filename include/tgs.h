@@ -148,6 +148,26 @@ int tgs_project_bin_sort(const TgsCamera* cam /*[host]*/, int N, const float* me
                          int32_t* sorted_gid, int32_t* tile_order, int64_t capacity, void* scratch,
                          int32_t* status, int32_t* sticky_overflow, void* stream);
 
+/* Colour prefetch (single-process training loop): the Gaussians' 3K SH coefficients are needed by K1
+ *     only for the colour they give from the camera.  tgs_project_bwd_adam_next (below) evaluates
+ *     that colour for the NEXT view inside the optimizer kernel, where the updated row is on chip,
+ *     and this variant of tgs_project_bin_sort takes it:
+ *       colors_in[N,3]  colours written by tgs_project_bwd_adam_next for THIS camera
+ *       color_tag       the device word that call was given; colors_in is used iff
+ *                       *color_tag == tag_expect (the optimizer kernel stores its tag_value last --
+ *                       a step skipped on an overflowed frame leaves the old tag), otherwise the
+ *                       colours are evaluated from `sh` exactly as tgs_project_bin_sort does.
+ *     Results are bit-identical to tgs_project_bin_sort either way; K1 reads 56 B instead of
+ *     44 + 12K B per Gaussian. */
+int tgs_project_bin_sort_colors(const TgsCamera* cam /*[host]*/, int N, const float* means,
+                                const float* log_scales, const float* quats, const float* opac_logit,
+                                const float* sh, int sh_stride, int sh_deg, float* splats,
+                                int32_t* radii, int32_t* group_base, int32_t* tile_start,
+                                int32_t* tile_cursor, int32_t* sorted_gid, int32_t* tile_order,
+                                int64_t capacity, void* scratch, int32_t* status,
+                                int32_t* sticky_overflow, const float* colors_in,
+                                const int32_t* color_tag, int32_t tag_expect, void* stream);
+
 /* K6  per-tile front-to-back compositing of RGB + depth in ONE pass  (stands behind gsplat
  *     `rasterize_gaussians` fwd, called twice by Splatfacto for rgb and depth; spec App. B.6).
  * out: out_rgb[H,W,3] (incl. background)  out_depth[H,W] (= sum w*depth, NOT divided by alpha)
@@ -209,6 +229,18 @@ int tgs_project_bwd_adam(const TgsCamera* cam /*[host]*/, int N, int sh_stride, 
                          const int32_t* group_base, const float* partials, float* v_xy,
                          const int32_t* skip_if_overflow /*status[2] of the frame, or NULL*/,
                          void* stream);
+
+/* tgs_project_bwd_adam + the colour prefetch for the next view (see tgs_project_bin_sort_colors):
+ *     after the update, colors_next[N,3] = max(sum_k Y_k(dir) c_k + 0.5, 0) of the UPDATED
+ *     coefficients and means, seen from next_cam, at the same active degree; then
+ *     *color_tag = tag_value.  On an overflowed frame (skip_if_overflow) neither is written. */
+int tgs_project_bwd_adam_next(const TgsCamera* cam /*[host]*/, int N, int sh_stride, int sh_deg,
+                              float* params, float* exp_avg, float* exp_avg_sq,
+                              const TgsAdamSpec* spec /*[host]*/, const float* splats,
+                              const int32_t* group_base, const float* partials, float* v_xy,
+                              const int32_t* skip_if_overflow /*status[2] of the frame, or NULL*/,
+                              const TgsCamera* next_cam /*[host]*/, float* colors_next,
+                              int32_t* color_tag, int32_t tag_value, void* stream);
 
 /* Data-parallel step (one view per rank, SURVEY section 8 row e).  The SH gradient of a rank is the
  *     outer product Y_k(dir(g)) x v_color[g,:], so the ranks exchange v_color (all-gather, 3 floats

@@ -587,9 +587,14 @@ dp.timing = True
 a.train_step(views[1], dp)
 rep = dp.comm_report()
 assert rep and rep["all_gather_ms"] > 0 and rep["all_reduce_ms"] > 0, rep
-da = (ref.params.flat - train(True, dp).params.flat).abs().max().item()
+ea = (ref.params.flat - train(True, dp).params.flat).abs()
+da = ea.max().item()
 db = (ref.params.flat - b.params.flat).abs().max().item()
-assert da < 1e-6 and db < 1e-6, (da, db)
+# dense exchange: the same kernels as the reference -> identical.  Factored exchange: the SH gradient is
+# rebuilt by another kernel (and the geometry gradients come from the colour-mode instantiation of K8), so
+# single gradients differ in the last bit -- which Adam's normalisation turns into a visible (but bounded
+# by the learning rate) difference on the few elements whose gradient is ~0
+assert db == 0.0 and da < 2e-5 and (ea > 1e-6).float().mean().item() < 1e-3, (da, db, (ea > 1e-6).float().mean().item())
 dp.assert_replicas_identical(a.params.flat)
 assert abs(dp.max_over_ranks(1.5) - 1.5) < 1e-12
 dp.barrier()
@@ -688,6 +693,66 @@ def test_nerfstudio_adapter_core_trains(dev):
     assert losses[-1] < 0.9 * losses[0], losses
     m = ag.metrics_dict(ag.render(view.cam), batch)
     assert "psnr" in m and "depth_mse" in m
+
+
+@pytest.mark.parametrize("deg,interval", [(3, 0), (1, 0), (3, 3)])
+def test_color_prefetch_is_bit_identical(dev, deg, interval):
+    """Colour prefetch (tgs_project_bwd_adam_next -> tgs_project_bin_sort_colors): the optimizer
+    kernel of step t evaluates the colours the UPDATED Gaussians show to the camera of step t+1 and
+    that step's K1 takes them instead of reading the SH rows.  Same parameters, Adam moments and
+    images, bit for bit, as the plain step sequence -- also when the announced next view is not the
+    one that comes (host-side mismatch), when the active SH degree changes in between (interval 3:
+    degrees 0,0,0,1,1,1,...), and when the optimizer kernel was skipped on an overflowed frame (the
+    tag word keeps its old value and K1 falls back to the SH rows on the device)."""
+    from touch_gs_amd import ops
+    from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
+    from touch_gs_amd.optim import GaussianParams
+    from touch_gs_amd.scene import make_view, synthetic_gaussians
+    N, W, H = 4100, 160, 96
+    views = [make_view(N, W, H, 3, 7, dev, view=v, n_views=4) for v in range(4)]
+    P, _ = synthetic_gaussians(N, W, H, 3, 99)
+
+    def fresh():
+        params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
+        return DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=interval), params)
+
+    order = [0, 1, 2, 3, 1, 1, 0, 2]
+    plain, pre = fresh(), fresh()
+    used = 0
+    for i, v in enumerate(order):
+        plain.train_step(views[v])
+        # announce the true next view, except at i == 3 where a wrong one is announced
+        nxt = views[order[i + 1]] if i + 1 < len(order) else None
+        if i == 3:
+            nxt = views[3]
+        ready = getattr(pre, "_prefetch_ready", None)
+        used += int(ready is not None and ready.matches(views[v].cam, N, pre.active_sh_degree()))
+        pre.train_step(views[v], next_view=nxt)
+        assert torch.equal(pre.last["rgb"], plain.last["rgb"]), i
+        assert torch.equal(pre.last["splats"], plain.last["splats"]), i
+    assert used >= (4 if interval == 0 else 2), used      # the prefetched colours really were taken
+    for x, y in ((pre.params.flat, plain.params.flat), (pre.optimizer.exp_avg, plain.optimizer.exp_avg),
+                 (pre.optimizer.exp_avg_sq, plain.optimizer.exp_avg_sq)):
+        assert torch.equal(x, y)
+
+    # device-side fallback: the frame of the announcing step overflows (capacity 16 pairs), its guarded
+    # optimizer kernel does nothing, so the announced colours were never written
+    m = fresh()
+    m.train_step(views[0], next_view=views[1])
+    good = m.budget
+    m.budget = ops.IntersectBudget(capacity=16, sync=False)
+    flat = m.params.flat.clone()
+    m.train_step(views[1], next_view=views[2])           # overflows: no update, no prefetch
+    assert int(m.last["status"][1]) == 1 and torch.equal(m.params.flat, flat)
+    m.optimizer.t -= 1; m.step -= 1                      # the step did not happen
+    m.budget = good
+    ready = m._prefetch_ready
+    assert ready is not None and ready.matches(views[2].cam, N, m.active_sh_degree())   # the host would use it
+    assert int(ready.tag_word) != ready.tag                                              # the device says no
+    ref = fresh()
+    ref.train_step(views[0]); ref.train_step(views[2])
+    m.train_step(views[2])
+    assert torch.equal(m.last["rgb"], ref.last["rgb"]) and torch.equal(m.params.flat, ref.params.flat)
 
 
 def test_spatial_sort_is_a_pure_relayout(dev):

@@ -14,6 +14,7 @@ model.fuse_adam = (len(sys.argv) < 3 or sys.argv[2] != 'separate')
 model.spatial_sort()   # the framework's default layout (trainer, bench.py)
 view = make_view(N, W, H, deg, 1236, dev, view=0, n_views=8)
 view.valid_count()
+prefetch = len(sys.argv) > 2 and sys.argv[2] == 'prefetch'   # colour prefetch for the (same) next view
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
-    model.train_step(view)
+    model.train_step(view, next_view=view if prefetch else None)
 torch.cuda.synchronize()

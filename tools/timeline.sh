@@ -4,14 +4,14 @@
 export TMPDIR=/tmp
 cd ${GRAFT_REPO_ROOT:-.}
 rm -rf /tmp/prof_tl
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_tl -- python tools/step_run.py ${1:-12} > /tmp/tl.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_tl -- python tools/step_run.py ${1:-12} $2 > /tmp/tl.log 2>&1
 mkdir -p gpurun_out
 python - <<'PY' | tee gpurun_out/timeline.txt
 import csv, glob
 f = glob.glob("/tmp/prof_tl/*/*kernel_trace.csv")[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-name = lambda r: r["Kernel_Name"].split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "")[:40]
+name = lambda r: r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:40]
 # steps end with the fused project_bwd kernel; print the last three complete steps
 ends = [i for i, r in enumerate(rows) if "k_project_bwd_lds" in r["Kernel_Name"]]
 for a, b in zip(ends[-4:-1], ends[-3:]):

@@ -23,20 +23,27 @@ constexpr float SH_C3_0 = -0.5900435899266435f, SH_C3_1 = 2.890611442640554f,
                 SH_C3_6 = -0.5900435899266435f;
 constexpr float BLUR = 0.3f;
 
+// The basis and the colour sum are evaluated by K1 AND by the colour prefetch of the fused optimizer
+// kernel, which must agree bit for bit.  Under -ffp-contract=fast the backend fuses any multiply that
+// feeds an add/subtract, and whether it does can depend on the surrounding code -- so every such
+// pair is written as an explicit fmaf here and no fusable pattern is left to the compiler.
 template <int DEG>
 __device__ __forceinline__ void sh_basis(float x, float y, float z, float* Y) {
   Y[0] = SH_C0;
   if constexpr (DEG >= 1) { Y[1] = -SH_C1 * y; Y[2] = SH_C1 * z; Y[3] = -SH_C1 * x; }
   if constexpr (DEG >= 2) {
     const float xx = x * x, yy = y * y, zz = z * z;
-    Y[4] = SH_C2_0 * x * y; Y[5] = SH_C2_1 * y * z; Y[6] = SH_C2_2 * (2.f * zz - xx - yy);
-    Y[7] = SH_C2_3 * x * z; Y[8] = SH_C2_4 * (xx - yy);
+    const float xx_yy = fmaf(x, x, -yy);                      // xx - yy
+    Y[4] = SH_C2_0 * x * y; Y[5] = SH_C2_1 * y * z;
+    Y[6] = SH_C2_2 * fmaf(-y, y, fmaf(2.f, zz, -xx));         // 2zz - xx - yy
+    Y[7] = SH_C2_3 * x * z; Y[8] = SH_C2_4 * xx_yy;
     if constexpr (DEG >= 3) {
-      Y[9] = SH_C3_0 * y * (3.f * xx - yy); Y[10] = SH_C3_1 * x * y * z;
-      Y[11] = SH_C3_2 * y * (4.f * zz - xx - yy);
-      Y[12] = SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy);
-      Y[13] = SH_C3_4 * x * (4.f * zz - xx - yy);
-      Y[14] = SH_C3_5 * z * (xx - yy); Y[15] = SH_C3_6 * x * (xx - 3.f * yy);
+      const float b = fmaf(-y, y, fmaf(4.f, zz, -xx));        // 4zz - xx - yy
+      Y[9] = SH_C3_0 * y * fmaf(3.f, xx, -yy); Y[10] = SH_C3_1 * x * y * z;
+      Y[11] = SH_C3_2 * y * b;
+      Y[12] = SH_C3_3 * z * fmaf(-3.f, yy, fmaf(-3.f, xx, 2.f * zz));
+      Y[13] = SH_C3_4 * x * b;
+      Y[14] = SH_C3_5 * z * xx_yy; Y[15] = SH_C3_6 * x * fmaf(-3.f, yy, xx);
     }
   }
 }
@@ -70,6 +77,36 @@ __device__ __forceinline__ void sh_basis_grad(float x, float y, float z, float (
     dY[15][0] = 3.f * SH_C3_6 * (xx - yy); dY[15][1] = -6.f * SH_C3_6 * x * y;
   }
 }
+
+// View-dependent colour of one Gaussian (B.5): rgb = max(sum_k Y_k(dir) c_k + 0.5, 0), dir from the
+// camera position to the mean.  `c` = the Gaussian's coefficient row (3 floats per basis) in global
+// memory, LDS or registers -- K1 and the colour prefetch of the fused optimizer kernel share this
+// function so that both produce the same bits.
+template <int DEG, typename Row>
+__device__ __forceinline__ void sh_color(const float* m, const float* campos, Row c, float* rgb) {
+  constexpr int K = (DEG + 1) * (DEG + 1);
+  float dx = m[0] - campos[0], dy = m[1] - campos[1], dz = m[2] - campos[2];
+  const float inv = 1.0f / sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+  float Y[16];
+  sh_basis<DEG>(dx * inv, dy * inv, dz * inv, Y);
+  rgb[0] = 0.f; rgb[1] = 0.f; rgb[2] = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    rgb[0] = fmaf(Y[k], c[3 * k], rgb[0]); rgb[1] = fmaf(Y[k], c[3 * k + 1], rgb[1]);
+    rgb[2] = fmaf(Y[k], c[3 * k + 2], rgb[2]);
+  }
+#pragma unroll
+  for (int ch = 0; ch < 3; ch++) rgb[ch] = fmaxf(rgb[ch] + 0.5f, 0.f);
+}
+
+// Colour prefetch request of the fused K8+Adam kernel: the NEXT view's camera position, the [N,3]
+// colour buffer and the tag word that marks it valid (colors == NULL: off).
+struct NextView {
+  float campos[3];
+  float* colors;
+  int32_t* tag;
+  int32_t tag_value;
+};
 
 struct Geom {  // everything the forward and backward share for one Gaussian
   float tx, ty, tz;
@@ -145,14 +182,15 @@ __device__ __forceinline__ void geom_eval(const CamK& cam, const float* m, const
 // FUSED: the workgroup (= one 256-Gaussian binning group) also builds the group scan, allocates the
 // group's pair range and counts its (tile, Gaussian) intersections (K3a), so the records are not
 // re-read and the pair offset is stored with the record instead of patched into it afterwards.
-template <int DEG, bool FUSED>  // DEG = -1: no SH (colours from colors_in or zero)
-__global__ __launch_bounds__(256) void k_project_fwd(
-    CamK cam, int N, const float* __restrict__ means, const float* __restrict__ log_scales,
+// PRE: the colours come from colors_in although DEG >= 0 (colour prefetch, k_project_fwd_colors)
+template <int DEG, bool FUSED, bool PRE>  // DEG = -1: no SH (colours from colors_in or zero)
+__device__ __forceinline__ void project_fwd_body(
+    const CamK& cam, int N, const float* __restrict__ means, const float* __restrict__ log_scales,
     const float* __restrict__ quats, const float* __restrict__ opac_logit,
     const float* __restrict__ sh, int sh_stride, const float* __restrict__ colors_in,
     float* __restrict__ splats, int32_t* __restrict__ radii, int32_t* __restrict__ group_base,
     int32_t* __restrict__ tile_count, int32_t* __restrict__ rank, int32_t* __restrict__ status,
-    long long capacity, int32_t* __restrict__ sticky) {
+    long long capacity, int32_t* __restrict__ sticky, GroupScan* Sp) {
   const int g = tgs_group_id() * 256 + threadIdx.x;
   if constexpr (!FUSED) { if (g >= N) return; }
   unsigned rect = 0u;
@@ -165,19 +203,8 @@ __global__ __launch_bounds__(256) void k_project_fwd(
   const float opac = 1.0f / (1.0f + expf(-opac_logit[g]));
 
   float rgb[3] = {0.f, 0.f, 0.f};
-  if constexpr (DEG >= 0) {
-    constexpr int K = (DEG + 1) * (DEG + 1);
-    float dx = m[0] - cam.campos[0], dy = m[1] - cam.campos[1], dz = m[2] - cam.campos[2];
-    const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-    float Y[16];
-    sh_basis<DEG>(dx * inv, dy * inv, dz * inv, Y);
-    const float* c = sh + (size_t)g * sh_stride * 3;
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-      rgb[0] += Y[k] * c[3 * k]; rgb[1] += Y[k] * c[3 * k + 1]; rgb[2] += Y[k] * c[3 * k + 2];
-    }
-#pragma unroll
-    for (int ch = 0; ch < 3; ch++) rgb[ch] = fmaxf(rgb[ch] + 0.5f, 0.f);
+  if constexpr (DEG >= 0 && !PRE) {
+    sh_color<DEG>(m, cam.campos, sh + (size_t)g * sh_stride * 3, rgb);
   } else if (colors_in) {
     rgb[0] = colors_in[3 * g]; rgb[1] = colors_in[3 * g + 1]; rgb[2] = colors_in[3 * g + 2];
   }
@@ -225,7 +252,7 @@ __global__ __launch_bounds__(256) void k_project_fwd(
   if (radii) radii[g] = radius;
   }  // g < N
   if constexpr (FUSED) {
-    __shared__ GroupScan S;
+    GroupScan& S = *Sp;
     int x0, y0, w, h, my_off;
     unpack_rect(rect, x0, y0, w, h);
     const int total = group_scan_store(S, w * h, x0, y0, w, __float_as_uint(tz), my_off);
@@ -235,6 +262,43 @@ __global__ __launch_bounds__(256) void k_project_fwd(
     }
     group_count_tiles(S, cam.TW, cam.TW * cam.TH, total, group_base, tile_count, rank, status, capacity, sticky);
   }
+}
+
+template <int DEG, bool FUSED>
+__global__ __launch_bounds__(256) void k_project_fwd(
+    CamK cam, int N, const float* __restrict__ means, const float* __restrict__ log_scales,
+    const float* __restrict__ quats, const float* __restrict__ opac_logit,
+    const float* __restrict__ sh, int sh_stride, const float* __restrict__ colors_in,
+    float* __restrict__ splats, int32_t* __restrict__ radii, int32_t* __restrict__ group_base,
+    int32_t* __restrict__ tile_count, int32_t* __restrict__ rank, int32_t* __restrict__ status,
+    long long capacity, int32_t* __restrict__ sticky) {
+  __shared__ GroupScan S;
+  project_fwd_body<DEG, FUSED, false>(cam, N, means, log_scales, quats, opac_logit, sh, sh_stride, colors_in,
+                                      splats, radii, group_base, tile_count, rank, status, capacity, sticky,
+                                      FUSED ? &S : nullptr);
+}
+
+// K1 + count with the colours evaluated ahead of time by the previous step's optimizer kernel
+// (tgs_project_bwd_adam_next): valid iff that kernel ran to its end, which it records in the tag word.
+// The choice is made ONCE, around the whole body -- a branch around the SH evaluation alone keeps
+// the compiler from issuing the coefficient loads up front with the other parameter loads
+// (52 instead of 78 VGPRs, K1 71 -> 83 us on the fallback path).
+template <int DEG>
+__global__ __launch_bounds__(256) void k_project_fwd_colors(
+    CamK cam, int N, const float* __restrict__ means, const float* __restrict__ log_scales,
+    const float* __restrict__ quats, const float* __restrict__ opac_logit,
+    const float* __restrict__ sh, int sh_stride, const float* __restrict__ colors_in,
+    float* __restrict__ splats, int32_t* __restrict__ radii, int32_t* __restrict__ group_base,
+    int32_t* __restrict__ tile_count, int32_t* __restrict__ rank, int32_t* __restrict__ status,
+    long long capacity, int32_t* __restrict__ sticky, const int32_t* __restrict__ color_tag,
+    int32_t tag_expect) {
+  __shared__ GroupScan S;
+  if (*color_tag == tag_expect)
+    project_fwd_body<DEG, true, true>(cam, N, means, log_scales, quats, opac_logit, sh, sh_stride, colors_in,
+                                      splats, radii, group_base, tile_count, rank, status, capacity, sticky, &S);
+  else
+    project_fwd_body<DEG, true, false>(cam, N, means, log_scales, quats, opac_logit, sh, sh_stride, colors_in,
+                                       splats, radii, group_base, tile_count, rank, status, capacity, sticky, &S);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -499,8 +563,9 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
     const float* __restrict__ partials, float* __restrict__ v_means,
     float* __restrict__ v_log_scales, float* __restrict__ v_quats,
     float* __restrict__ v_opac_logit, float* __restrict__ v_sh, float* __restrict__ v_xy,
-    AdamK ad_in, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq) {
+    AdamK ad_in, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq, NextView nx) {
   // overflowed frame: the pair index space is not backed by memory and the step must not touch the model
+  // (nor is the next view's colour prefetch produced: its tag word keeps its old value)
   if (ad_in.guard && ad_in.guard[1]) {
     // colour mode (v_sh is the rank's colour-gradient block): the pad slot carries the overflow flag
     if (COLOR_ONLY && blockIdx.x == 0 && threadIdx.x == 0) v_sh[3 * (size_t)N + 3] = 1.f;
@@ -626,6 +691,7 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
         float pm = m[j], M = ea[e], V = es[e];
         adam1(ad, ad.lr_means, pm, vm[j], M, V);
         means[3 * g + j] = pm; ea[e] = M; es[e] = V;
+        m[j] = pm;   // the colour prefetch below looks from the NEXT camera at the UPDATED mean
       }
 #pragma unroll
       for (int j = 0; j < 3; j++) {
@@ -685,8 +751,23 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
           adam1(ad, c + 2 < 3 ? ad.lr_dc : ad.lr_rest, P[u].z, G.z, M[u].z, V[u].z);
           adam1(ad, ad.lr_rest, P[u].w, G.w, M[u].w, V[u].w);
           st4_nt(sh + e, P[u]); st4_nt(exp_avg + ad.e_opac + e, M[u]); st4_nt(exp_avg_sq + ad.e_opac + e, V[u]);
+          if (nx.colors) st4(lds + row * RS + 4 * c4, P[u]);   // updated coefficients replace the consumed gradient
         }
       }
+    }
+  }
+  if constexpr (FUSE_ADAM) {
+    // Colour prefetch: the next step's K1 needs, of the 3K updated coefficients, only the colour they
+    // give from the next camera -- evaluate it here, where the updated row is on chip, and K1 reads
+    // 12 B instead of 12K B per Gaussian (tgs_project_bin_sort_colors).
+    if (nx.colors) {
+      __syncthreads();
+      if (g < N) {
+        float rgb[3];
+        sh_color<DEG>(m, nx.campos, lds + tid * RS, rgb);
+        nx.colors[3 * g] = rgb[0]; nx.colors[3 * g + 1] = rgb[1]; nx.colors[3 * g + 2] = rgb[2];
+      }
+      if (g == 0) *nx.tag = nx.tag_value;
     }
   }
 }
@@ -904,7 +985,7 @@ extern "C" int tgs_project_bwd(const TgsCamera* cam, int N, const float* means,
                      const_cast<float*>(means), const_cast<float*>(log_scales),                  \
                      const_cast<float*>(quats), const_cast<float*>(opac_logit),                  \
                      const_cast<float*>(sh), splats, group_base, partials, v_means, v_log_scales,\
-                     v_quats, v_opac_logit, v_sh, v_xy, none, (float*)nullptr, (float*)nullptr)
+                     v_quats, v_opac_logit, v_sh, v_xy, none, (float*)nullptr, (float*)nullptr, NextView{})
     DISPATCH_DEG_KS(LAUNCH_LDS, sh_deg, sh_stride);
 #undef LAUNCH_LDS
     TGS_CHECK_LAUNCH();
@@ -926,11 +1007,11 @@ extern "C" int tgs_project_bwd(const TgsCamera* cam, int N, const float* means,
   return TGS_OK;
 }
 
-extern "C" int tgs_project_bwd_adam(const TgsCamera* cam, int N, int sh_stride, int sh_deg,
-                                    float* params, float* exp_avg, float* exp_avg_sq,
-                                    const TgsAdamSpec* spec, const float* splats,
-                                    const int32_t* group_base, const float* partials, float* v_xy,
-                                    const int32_t* skip_if_overflow, void* stream) {
+static int project_bwd_adam_impl(const TgsCamera* cam, int N, int sh_stride, int sh_deg,
+                                 float* params, float* exp_avg, float* exp_avg_sq,
+                                 const TgsAdamSpec* spec, const float* splats,
+                                 const int32_t* group_base, const float* partials, float* v_xy,
+                                 const int32_t* skip_if_overflow, const NextView& nx, void* stream) {
   TGS_CHECK_ARG(camera_ok(cam), "bad camera");
   if (N <= 0) return TGS_OK;
   TGS_CHECK_ARG(params && exp_avg && exp_avg_sq && spec && splats && group_base && partials, "null pointer");
@@ -951,21 +1032,48 @@ extern "C" int tgs_project_bwd_adam(const TgsCamera* cam, int N, int sh_stride, 
   hipLaunchKernelGGL((k_project_bwd_lds<D, KS, true>), grid, block, lds_bytes, s, k, N, means,   \
                      log_scales, quats, opac, sh, splats, group_base, partials, (float*)nullptr, \
                      (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, v_xy, a,\
-                     exp_avg, exp_avg_sq)
+                     exp_avg, exp_avg_sq, nx)
   DISPATCH_DEG_KS(LAUNCH_F, sh_deg, sh_stride);
 #undef LAUNCH_F
   TGS_CHECK_LAUNCH();
   return TGS_OK;
 }
 
+extern "C" int tgs_project_bwd_adam(const TgsCamera* cam, int N, int sh_stride, int sh_deg,
+                                    float* params, float* exp_avg, float* exp_avg_sq,
+                                    const TgsAdamSpec* spec, const float* splats,
+                                    const int32_t* group_base, const float* partials, float* v_xy,
+                                    const int32_t* skip_if_overflow, void* stream) {
+  return project_bwd_adam_impl(cam, N, sh_stride, sh_deg, params, exp_avg, exp_avg_sq, spec, splats,
+                               group_base, partials, v_xy, skip_if_overflow, NextView{}, stream);
+}
+
+extern "C" int tgs_project_bwd_adam_next(const TgsCamera* cam, int N, int sh_stride, int sh_deg,
+                                         float* params, float* exp_avg, float* exp_avg_sq,
+                                         const TgsAdamSpec* spec, const float* splats,
+                                         const int32_t* group_base, const float* partials,
+                                         float* v_xy, const int32_t* skip_if_overflow,
+                                         const TgsCamera* next_cam, float* colors_next,
+                                         int32_t* color_tag, int32_t tag_value, void* stream) {
+  TGS_CHECK_ARG(camera_ok(next_cam), "bad next camera");
+  TGS_CHECK_ARG(colors_next && color_tag, "null colour prefetch buffer");
+  const CamK kn = make_camk(next_cam);
+  NextView nx;
+  nx.campos[0] = kn.campos[0]; nx.campos[1] = kn.campos[1]; nx.campos[2] = kn.campos[2];
+  nx.colors = colors_next; nx.tag = color_tag; nx.tag_value = tag_value;
+  return project_bwd_adam_impl(cam, N, sh_stride, sh_deg, params, exp_avg, exp_avg_sq, spec, splats,
+                               group_base, partials, v_xy, skip_if_overflow, nx, stream);
+}
+
 // K1 + K3a fused, then scan / fill / sort: the whole front half of a frame in one call.
-extern "C" int tgs_project_bin_sort(const TgsCamera* cam, int N, const float* means,
-                                    const float* log_scales, const float* quats,
-                                    const float* opac_logit, const float* sh, int sh_stride,
-                                    int sh_deg, float* splats, int32_t* radii, int32_t* group_base,
-                                    int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
-                                    int32_t* tile_order, int64_t capacity, void* scratch,
-                                    int32_t* status, int32_t* sticky_overflow, void* stream) {
+static int project_bin_sort_impl(const TgsCamera* cam, int N, const float* means,
+                                 const float* log_scales, const float* quats,
+                                 const float* opac_logit, const float* sh, int sh_stride,
+                                 int sh_deg, float* splats, int32_t* radii, int32_t* group_base,
+                                 int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
+                                 int32_t* tile_order, int64_t capacity, void* scratch,
+                                 int32_t* status, int32_t* sticky_overflow, const float* colors_in,
+                                 const int32_t* color_tag, int32_t tag_expect, void* stream) {
   TGS_CHECK_ARG(camera_ok(cam), "bad camera");
   TGS_CHECK_ARG(N >= 0 && capacity >= 0 && capacity < (1ll << 31), "bad size");
   TGS_CHECK_ARG(cam->W <= 4080 && cam->H <= 4080, "image side > 4080 px (255 tiles)");
@@ -987,18 +1095,60 @@ extern "C" int tgs_project_bin_sort(const TgsCamera* cam, int N, const float* me
   hipLaunchKernelGGL((k_project_fwd<D, true>), grid, block, 0, s, k, N, means, log_scales, quats,  \
                      opac_logit, sh, sh_stride, (const float*)nullptr, splats, radii, group_base,   \
                      tile_cursor, sc.rank, status, (long long)capacity, sticky_overflow)
-    switch (sh_deg) {
-      case 0: LAUNCH(0); break;
-      case 1: LAUNCH(1); break;
-      case 2: LAUNCH(2); break;
-      case 3: LAUNCH(3); break;
-      default: LAUNCH(-1); break;
+#define LAUNCH_PRE(D)                                                                              \
+  hipLaunchKernelGGL((k_project_fwd_colors<D>), grid, block, 0, s, k, N, means, log_scales, quats, \
+                     opac_logit, sh, sh_stride, colors_in, splats, radii, group_base, tile_cursor,  \
+                     sc.rank, status, (long long)capacity, sticky_overflow, color_tag, tag_expect)
+    if (colors_in && color_tag && sh_deg >= 0) {
+      switch (sh_deg) {
+        case 0: LAUNCH_PRE(0); break;
+        case 1: LAUNCH_PRE(1); break;
+        case 2: LAUNCH_PRE(2); break;
+        default: LAUNCH_PRE(3); break;
+      }
+    } else {
+      switch (sh_deg) {
+        case 0: LAUNCH(0); break;
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        case 3: LAUNCH(3); break;
+        default: LAUNCH(-1); break;
+      }
     }
 #undef LAUNCH
+#undef LAUNCH_PRE
     TGS_CHECK_LAUNCH();
   }
   return tgs_bin_finish(k, N, splats, group_base, tile_start, tile_cursor, sorted_gid, tile_order,
                         capacity, scratch, status, s);
+}
+
+extern "C" int tgs_project_bin_sort(const TgsCamera* cam, int N, const float* means,
+                                    const float* log_scales, const float* quats,
+                                    const float* opac_logit, const float* sh, int sh_stride,
+                                    int sh_deg, float* splats, int32_t* radii, int32_t* group_base,
+                                    int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
+                                    int32_t* tile_order, int64_t capacity, void* scratch,
+                                    int32_t* status, int32_t* sticky_overflow, void* stream) {
+  return project_bin_sort_impl(cam, N, means, log_scales, quats, opac_logit, sh, sh_stride, sh_deg, splats,
+                               radii, group_base, tile_start, tile_cursor, sorted_gid, tile_order, capacity,
+                               scratch, status, sticky_overflow, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int tgs_project_bin_sort_colors(const TgsCamera* cam, int N, const float* means,
+                                           const float* log_scales, const float* quats,
+                                           const float* opac_logit, const float* sh, int sh_stride,
+                                           int sh_deg, float* splats, int32_t* radii,
+                                           int32_t* group_base, int32_t* tile_start,
+                                           int32_t* tile_cursor, int32_t* sorted_gid,
+                                           int32_t* tile_order, int64_t capacity, void* scratch,
+                                           int32_t* status, int32_t* sticky_overflow,
+                                           const float* colors_in, const int32_t* color_tag,
+                                           int32_t tag_expect, void* stream) {
+  TGS_CHECK_ARG(sh && colors_in && color_tag, "null pointer (the SH rows stay the fallback)");
+  return project_bin_sort_impl(cam, N, means, log_scales, quats, opac_logit, sh, sh_stride, sh_deg, splats,
+                               radii, group_base, tile_start, tile_cursor, sorted_gid, tile_order, capacity,
+                               scratch, status, sticky_overflow, colors_in, color_tag, tag_expect, stream);
 }
 
 extern "C" int tgs_sh_fwd(int N, int sh_deg, int sh_stride, const float* dirs, const float* coeffs,
@@ -1064,7 +1214,7 @@ extern "C" int tgs_project_bwd_color(const TgsCamera* cam, int N, const float* m
                      const_cast<float*>(means), const_cast<float*>(log_scales),                  \
                      const_cast<float*>(quats), const_cast<float*>(opac_logit),                  \
                      const_cast<float*>(sh), splats, group_base, partials, v_means, v_log_scales,\
-                     v_quats, v_opac_logit, v_color, v_xy, none, (float*)nullptr, (float*)nullptr)
+                     v_quats, v_opac_logit, v_color, v_xy, none, (float*)nullptr, (float*)nullptr, NextView{})
     DISPATCH_DEG_KS(LAUNCH_C, sh_deg, sh_stride);
 #undef LAUNCH_C
     TGS_CHECK_LAUNCH();

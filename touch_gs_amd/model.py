@@ -117,12 +117,12 @@ class DepthGaussianSplattingModel:
     def num_points(self) -> int:
         return self.params.N
 
-    def active_sh_degree(self) -> int:
+    def active_sh_degree(self, step: Optional[int] = None) -> int:
         c = self.config
         max_deg = int(round(math.sqrt(self.params.K))) - 1
         if c.sh_degree_interval <= 0:
             return min(c.sh_degree, max_deg)
-        return min(self.step // c.sh_degree_interval, c.sh_degree, max_deg)
+        return min((self.step if step is None else step) // c.sh_degree_interval, c.sh_degree, max_deg)
 
     def get_outputs(self, cam: Camera, sh_degree: Optional[int] = None) -> Dict[str, torch.Tensor]:
         """Camera -> {rgb, depth, accumulation} (differentiable; autograd path)."""
@@ -211,7 +211,8 @@ class DepthGaussianSplattingModel:
         return spec
 
     def forward_backward(self, view: View, want_v_xy: bool = False, fuse_adam: bool = False,
-                         color_block: Optional[torch.Tensor] = None, begin_step: bool = True):
+                         color_block: Optional[torch.Tensor] = None, begin_step: bool = True,
+                         colors=None, prefetch=None):
         """Forward + loss + backward of one view into ``params.grad`` (overwritten) -- or, with
         ``fuse_adam``, straight through the optimizer update (K8+K9 fused, ``params.grad`` untouched).
         No host sync unless ``budget.sync``.  Returns device tensors (l1+depth tile losses, ssim sum)."""
@@ -219,7 +220,8 @@ class DepthGaussianSplattingModel:
         deg = self.active_sh_degree()
         H, W = cam.H, cam.W
         splats, radii, group_base, tile_start, sorted_gid, status = ops.project_bin_sort(
-            cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, self.budget, want_radii=want_v_xy)
+            cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, self.budget, want_radii=want_v_xy,
+            colors=colors)
         guard = None if self.budget.sync else status   # overflowed frame => optimizer kernels are no-ops
         rgb, depth_acc, fT, fidx = ops.rasterize_fwd(cam, splats, sorted_gid, tile_start)
         v_img, ssim_sum = None, None
@@ -230,7 +232,7 @@ class DepthGaussianSplattingModel:
                                                 loss=self.loss_spec(view), want_tile_loss=True)
         if fuse_adam:
             v_xy = self.optimizer.backward_and_step(cam, deg, splats, group_base, partials, want_v_xy,
-                                                    begin=begin_step, guard=guard)
+                                                    begin=begin_step, guard=guard, prefetch=prefetch)
         elif color_block is not None:   # data-parallel: geometry gradients + colour-gradient block
             v_xy = ops.project_bwd_color(cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, splats,
                                          group_base, partials, p.grad_views()[:4], color_block, want_v_xy, guard=guard)
@@ -267,6 +269,7 @@ class DepthGaussianSplattingModel:
             density.vis_count = density.vis_count[perm]
             density.max_radius = density.max_radius[perm]
         self._graphs = {}
+        self._prefetch_ready = None
         return perm
 
     def enable_densification(self, cfg=None):
@@ -378,12 +381,18 @@ class DepthGaussianSplattingModel:
         self._graphs = {}
         self.optimizer.use_device_bias_corr = False
 
-    def train_step(self, view: View, dp=None) -> None:
-        """One optimizer iteration on one view (per rank).  ``dp``: a parallel.GradSync or None."""
+    def train_step(self, view: View, dp=None, next_view: Optional[View] = None) -> None:
+        """One optimizer iteration on one view (per rank).  ``dp``: a parallel.GradSync or None.
+        ``next_view``: the view of the FOLLOWING train_step call, if the caller knows it (single
+        process, fused optimizer): the optimizer kernel then also evaluates the colours the updated
+        Gaussians show to that camera, and the following step's K1 skips the SH rows (colour
+        prefetch; same results bit for bit).  The caller promises not to modify the parameters
+        between the two calls except through this class."""
         distributed = dp is not None and dp.active
         opt = self.optimizer
         opt.lrs["means"] = self.config.lr_means_at(self.step)   # scheduled position learning rate
         deg = self.active_sh_degree()
+        pre, self._prefetch_ready = getattr(self, "_prefetch_ready", None), None
         graphs = getattr(self, "_graphs", None)
         if graphs and not distributed and getattr(self, "density", None) is None:
             entry = graphs.get(id(view))
@@ -411,7 +420,18 @@ class DepthGaussianSplattingModel:
                 self._color_block = torch.zeros(n, dtype=torch.float32, device=dev)
                 self._color_all = torch.zeros(dp.world, n, dtype=torch.float32, device=dev)
             block = self._color_block
-        self.forward_backward(view, want_v_xy=density is not None, fuse_adam=fuse, color_block=block)
+        colors = pre if (pre is not None and fuse and pre.matches(view.cam, self.params.N, deg)) else None
+        arm = None
+        if fuse and next_view is not None and density is None and self.active_sh_degree(self.step + 1) == deg:
+            bufs = getattr(self, "_prefetch_bufs", None)
+            N, dev = self.params.N, self.params.flat.device
+            if bufs is None or bufs[0].N != N or bufs[0].colors.device != dev:
+                bufs = self._prefetch_bufs = [ops.ColorPrefetch(N, dev), ops.ColorPrefetch(N, dev)]
+            # two buffers alternate: the one this step's K1 reads is not the one this step's K9 writes
+            arm = (bufs[1] if colors is bufs[0] else bufs[0]).arm(next_view.cam, deg)
+        self.forward_backward(view, want_v_xy=density is not None, fuse_adam=fuse, color_block=block,
+                              colors=colors, prefetch=arm)
+        self._prefetch_ready = arm
         if density is not None:
             density.accumulate(self.last["v_xy"], self.last["radii"], view.cam.W, view.cam.H)
         if factored:
@@ -439,6 +459,7 @@ class DepthGaussianSplattingModel:
         if density is not None and density.due(self.step):
             self.params, self.optimizer, self.last_refine = density.refine(self.params, self.optimizer, self.step, dp)
             self.budget = ops.IntersectBudget()  # the intersection count changes with N
+            self._prefetch_ready = None
             if self.config.spatial_sort:
                 self.spatial_sort()              # the appended clones / splits go back to their neighbours
 
@@ -463,6 +484,7 @@ class DepthGaussianSplattingModel:
             if getattr(self, "density", None) is not None:
                 self.density.reset_stats(sd["N"], dev)
         self.params.flat.copy_(sd["flat"])
+        self._prefetch_ready = None
         self.step = sd["step"]
         self.optimizer.load_state_dict(sd["optim"])
 

@@ -148,10 +148,34 @@ def bin_sort(cam: Camera, splats, budget: Optional[IntersectBudget] = None):
     return group_base, tile_start, sorted_gid, status
 
 
+class ColorPrefetch:
+    """Colours of the Gaussians for ONE upcoming view, evaluated by the previous step's fused optimizer
+    kernel (tgs_project_bwd_adam_next) so that K1 does not re-read the 12K-byte SH rows
+    (tgs_project_bin_sort_colors).  ``tag_word`` (device int32) holds ``tag`` once the kernel that was
+    asked for this prefetch has run to its end; K1 falls back to the SH rows otherwise."""
+
+    def __init__(self, N: int, device):
+        self.colors = torch.empty(max(N, 1), 3, dtype=torch.float32, device=device)
+        self.tag_word = torch.zeros(1, dtype=torch.int32, device=device)
+        self.tag = 0
+        self.cam = None
+        self.N, self.sh_deg = N, -1
+
+    def arm(self, cam: Camera, sh_deg: int) -> "ColorPrefetch":
+        self.tag += 1
+        self.cam, self.sh_deg = cam, sh_deg
+        return self
+
+    def matches(self, cam: Camera, N: int, sh_deg: int) -> bool:
+        return self.cam is cam and self.N == N and self.sh_deg == sh_deg and self.tag > 0
+
+
 def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_deg: int,
-                     budget: Optional[IntersectBudget] = None, want_radii: bool = False):
+                     budget: Optional[IntersectBudget] = None, want_radii: bool = False,
+                     colors: Optional[ColorPrefetch] = None):
     """K1 fused with the tile counting, then scan / fill / sort: the front half of a frame in ONE C
-    call -> (splats, radii or None, group_base, tile_start, sorted_gid, status).  (tgs_project_bin_sort)"""
+    call -> (splats, radii or None, group_base, tile_start, sorted_gid, status).  (tgs_project_bin_sort;
+    with ``colors`` -- a ColorPrefetch armed for THIS camera -- tgs_project_bin_sort_colors)"""
     lib = _lib.load()
     budget = budget or _default_budget
     N = means.shape[0]
@@ -175,12 +199,21 @@ def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_d
     while True:
         sorted_gid = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
         scratch = torch.empty(lib.tgs_sort_scratch_bytes(cap), dtype=torch.uint8, device=dev)
-        check(lib.tgs_project_bin_sort(C.byref(cs), N, ptr(means), ptr(log_scales), ptr(quats), ptr(opac_logit),
-                                       ptr(sh), sh_stride, sh_deg if sh is not None else -1, ptr(splats),
-                                       ptr(radii), ptr(group_base), ptr(tile_start), ptr(tile_cursor),
-                                       ptr(sorted_gid), ptr(tile_order), cap, ptr(scratch), ptr(status),
-                                       ptr(budget.sticky_word(dev)), _stream()),
-              "tgs_project_bin_sort")
+        if colors is None or sh is None:
+            check(lib.tgs_project_bin_sort(C.byref(cs), N, ptr(means), ptr(log_scales), ptr(quats), ptr(opac_logit),
+                                           ptr(sh), sh_stride, sh_deg if sh is not None else -1, ptr(splats),
+                                           ptr(radii), ptr(group_base), ptr(tile_start), ptr(tile_cursor),
+                                           ptr(sorted_gid), ptr(tile_order), cap, ptr(scratch), ptr(status),
+                                           ptr(budget.sticky_word(dev)), _stream()),
+                  "tgs_project_bin_sort")
+        else:
+            check(lib.tgs_project_bin_sort_colors(C.byref(cs), N, ptr(means), ptr(log_scales), ptr(quats),
+                                                  ptr(opac_logit), ptr(sh), sh_stride, sh_deg, ptr(splats),
+                                                  ptr(radii), ptr(group_base), ptr(tile_start), ptr(tile_cursor),
+                                                  ptr(sorted_gid), ptr(tile_order), cap, ptr(scratch), ptr(status),
+                                                  ptr(budget.sticky_word(dev)), ptr(colors.colors),
+                                                  ptr(colors.tag_word), colors.tag, _stream()),
+                  "tgs_project_bin_sort_colors")
         budget.last_status = status
         if not budget.sync:
             break

@@ -164,8 +164,10 @@ class FusedAdam:
         return self.p.K in (4, 16) and 0 <= sh_deg and (sh_deg + 1) ** 2 <= self.p.K
 
     def backward_and_step(self, cam, sh_deg: int, splats, group_base, partials, want_v_xy: bool = False,
-                          begin: bool = True, guard=None):
-        """K8 + K9 in one launch (single-process training): gradients never reach HBM."""
+                          begin: bool = True, guard=None, prefetch=None):
+        """K8 + K9 in one launch (single-process training): gradients never reach HBM.
+        ``prefetch`` = ops.ColorPrefetch armed for the next view: the kernel also writes the colours
+        the UPDATED Gaussians show to that camera (tgs_project_bwd_adam_next)."""
         lib = _lib.load()
         if begin:
             self.begin_step()
@@ -173,9 +175,17 @@ class FusedAdam:
         cs = cam.c_struct()
         v_xy = torch.empty(self.p.N, 2, dtype=torch.float32, device=self.p.flat.device) if want_v_xy else None
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        check(lib.tgs_project_bwd_adam(C.byref(cs), self.p.N, self.p.K, sh_deg, ptr(self.p.flat), ptr(self.exp_avg),
-                                       ptr(self.exp_avg_sq), C.byref(s), ptr(splats), ptr(group_base),
-                                       ptr(partials), ptr(v_xy), ptr(guard), stream), "tgs_project_bwd_adam")
+        if prefetch is None:
+            check(lib.tgs_project_bwd_adam(C.byref(cs), self.p.N, self.p.K, sh_deg, ptr(self.p.flat), ptr(self.exp_avg),
+                                           ptr(self.exp_avg_sq), C.byref(s), ptr(splats), ptr(group_base),
+                                           ptr(partials), ptr(v_xy), ptr(guard), stream), "tgs_project_bwd_adam")
+        else:
+            ncs = prefetch.cam.c_struct()
+            check(lib.tgs_project_bwd_adam_next(C.byref(cs), self.p.N, self.p.K, sh_deg, ptr(self.p.flat),
+                                                ptr(self.exp_avg), ptr(self.exp_avg_sq), C.byref(s), ptr(splats),
+                                                ptr(group_base), ptr(partials), ptr(v_xy), ptr(guard),
+                                                C.byref(ncs), ptr(prefetch.colors), ptr(prefetch.tag_word),
+                                                prefetch.tag, stream), "tgs_project_bwd_adam_next")
         return v_xy
 
     def can_gather_sh(self) -> bool:

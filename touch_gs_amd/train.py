@@ -157,7 +157,9 @@ def main(argv=None):
     t0 = time.time()
     for step in range(model.step, args.max_num_iterations):
         view = train_views[dp.views_for_step(step, len(train_views))]
-        model.train_step(view, dp if dp.active else None)
+        # single process: tell the step which view follows (colour prefetch, model.train_step)
+        nxt = None if dp.active else train_views[dp.views_for_step(step + 1, len(train_views))]
+        model.train_step(view, dp if dp.active else None, next_view=nxt)
         if dp.rank == 0 and (step + 1) % args.steps_per_eval == 0:
             model.flush()
             loss = model.loss_from(model.last["tile_loss"], model.last["ssim_sum"], view)
