@@ -524,11 +524,11 @@ def test_tile_order_schedule(dev, W, H):
     out_a = ops.rasterize_fwd(acam, splats, sg, ts)
     bwd_a = ops.rasterize_bwd(acam, splats, gb, sg, ts, out_a[0], out_a[1], out_a[2],
                               v_rgb=torch.ones_like(out_a[0]), v_depth=torch.ones_like(out_a[1]))[0]
-    n_pairs = int(ts[-1])
     del ts.tile_order                      # wrappers now pass NULL: spatial order
     out_b = ops.rasterize_fwd(acam, splats, sg, ts)
     bwd_b = ops.rasterize_bwd(acam, splats, gb, sg, ts, out_b[0], out_b[1], out_b[2],
                               v_rgb=torch.ones_like(out_b[0]), v_depth=torch.ones_like(out_b[1]))[0]
     for a, b in zip(out_a[:3], out_b[:3]):
         assert torch.equal(a, b)
-    assert torch.equal(bwd_a[:n_pairs], bwd_b[:n_pairs])
+    # the pair index space has holes (one region per XCD): compare the slots that exist, through K8a
+    assert torch.equal(ops.reduce_partials(acam, splats, gb, bwd_a), ops.reduce_partials(acam, splats, gb, bwd_b))

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(TGS_GROUP) void k_tile_count(
 // alternating same-box runs after clock warm-up).
 __global__ __launch_bounds__(1024) void k_scan_tiles(int T, int NB, int32_t* __restrict__ tile_count,
                                                      int32_t* __restrict__ tile_start,
-                                                     const int32_t* __restrict__ status,
+                                                     int32_t* __restrict__ status,
                                                      int32_t* __restrict__ tile_order) {
   __shared__ int wave_tot[16];
   __shared__ int s_base;
@@ -102,6 +102,15 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int T, int NB, int32_t* __r
     return;
   }
   const bool overflow = status[1] != 0;
+  if (blockIdx.x == 0 && tid == 0) {
+    // status[0]: the frame's intersection count = sum of the 8 per-XCD allocators; on overflow the
+    // capacity that would have sufficed with this frame's split over the XCDs (8 x the fullest region)
+    const int32_t* xa = tile_count + TGS_ALLOC_OFF(T);
+    long long n = 0, mx = 0;
+    for (int x = 0; x < TGS_XCC; x++) { n += xa[x * TGS_ALLOC_STRIDE]; mx = max(mx, (long long)xa[x * TGS_ALLOC_STRIDE]); }
+    if (overflow) n = max(n, TGS_XCC * mx);
+    status[0] = (int32_t)min(n, 0x7fffffffll);
+  }
   int32_t* __restrict__ sub_start = tile_count + TGS_XCC * T;
   int32_t* __restrict__ agg = sub_start + TGS_XCC * T;     // [NB] aggregate + 1 of every scan workgroup, 0 = not yet
   const int b = blockIdx.x, t = b * 1024 + tid;

@@ -31,7 +31,12 @@ int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* gro
 // counter buffer layout: count[8][T] | sub_start[8][T] | scan aggregates[64] | longest list[1] (+pad)
 #define TGS_XCC 8
 #define TGS_SCAN_WGS 64
-static inline int tgs_counter_len(int T) { return 2 * TGS_XCC * T + TGS_SCAN_WGS + 4; }
+// ... | pair allocators: 8 words, one per XCD, each in a 128-B line of its own.  The pair index space
+// [0, capacity) is cut into one region per XCD and a group takes its contiguous pair range from the
+// region of the XCD it runs on.
+#define TGS_ALLOC_STRIDE 32
+#define TGS_ALLOC_OFF(T) ((2 * TGS_XCC * (T) + TGS_SCAN_WGS + 4 + 31) / 32 * 32)
+static inline int tgs_counter_len(int T) { return TGS_ALLOC_OFF(T) + TGS_XCC * TGS_ALLOC_STRIDE; }
 
 // Aggregated counting (spatially ordered parameter buffers): when the tile bounding box of a group's
 // 256 Gaussians holds at most TGS_AGG_TILES tiles, its pairs are first counted per tile in an LDS
@@ -57,7 +62,7 @@ struct GroupScan {
   int x0[TGS_GROUP], y0[TGS_GROUP], w[TGS_GROUP];
   unsigned depth_bits[TGS_GROUP];
   int wave_tot[TGS_GROUP / TGS_WAVE];
-  int base;
+  int base, fits;
   int wave_bbox[TGS_GROUP / TGS_WAVE][4];   // per wave: min x0, min y0, max x1, max y1 of its rects (tiles)
   int hist[TGS_AGG_TILES];     // aggregated counting: pairs per tile of the bounding box, then their base rank
 };
@@ -127,6 +132,7 @@ static __global__ __launch_bounds__(256) void k_clear_counters(int32_t* __restri
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < TGS_XCC * T) tile_cursor[i] = 0;
   if (i < TGS_SCAN_WGS + 4) tile_cursor[2 * TGS_XCC * T + i] = 0;   // look-back flags of k_scan_tiles, longest list
+  if (i < TGS_XCC) tile_cursor[TGS_ALLOC_OFF(T) + i * TGS_ALLOC_STRIDE] = 0;   // pair allocators
   if (i == 0) status[0] = 0;
   if (i == 1) status[1] = sticky ? (*sticky != 0) : 0;
 }
@@ -156,19 +162,11 @@ __device__ __forceinline__ void group_count_tiles(GroupScan& S, int TW, int T, i
                                                   int32_t* __restrict__ status, long long capacity,
                                                   int32_t* __restrict__ sticky) {
   const int tid = threadIdx.x;
-  if (tid == 0) {
-    const int base = total ? atomicAdd(&status[0], total) : 0;
-    S.base = base;
-    group_base[tgs_group_id()] = base;
-    if ((long long)base + total > capacity) {
-      status[1] = 1;
-      if (sticky) *sticky = 1;
-    }
-  }
-  __syncthreads();
-  const long long base = S.base;
-  const bool fits = base + total <= capacity;
   const int x = xcc_id();
+  // pair range of the group: one returning atomic on the XCD's allocator.  Issued first and consumed
+  // last (publication below), so its round trip to the memory side overlaps the counting.
+  int local = 0;
+  if (tid == 0 && total > 0) local = atomicAdd(&tile_count[TGS_ALLOC_OFF(T) + x * TGS_ALLOC_STRIDE], total);
   int32_t* __restrict__ my_count = tile_count + (size_t)x * T;
   int bx0 = 1 << 30, by0 = 1 << 30, bx1 = 0, by1 = 0;   // tile bounding box of the group's rects
 #pragma unroll
@@ -178,11 +176,12 @@ __device__ __forceinline__ void group_count_tiles(GroupScan& S, int TW, int T, i
   }
   const int bw = bx1 - bx0, bh = by1 - by0;
   const int area = bw * bh;
-  int first_direct = 0;
-  if (total > 0 && area <= TGS_AGG_TILES) {   // workgroup-uniform
+  const bool agg = total > 0 && area <= TGS_AGG_TILES;   // workgroup-uniform
+  if (agg)
     for (int b = tid; b < area; b += TGS_GROUP) S.hist[b] = 0;
-    __syncthreads();
-    int lr[TGS_AGG_U], lb[TGS_AGG_U];
+  __syncthreads();                                            // the group scan (and the cleared histogram) is visible
+  int lr[TGS_AGG_U], lb[TGS_AGG_U];
+  if (agg) {
 #pragma unroll
     for (int u = 0; u < TGS_AGG_U; u++) {
       const int i = tid + u * TGS_GROUP;
@@ -202,7 +201,23 @@ __device__ __forceinline__ void group_count_tiles(GroupScan& S, int TW, int T, i
         S.hist[b] = atomicAdd(&my_count[(by0 + by) * TW + bx0 + (b - by * bw)], c);
       }
     }
-    __syncthreads();
+  }
+  if (tid == 0) {                                             // publication of the pair range
+    const long long region = capacity / TGS_XCC;              // pairs per XCD region
+    const int base = (int)(x * region) + local;
+    S.base = base;
+    S.fits = (long long)local + total <= region;
+    group_base[tgs_group_id()] = base;
+    if (!S.fits) {
+      status[1] = 1;
+      if (sticky) *sticky = 1;
+    }
+  }
+  __syncthreads();
+  const long long base = S.base;
+  const bool fits = S.fits != 0;
+  int first_direct = 0;
+  if (agg) {
 #pragma unroll
     for (int u = 0; u < TGS_AGG_U; u++) {
       const int i = tid + u * TGS_GROUP;
