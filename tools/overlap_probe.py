@@ -1,6 +1,6 @@
-"""Developer tool: does SSIM overlap usefully with the compositing kernels when launched on a second
-stream?  (independent launches, no data dependency; cfg3)"""
-import sys, time, torch
+"""Developer probe: do the compositing kernels (VALU-bound) and the SSIM kernels (latency-bound) overlap
+when they run on two streams?  Prints K6 alone, SSIM alone, both concurrently; same for K7."""
+import sys, torch
 sys.path.insert(0, '.')
 from touch_gs_amd import ops
 from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
@@ -9,49 +9,41 @@ from touch_gs_amd.scene import make_view, synthetic_gaussians
 N, W, H, deg = 1_000_000, 1920, 1080, 3
 dev = torch.device('cuda:0')
 P, _ = synthetic_gaussians(N, W, H, deg, 1236)
-p = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
-model = DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=0), p)
+params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
+model = DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=0), params)
+model.spatial_sort()
 view = make_view(N, W, H, deg, 1236, dev, view=0, n_views=8)
-view.valid_count()
-cam = view.cam
-splats, radii, gb, ts, sg, _ = ops.project_bin_sort(cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, model.budget)
-rgb, dacc, fT, _ = ops.rasterize_fwd(cam, splats, sg, ts)
-spec = model.loss_spec(view)
-side = torch.cuda.Stream()
-torch.cuda.synchronize()
+p = model.params
+sp, _, gb, ts, sg, st = ops.project_bin_sort(view.cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg)
+rgb, dacc, fT, _ = ops.rasterize_fwd(view.cam, sp, sg, ts)
+_, v_img = ops.ssim_fwd_bwd(rgb, view.rgb, weight=-0.2 / (3 * H * W), reduce=False)
+s2 = torch.cuda.Stream()
+main = torch.cuda.current_stream()
 
+def k6(): ops.rasterize_fwd(view.cam, sp, sg, ts)
+def k7(): ops.rasterize_bwd(view.cam, sp, gb, sg, ts, rgb, dacc, fT, v_rgb=v_img, loss=model.loss_spec(view), want_tile_loss=True)
+def ssim(): ops.ssim_fwd_bwd(rgb, view.rgb, weight=-0.2 / (3 * H * W), reduce=False)
 
-def k7():
-    ops.rasterize_bwd(cam, splats, gb, sg, ts, rgb, dacc, fT, loss=spec, want_tile_loss=True)
+def timed(fa, fb, reps=10):
+    out = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(main)
+        if fb is not None:
+            s2.wait_event(e0)
+            with torch.cuda.stream(s2):
+                fb()
+                eb = torch.cuda.Event(); eb.record(s2)
+        if fa is not None:
+            fa()
+        if fb is not None:
+            main.wait_event(eb)
+        e1.record(main)
+        torch.cuda.synchronize()
+        out.append(e0.elapsed_time(e1) * 1e3)
+    return sorted(out)[len(out) // 2]
 
-
-def k6():
-    ops.rasterize_fwd(cam, splats, sg, ts)
-
-
-def ssim():
-    ops.ssim_fwd_bwd(rgb, view.rgb, weight=-0.2 / (3 * H * W))
-
-
-def wall(fn, n=20):
-    for _ in range(3): fn()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(n): fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n * 1e6
-
-
-def both(a, b):
-    def f():
-        ev = torch.cuda.Event(); ev.record()
-        side.wait_event(ev)
-        with torch.cuda.stream(side):
-            b()
-        a()
-        ev2 = torch.cuda.Event(); ev2.record(side)
-        torch.cuda.current_stream().wait_event(ev2)
-    return f
-
-
-print("k7 %.0f  k6 %.0f  ssim %.0f us" % (wall(k7), wall(k6), wall(ssim)))
-print("k7 || ssim %.0f us   k6 || ssim %.0f us   k7 || k6 %.0f us" % (wall(both(k7, ssim)), wall(both(k6, ssim)), wall(both(k7, k6))))
+for name, f in (("K6", k6), ("K7", k7)):
+    a, b, ab = timed(f, None), timed(None, ssim), timed(f, ssim)
+    print(f"{name} alone {a:.0f} us, SSIM alone (side stream) {b:.0f} us, concurrent {ab:.0f} us  (sum {a + b:.0f})")
