@@ -23,5 +23,11 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/prof_pmc$i -- python tools/step_run.py 3 separate > /tmp/pmc$i.log 2>&1
   i=$((i+1))
 done
-python tools/pmc_to_json.py $OUT/kernel_stats.csv /tmp/prof_pmc0 /tmp/prof_pmc1 /tmp/prof_pmc2 /tmp/prof_pmc3 > $OUT/pmc_step_cfg3.json
+# the step as bench.py runs it (fused K8+Adam with the colour prefetch, K1 on prefetched colours): HBM traffic only
+for set in "FETCH_SIZE" "WRITE_SIZE"; do
+  rm -rf /tmp/prof_pmc$i
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/prof_pmc$i -- python tools/step_run.py 4 prefetch > /tmp/pmc$i.log 2>&1
+  i=$((i+1))
+done
+python tools/pmc_to_json.py $OUT/kernel_stats.csv /tmp/prof_pmc0 /tmp/prof_pmc1 /tmp/prof_pmc2 /tmp/prof_pmc3 /tmp/prof_pmc4 /tmp/prof_pmc5 > $OUT/pmc_step_cfg3.json
 echo "wrote $OUT"

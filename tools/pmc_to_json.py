@@ -30,7 +30,9 @@ for k, c in avg.items():
         hbm[k] = {"read_bytes": rd, "write_bytes": wr, "total_bytes": rd + wr}
 print(json.dumps({
     "note": "rocprofv3 per-dispatch averages on cfg3 (1M Gaussians, 1920x1080, SH3). Counters: four separate --pmc "
-            "passes over `tools/step_run.py 3 separate` (FETCH_SIZE | WRITE_SIZE | 8 SQ | 6 SQ + GRBM); FETCH_SIZE/"
+            "passes over `tools/step_run.py 3 separate` (FETCH_SIZE | WRITE_SIZE | 8 SQ | 6 SQ + GRBM) plus FETCH_SIZE and "
+            "WRITE_SIZE passes over `tools/step_run.py 4 prefetch` (the fused step with the colour prefetch: "
+            "k_project_bwd_lds<.., true, false>, k_project_fwd_colors); FETCH_SIZE/"
             "WRITE_SIZE in KB as reported. Durations: kernel trace of `bench.py --steps 20 --warmup 5` (profiler "
             "attached). Produced by tools/collect_profiles.sh.",
     "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE under-reports wide coalesced reads by exactly 2x on "
