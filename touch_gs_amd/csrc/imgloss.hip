@@ -15,6 +15,7 @@
 // bank-conflict cycles; 77 + 80 us at 1080p).  Read amplification here: 74/64 horizontally,
 // (SEG+10)/SEG vertically.  Roofline: HBM (9 adjoint planes written, then read).
 #include <math.h>
+#include <stdlib.h>
 #include "tgs_common.h"
 
 namespace {
@@ -25,11 +26,10 @@ struct Win { float g[WIN]; };
 constexpr int SW = 64;              // strip width (output columns per workgroup)
 constexpr int NTH = 3 * SW;         // threads: (column, channel)
 constexpr int RB = WIN;             // input rows per staged block = window height (phase p = row in block)
-#ifndef TGS_SSIM_NBLK
-#define TGS_SSIM_NBLK 4
-#endif
-constexpr int NBLK = TGS_SSIM_NBLK; // blocks per segment
-constexpr int SEG = RB * NBLK - 2 * HALO;   // 34 output rows per workgroup
+// blocks per segment (nblk, a launch argument): SEG = 11 nblk - 10 output rows per workgroup.  4 (34 rows)
+// at 1080p and above; small images take shorter segments -- the kernels are latency chains over the
+// blocks of a segment, and an 800x800 image has only 312 segments of 34 rows for 256 CUs.
+__host__ __device__ constexpr int seg_rows(int nblk) { return RB * nblk - 2 * HALO; }
 
 // Stages input rows [r0, r0 + RB) x columns [x0 - 5, x0 + SW + 5) of an interleaved [H, W, CH]
 // image into LDS (zero outside the image), in batches of 8 loads in flight per thread.
@@ -64,7 +64,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                                                   const float* __restrict__ img,
                                                   const float* __restrict__ gt,
                                                   float* __restrict__ adj /*[H,W,3,3] or null*/,
-                                                  float* __restrict__ block_partials, int n_partials) {
+                                                  float* __restrict__ block_partials, int n_partials, int NBLK) {
+  const int SEG = seg_rows(NBLK);
   constexpr int ROWF = RowBlock<3>::ROWF;
   __shared__ float sa[RB * ROWF], sb[RB * ROWF];
   __shared__ float red[NTH / TGS_WAVE];
@@ -148,7 +149,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                                                   const float* __restrict__ img,
                                                   const float* __restrict__ gt,
                                                   const float* __restrict__ adj,
-                                                  float* __restrict__ v_img) {
+                                                  float* __restrict__ v_img, int NBLK) {
+  const int SEG = seg_rows(NBLK);
   constexpr int ROWF = RowBlock<9>::ROWF;
   __shared__ float sadj[RB * ROWF];
   const int tid = threadIdx.x;
@@ -210,13 +212,19 @@ extern "C" int tgs_ssim_fwd_bwd(int W, int H, const float* img, const float* gt,
   // block_partials has one entry per 16x16 tile (the buffer contract of include/tgs.h); the
   // streaming kernels write one sum per workgroup (fewer) and zero the rest
   const int n_partials = ((W + 15) / 16) * ((H + 15) / 16);
+  int nblk = 4;
+  while (nblk > 2 && (long long)((W + SW - 1) / SW) * ((H + seg_rows(nblk) - 1) / seg_rows(nblk)) < 3 * 256) nblk--;
+  if (const char* e = getenv("TGS_SSIM_NBLK")) nblk = max(2, min(16, atoi(e)));   // tuning override
+  // block_partials holds one entry per 16x16 tile and one workgroup sum goes into each of the first entries
+  while (nblk < 16 && (long long)((W + SW - 1) / SW) * ((H + seg_rows(nblk) - 1) / seg_rows(nblk)) > n_partials) nblk++;
+  const int SEG = seg_rows(nblk);
   const dim3 grid((W + SW - 1) / SW, (H + SEG - 1) / SEG, 1), block(NTH);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_ssim_fwd, grid, block, 0, s, W, H, win, img, gt, v_img ? scratch : nullptr,
-                     block_partials, n_partials);
+                     block_partials, n_partials, nblk);
   TGS_CHECK_LAUNCH();
   if (v_img) {
-    hipLaunchKernelGGL(k_ssim_bwd, grid, block, 0, s, W, H, win, weight, img, gt, scratch, v_img);
+    hipLaunchKernelGGL(k_ssim_bwd, grid, block, 0, s, W, H, win, weight, img, gt, scratch, v_img, nblk);
     TGS_CHECK_LAUNCH();
   }
   return TGS_OK;
