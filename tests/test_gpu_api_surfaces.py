@@ -695,6 +695,114 @@ def test_nerfstudio_adapter_core_trains(dev):
     assert "psnr" in m and "depth_mse" in m
 
 
+def _nerfstudio_stub():
+    """A stand-in for the parts of the nerfstudio API the plugin shell touches (shape per SURVEY App. A /
+    reference legacy/config_tactile.py:23-56, legacy/model_tactile.py:38-56): config containers that keep
+    their keyword arguments, `Model` = nn.Module that stores config / kwargs and calls populate_modules(),
+    `Cameras` with batched intrinsics and camera_to_worlds.  NOT nerfstudio -- it only lets the shell's own
+    code execute."""
+    import dataclasses, sys, types
+
+    class Cfg:
+        def __init__(self, *a, **kw):
+            self.__dict__.update(kw)
+
+    @dataclasses.dataclass
+    class NSModelConfig:
+        _target: type = None
+
+        def setup(self, **kw):
+            return self._target(self, **kw)
+
+    class Model(torch.nn.Module):
+        def __init__(self, config, scene_box=None, num_train_data=0, **kwargs):
+            super().__init__()
+            self.config, self.scene_box, self.num_train_data, self.kwargs = config, scene_box, num_train_data, kwargs
+            self.populate_modules()
+
+    class Cameras:
+        def __init__(self, camera_to_worlds, fx, fy, cx, cy, width, height):
+            self.camera_to_worlds = camera_to_worlds
+            t = lambda v: torch.tensor([[v]])
+            self.fx, self.fy, self.cx, self.cy, self.width, self.height = t(fx), t(fy), t(cx), t(cy), t(width), t(height)
+
+    layout = {"nerfstudio.configs.base_config": dict(ViewerConfig=Cfg),
+              "nerfstudio.engine.trainer": dict(TrainerConfig=Cfg),
+              "nerfstudio.plugins.types": dict(MethodSpecification=Cfg),
+              "nerfstudio.cameras.cameras": dict(Cameras=Cameras),
+              "nerfstudio.data.datamanagers.full_images_datamanager": dict(FullImageDatamanagerConfig=Cfg),
+              "nerfstudio.data.dataparsers.nerfstudio_dataparser": dict(NerfstudioDataParserConfig=Cfg),
+              "nerfstudio.engine.optimizers": dict(AdamOptimizerConfig=Cfg),
+              "nerfstudio.engine.schedulers": dict(ExponentialDecaySchedulerConfig=Cfg),
+              "nerfstudio.models.base_model": dict(Model=Model, ModelConfig=NSModelConfig),
+              "nerfstudio.pipelines.base_pipeline": dict(VanillaPipelineConfig=Cfg)}
+    mods = {}
+    for name, attrs in layout.items():
+        parts = name.split(".")
+        for i in range(1, len(parts) + 1):
+            mods.setdefault(".".join(parts[:i]), types.ModuleType(".".join(parts[:i])))
+        mods[name].__dict__.update(attrs)
+    return mods, Cameras
+
+
+def test_nerfstudio_plugin_shell_executes_against_a_stub(dev):
+    """nerfstudio cannot be installed here, so the MethodSpecification / Model shell of
+    touch_gs_amd/nerfstudio_plugin.py never ran.  This test runs it against a minimal stand-in for the
+    nerfstudio API (see _nerfstudio_stub): the module imports, the method spec carries the reference's
+    method name and the three flags, the Model builds its parameter groups from seed points, and a
+    nerfstudio-style iteration (get_outputs -> get_loss_dict -> backward -> one Adam per group with the
+    spec's learning rates) reduces the loss."""
+    import importlib, sys
+    import touch_gs_amd.nerfstudio_plugin as plug
+    from touch_gs_amd.scene import make_view, synthetic_gaussians
+    mods, Cameras = _nerfstudio_stub()
+    saved = {k: sys.modules.get(k) for k in mods}
+    sys.modules.update(mods)
+    try:
+        plug = importlib.reload(plug)
+        assert plug.available
+        spec = plug.depth_gaussian_splatting
+        assert spec.config.method_name == "depth-gaussian-splatting"
+        mc = spec.config.pipeline.model
+        assert (mc.depth_loss_mult, mc.depth_loss_type, mc.uncertainty_weight) == (0.2, "DEPTH_UNCERTAINTY_WEIGHTED_LOSS", 1.0)
+        assert set(spec.config.optimizers) == set(plug.PARAM_GROUP_LRS)
+        assert spec.config.optimizers["xyz"]["scheduler"].lr_final == plug.XYZ_LR_FINAL
+        N, W, H = 3000, 128, 80
+        view = make_view(N, W, H, 3, 5, dev)
+        P, _ = synthetic_gaussians(N, W, H, 3, 99)
+        mc.depth_loss_mult, mc.uncertainty_weight = 0.005, 0.01          # scripts/train_bunny_real.sh:52
+        model = mc.setup(scene_box=None, num_train_data=1, seed_points=(P["means"], torch.rand(N, 3) * 255))
+        groups = model.get_param_groups()
+        assert set(groups) == set(plug.PARAM_GROUP_LRS)
+        assert {k for k, _ in model.named_parameters()} == {f"gauss_params.{k}" for k in groups}
+        # the stub camera is what nerfstudio hands over: OpenGL camera-to-world [1,3,4] + batched intrinsics
+        c2w = torch.linalg.inv(torch.tensor(view.cam.viewmat, dtype=torch.float64).reshape(4, 4))
+        c2w[:3, 1:3] *= -1                                              # OpenCV -> OpenGL axes
+        cams = Cameras(c2w[None, :3, :].float(), view.cam.fx, view.cam.fy, view.cam.cx, view.cam.cy, W, H)
+        opts = {k: torch.optim.Adam(v, lr=spec.config.optimizers[k]["optimizer"].lr * 20, eps=1e-15) for k, v in groups.items()}
+        batch = {"image": view.rgb, "depth_image": view.depth[..., None], "uncertainty": view.uncertainty[..., None]}
+        losses = []
+        for it in range(10):
+            out = model.get_outputs(cams)
+            assert out["rgb"].shape == (H, W, 3) and out["depth"].shape == (H, W, 1) and out["accumulation"].shape == (H, W, 1)
+            loss = sum(model.get_loss_dict(out, batch).values())
+            for o in opts.values():
+                o.zero_grad()
+            loss.backward()
+            for o in opts.values():
+                o.step()
+            losses.append(float(loss))
+        assert losses[-1] < 0.95 * losses[0], losses
+        assert "psnr" in model.get_metrics_dict(model.get_outputs(cams), batch)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+        importlib.reload(plug)
+
+
 @pytest.mark.parametrize("deg,interval", [(3, 0), (1, 0), (3, 3)])
 def test_color_prefetch_is_bit_identical(dev, deg, interval):
     """Colour prefetch (tgs_project_bwd_adam_next -> tgs_project_bin_sort_colors): the optimizer
