@@ -498,11 +498,12 @@ def test_degenerate_sizes(dev):
         assert np.abs(rgb.detach().cpu().numpy() - o["rgb"].numpy()).max() < 1e-5
 
 
-@pytest.mark.parametrize("W,H", [(208, 144), (70, 50), (16, 16)])
+@pytest.mark.parametrize("W,H", [(208, 144), (70, 50), (16, 16), (1920, 1080), (3840, 2160)])
 def test_tile_order_schedule(dev, W, H):
-    """tgs_bin_sort's tile_order: block b (XCD b % 8) gets a tile of band b % 8, every band is visited
-    longest list first (ties by tile id), every tile appears exactly once, padding entries are T; the
-    compositing kernels give bit-identical results with and without the schedule."""
+    """tgs_bin_sort's tile_order: block b (XCD b % 8) gets a tile of every 8th 16-tile granule, every chunk
+    of <= 1024 slots of an XCD is visited longest list first (ties by tile id; 3840x2160 has four chunks per
+    XCD), every tile appears exactly once, padding entries are T; the compositing kernels give
+    bit-identical results with and without the schedule."""
     from touch_gs_amd import ops
     P, cam = scene(3000, W, H, 2, 23)
     acam = amd_cam(cam)
@@ -510,17 +511,27 @@ def test_tile_order_schedule(dev, W, H):
     splats = ops.project_fwd(acam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], 2)
     gb, ts, sg, st = ops.bin_sort(acam, splats)
     T = acam.num_tiles
+    TW, TH = acam.tiles
     order = ts.tile_order.cpu().numpy()
     n = np.diff(ts.cpu().numpy())
-    per = (T + 7) // 8
+    G = 16                                       # granule: XCD x owns the tiles t with (t // 16) % 8 == x
+    per = -(-(-(-T // G)) // 8) * G              # slots per XCD
     assert order.shape[0] == per * 8
     assert sorted(order[order < T].tolist()) == list(range(T)) and int((order == T).sum()) == per * 8 - T
+    n_sub = -(-per // 1024)
+    chunk = -(-per // n_sub)
     for x in range(8):
-        band = order[x::8]
-        band = band[band < T]
-        assert np.all((band >= x * per) & (band < (x + 1) * per))
-        keys = [(-int(n[t]), int(t)) for t in band]
-        assert keys == sorted(keys)
+        mine = order[x::8]
+        assert np.all((mine[mine < T] // G) % 8 == x)
+        for c in range(n_sub):                   # every chunk of <= 1024 slots: its own tiles, longest list first
+            got = mine[c * chunk:(c + 1) * chunk]
+            slots = np.arange(c * chunk, min((c + 1) * chunk, per))
+            want = ((slots // G) * 8 + x) * G + slots % G
+            want = want[want < T]
+            got = got[got < T]
+            assert sorted(got.tolist()) == sorted(want.tolist())
+            keys = [(-int(n[t]), int(t)) for t in got]
+            assert keys == sorted(keys)
     out_a = ops.rasterize_fwd(acam, splats, sg, ts)
     bwd_a = ops.rasterize_bwd(acam, splats, gb, sg, ts, out_a[0], out_a[1], out_a[2],
                               v_rgb=torch.ones_like(out_a[0]), v_depth=torch.ones_like(out_a[1]))[0]

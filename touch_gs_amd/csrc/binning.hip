@@ -69,36 +69,13 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int T, int NB, int32_t* __r
                                                      int32_t* __restrict__ tile_order) {
   __shared__ int wave_tot[16];
   __shared__ int s_base;
-  __shared__ unsigned long long okeys[8192];   // one XCD band: <= ceil(255*255/8) = 8129 tiles
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= NB) {
+    // K6 / K7 schedule when no sort launch follows (no Gaussians: every list is empty): the XCD's
+    // slots in spatial order
     const int x = blockIdx.x - NB;
-    const int per = (T + 7) >> 3;
-    const int t0 = x * per, len = max(0, min(per, T - t0));
-    int np2 = 2;
-    while (np2 < per) np2 <<= 1;
-    // ascending on (~n, tile) = descending list length, ties by tile id; pads sort to the end
-    for (int i = tid; i < np2; i += 1024) {
-      unsigned n = 0;
-      if (i < len)
-        for (int c = 0; c < TGS_XCC; c++) n += (unsigned)tile_count[c * T + t0 + i];
-      okeys[i] = i < len ? ((unsigned long long)(~n) << 32) | (unsigned)(t0 + i) : ~0ull;
-    }
-    __syncthreads();
-    for (int k = 2; k <= np2; k <<= 1) {
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int i = tid; i < (np2 >> 1); i += 1024) {
-          const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
-          const int hi = lo | j;
-          const bool up = (lo & k) == 0;
-          const unsigned long long a = okeys[lo], b = okeys[hi];
-          if ((a > b) == up) { okeys[lo] = b; okeys[hi] = a; }
-        }
-        __syncthreads();
-      }
-    }
-    for (int i = tid; i < per; i += 1024)
-      tile_order[i * 8 + x] = i < len ? (int)(okeys[i] & 0xffffffffull) : T;   // T = no tile
+    const int per = tgs_xcd_slots(T);
+    for (int i = tid; i < per; i += 1024) tile_order[i * TGS_XCDS + x] = tgs_xcd_slot_tile(T, x, i);
     return;
   }
   const bool overflow = status[1] != 0;
@@ -341,34 +318,39 @@ __device__ __forceinline__ void sort_tile_regs(const u64* __restrict__ pairs, in
   }
 }
 
-// Visiting order of the compositing kernels for XCD band x (<= 1024 tiles): tiles by descending list
-// length, ties by tile id -- the same register sort on (~length, tile) keys.
-__device__ __forceinline__ void band_order_regs(int T, int x, const int32_t* __restrict__ tile_start,
-                                                int32_t* __restrict__ tile_order, int lane) {
-  const int per = (T + 7) >> 3;
-  const int t0 = x * per, len = max(0, min(per, T - t0));
+// Visiting order of the compositing kernels for XCD x (tgs_common.h: every 8th granule of 16 tiles): its
+// slots are cut into chunks of <= 1024 consecutive slots and every chunk is put in descending
+// list-length order, ties by tile id, by one wave -- the same register sort on (~length, tile) keys.
+// The XCD therefore visits chunk 0 longest first, then chunk 1, ...: the tail of the launch is made
+// of the last chunk's shortest lists.
+__device__ __forceinline__ void xcd_order_regs(int T, int x, int c, int chunk,
+                                               const int32_t* __restrict__ tile_start,
+                                               int32_t* __restrict__ tile_order, int lane) {
+  const int per = tgs_xcd_slots(T);
+  const int i0 = c * chunk, len = max(0, min(chunk, per - i0));
   u64 k[16];
 #pragma unroll
   for (int r = 0; r < 16; r++) {
     const int i = r * TGS_WAVE + lane;
-    k[r] = i < len ? ((u64)(~(unsigned)(tile_start[t0 + i + 1] - tile_start[t0 + i])) << 32) | (unsigned)(t0 + i) : ~0ull;
+    const int tile = i < len ? tgs_xcd_slot_tile(T, x, i0 + i) : T;
+    k[r] = tile < T ? ((u64)(~(unsigned)(tile_start[tile + 1] - tile_start[tile])) << 32) | (unsigned)tile : ~0ull;
   }
   sort_regs<16, 1>(k, lane, nullptr);
 #pragma unroll
   for (int r = 0; r < 16; r++) {
-    const int i = lane * 16 + r;
-    if (i < per) tile_order[i * 8 + x] = i < len ? (int)(k[r] & 0xffffffffull) : T;   // T = no tile
+    const int e = lane * 16 + r;
+    if (e < len) tile_order[(i0 + e) * TGS_XCDS + x] = k[r] != ~0ull ? (int)(k[r] & 0xffffffffull) : T;   // T = no tile
   }
 }
 
 // common classes: lists <= 512 (8 keys per lane) and <= 1024 (16 keys per lane); one wave per tile
 __global__ __launch_bounds__(TGS_WAVE) void k_sort_tiles_wave(
     int T, const int32_t* __restrict__ tile_start, const u64* __restrict__ pairs,
-    int32_t* __restrict__ sorted_gid, int32_t* __restrict__ tile_order, int n_order) {
-  // the first n_order (0 or 8) blocks build the K6 / K7 schedule of one XCD band (<= 1024 tiles) each;
-  // they are the longest blocks of the launch, so they are dispatched first
+    int32_t* __restrict__ sorted_gid, int32_t* __restrict__ tile_order, int n_order, int chunk) {
+  // the first n_order (0 or 8 x chunks per XCD) blocks build the K6 / K7 schedule of one chunk of one
+  // XCD's slots each; they are the longest blocks of the launch, so they are dispatched first
   if ((int)blockIdx.x < n_order) {
-    band_order_regs(T, blockIdx.x, tile_start, tile_order, threadIdx.x);
+    xcd_order_regs(T, blockIdx.x % TGS_XCDS, blockIdx.x / TGS_XCDS, chunk, tile_start, tile_order, threadIdx.x);
     return;
   }
   const int tile = blockIdx.x - n_order;
@@ -451,7 +433,9 @@ extern "C" int tgs_num_groups(int N) { return (N + TGS_GROUP - 1) / TGS_GROUP; }
 extern "C" int tgs_num_tiles(int W, int H) {
   return ((W + TGS_BLOCK - 1) / TGS_BLOCK) * ((H + TGS_BLOCK - 1) / TGS_BLOCK);
 }
-extern "C" int tgs_tile_order_len(int W, int H) { return ((tgs_num_tiles(W, H) + 7) / 8) * 8; }
+extern "C" int tgs_tile_order_len(int W, int H) {
+  return TGS_XCDS * tgs_xcd_slots(tgs_num_tiles(W, H));
+}
 extern "C" int tgs_tile_counter_len(int W, int H) { return tgs_counter_len(tgs_num_tiles(W, H)); }
 // scratch layout: pairs u64[cap] | fallback u64[2*cap] | rank i32[cap]
 extern "C" size_t tgs_sort_scratch_bytes(int64_t capacity) {
@@ -467,9 +451,13 @@ int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* gro
   const int G = tgs_num_groups(N);
   const BinScratch sc = carve_scratch(scratch, capacity);
   const int NB = (T + 1023) / 1024;   // <= 64 (image sides are limited to 255 tiles)
-  // K6 / K7 schedule: bands of <= 1024 tiles are ordered by 8 extra blocks of the wave-sort launch
-  // (register sort); larger images (and N = 0, which launches no sort) by 8 workgroups of the scan
-  const bool order_in_sort = tile_order && G > 0 && ((T + 7) >> 3) <= 1024;
+  // K6 / K7 schedule: ordered by extra blocks of the wave-sort launch (one per chunk of <= 1024 slots
+  // of every XCD); without Gaussians no sort is launched and 8 workgroups of the scan write the
+  // spatial order
+  const bool order_in_sort = tile_order && G > 0;
+  const int per = tgs_xcd_slots(T);
+  const int n_sub = (per + 1023) / 1024, chunk = (per + n_sub - 1) / n_sub;
+  const int n_order = order_in_sort ? TGS_XCDS * n_sub : 0;
   hipLaunchKernelGGL(k_scan_tiles, dim3(NB + ((tile_order && !order_in_sort) ? 8 : 0)), dim3(1024), 0, s, T, NB,
                      tile_cursor, tile_start, status, tile_order);
   TGS_CHECK_LAUNCH();
@@ -478,8 +466,8 @@ int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* gro
                        tile_cursor + TGS_XCC * T, sc.rank, (uint2*)sc.pairs, status);
     TGS_CHECK_LAUNCH();
     const int32_t* max_list = tile_cursor + 2 * TGS_XCC * T + TGS_SCAN_WGS;
-    hipLaunchKernelGGL(k_sort_tiles_wave, dim3(T + (order_in_sort ? 8 : 0)), dim3(TGS_WAVE), 0, s, T, tile_start,
-                       sc.pairs, sorted_gid, tile_order, order_in_sort ? 8 : 0);
+    hipLaunchKernelGGL(k_sort_tiles_wave, dim3(T + n_order), dim3(TGS_WAVE), 0, s, T, tile_start,
+                       sc.pairs, sorted_gid, tile_order, n_order, chunk);
     TGS_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_sort_tiles_wg4, dim3(T < 2048 ? T : 2048), dim3(TGS_WAVE * 4), 0, s, T, tile_start,
                        sc.pairs, sorted_gid, max_list);

@@ -39,9 +39,8 @@ constexpr float T_STOP = 1e-4f;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LOG2_255 = 7.994353436858858f;   // alpha >= 1/255  <=>  s <= log2(255)
 
-__device__ __forceinline__ int xcd_tile(int b, int T) {
-  const int q = (T + 7) >> 3;          // tiles per XCD band
-  return (b & 7) * q + (b >> 3);       // may be >= T (padded grid)
+__device__ __forceinline__ int xcd_tile(int b, int T) {   // schedule without a tile_order
+  return tgs_xcd_slot_tile(T, b & 7, b >> 3);
 }
 
 // v[l] + v[l ^ 16] and v[l] + v[l ^ 32] with the gfx950 lane-swap instructions (3 VALU each: a
@@ -497,7 +496,7 @@ extern "C" int tgs_rasterize_fwd(const TgsCamera* cam, const float* splats,
                 "null pointer");
   const CamK k = make_camk(cam);
   const int T = k.TW * k.TH;
-  const int grid = ((T + 7) / 8) * 8;
+  const int grid = TGS_XCDS * tgs_xcd_slots(T);
   if (final_idx)
     hipLaunchKernelGGL(k_raster_fwd<true>, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T,
                        splats, sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx, tile_order);
@@ -532,7 +531,7 @@ extern "C" int tgs_rasterize_bwd(const TgsCamera* cam, const float* splats,
   }
   const CamK k = make_camk(cam);
   const int T = k.TW * k.TH;
-  const int grid = ((T + 7) / 8) * 8;
+  const int grid = TGS_XCDS * tgs_xcd_slots(T);
   hipLaunchKernelGGL(k_raster_bwd, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T, splats,
                      group_base, sorted_gid, tile_start, out_rgb, out_depth, final_T,
                      v_rgb, v_depth, v_alpha, lk, partials, tile_loss, tile_order);

@@ -7,6 +7,26 @@
 
 #define TGS_WAVE 64
 
+// K6 / K7 schedule: block b of the launch runs on XCD b % 8 (observed dispatch order).  The tiles (row
+// major) are dealt to the XCDs in granules of TGS_XCD_GRANULE consecutive tiles: granule q belongs to
+// XCD q % 8.  Slot i of XCD x (i = b / 8) is tile ((i / G) * 8 + x) * G + i % G; slots past the last
+// tile hold none.  Fine interleaving balances the XCDs for any view -- one contiguous image band per
+// XCD left the XCDs of the emptier bands idle (K7 -12 %, K6 -12 % averaged over the 8 orbit views of
+// cfg3, tools/order_probe.py) -- and 16-tile granules keep the horizontal neighbours (which share
+// most of their Gaussians) in one L2; whole tile rows per XCD (68 rows over 8 XCDs: 9 against 8)
+// were 6 % off balance.
+#define TGS_XCDS 8
+#define TGS_XCD_GRANULE 16
+static inline __host__ __device__ int tgs_xcd_slots(int T) {
+  const int q = (T + TGS_XCD_GRANULE - 1) / TGS_XCD_GRANULE;
+  return ((q + TGS_XCDS - 1) / TGS_XCDS) * TGS_XCD_GRANULE;
+}
+static inline __host__ __device__ int tgs_xcd_slot_tile(int T, int x, int i) {
+  const int k = i / TGS_XCD_GRANULE;
+  const int tile = (k * TGS_XCDS + x) * TGS_XCD_GRANULE + (i - k * TGS_XCD_GRANULE);
+  return tile < T ? tile : T;      // T = no tile
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------

@@ -127,7 +127,7 @@ def bin_sort(cam: Camera, splats, budget: Optional[IntersectBudget] = None):
     tile_cursor, status = counters[:nc], counters[nc:]
     # block -> tile schedule of K6 / K7 (longest list first inside each XCD's band); it rides on the
     # tile_start tensor object so that the (tile_start, sorted_gid) pair keeps its meaning for callers
-    tile_order = torch.empty((T + 7) // 8 * 8, dtype=torch.int32, device=dev)
+    tile_order = torch.empty(lib.tgs_tile_order_len(cam.W, cam.H), dtype=torch.int32, device=dev)
     tile_start.tile_order = tile_order
     cap = budget.initial(N)
     while True:
@@ -192,7 +192,7 @@ def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_d
     tile_cursor, status = counters[:nc], counters[nc:]
     # block -> tile schedule of K6 / K7 (longest list first inside each XCD's band); it rides on the
     # tile_start tensor object so that the (tile_start, sorted_gid) pair keeps its meaning for callers
-    tile_order = torch.empty((T + 7) // 8 * 8, dtype=torch.int32, device=dev)
+    tile_order = torch.empty(lib.tgs_tile_order_len(cam.W, cam.H), dtype=torch.int32, device=dev)
     tile_start.tile_order = tile_order
     sh_stride = sh.shape[1] if sh is not None else 0
     cap = budget.initial(N)
