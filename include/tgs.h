@@ -86,7 +86,7 @@ const char* tgs_last_error(void);
 /* Number of binning groups / tiles for sizing the caller's buffers. */
 int tgs_num_groups(int N);                 /* ceil(N/TGS_GROUP) */
 int tgs_num_tiles(int W, int H);           /* ceil(W/16)*ceil(H/16) */
-int tgs_tile_order_len(int W, int H);      /* 8 * 16 * ceil(ceil(tiles / 16) / 8) (one entry per K6/K7 block) */
+int tgs_tile_order_len(int W, int H);      /* 8 * 8 * ceil(ceil(tiles / 8) / 8) (one entry per K6/K7 block) */
 int tgs_tile_counter_len(int W, int H);    /* int32 entries of the tile_cursor scratch: per-XCD counter rows + sub-list starts */
 /* Bytes of scratch tgs_bin_sort needs for a given intersection capacity. */
 size_t tgs_sort_scratch_bytes(int64_t capacity);
@@ -121,7 +121,7 @@ int tgs_sh_bwd(int N, int sh_deg, int sh_stride, const float* dirs, const float*
  *      tile_start[T+1]  [start,end) of every tile's list; tile_start[T] = #intersections
  *      sorted_gid[cap]  Gaussian ids, per tile, front to back, ties by id
  *      tile_order[L]    (may be NULL; L = tgs_tile_order_len) tile visited by block b of K6 / K7:
- *                       block b runs on XCD b % 8; XCD x owns every 8th granule of 16 consecutive
+ *                       block b runs on XCD b % 8; XCD x owns every 8th granule of 8 consecutive
  *                       tiles (balanced for any view) and visits its tiles longest list first inside
  *                       chunks of <= 1024; entry [i * 8 + x] = i-th visit of XCD x, T = "no tile"
  *      status[2]        {#intersections, overflow flag}; if #intersections > capacity nothing

@@ -500,7 +500,7 @@ def test_degenerate_sizes(dev):
 
 @pytest.mark.parametrize("W,H", [(208, 144), (70, 50), (16, 16), (1920, 1080), (3840, 2160)])
 def test_tile_order_schedule(dev, W, H):
-    """tgs_bin_sort's tile_order: block b (XCD b % 8) gets a tile of every 8th 16-tile granule, every chunk
+    """tgs_bin_sort's tile_order: block b (XCD b % 8) gets a tile of every 8th 8-tile granule, every chunk
     of <= 1024 slots of an XCD is visited longest list first (ties by tile id; 3840x2160 has four chunks per
     XCD), every tile appears exactly once, padding entries are T; the compositing kernels give
     bit-identical results with and without the schedule."""
@@ -514,7 +514,7 @@ def test_tile_order_schedule(dev, W, H):
     TW, TH = acam.tiles
     order = ts.tile_order.cpu().numpy()
     n = np.diff(ts.cpu().numpy())
-    G = 16                                       # granule: XCD x owns the tiles t with (t // 16) % 8 == x
+    G = 8                                        # granule: XCD x owns the tiles t with (t // 8) % 8 == x
     per = -(-(-(-T // G)) // 8) * G              # slots per XCD
     assert order.shape[0] == per * 8
     assert sorted(order[order < T].tolist()) == list(range(T)) and int((order == T).sum()) == per * 8 - T

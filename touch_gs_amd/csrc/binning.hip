@@ -318,7 +318,7 @@ __device__ __forceinline__ void sort_tile_regs(const u64* __restrict__ pairs, in
   }
 }
 
-// Visiting order of the compositing kernels for XCD x (tgs_common.h: every 8th granule of 16 tiles): its
+// Visiting order of the compositing kernels for XCD x (tgs_common.h: every 8th granule of 8 tiles): its
 // slots are cut into chunks of <= 1024 consecutive slots and every chunk is put in descending
 // list-length order, ties by tile id, by one wave -- the same register sort on (~length, tile) keys.
 // The XCD therefore visits chunk 0 longest first, then chunk 1, ...: the tail of the launch is made

@@ -12,11 +12,13 @@
 // XCD q % 8.  Slot i of XCD x (i = b / 8) is tile ((i / G) * 8 + x) * G + i % G; slots past the last
 // tile hold none.  Fine interleaving balances the XCDs for any view -- one contiguous image band per
 // XCD left the XCDs of the emptier bands idle (K7 -12 %, K6 -12 % averaged over the 8 orbit views of
-// cfg3, tools/order_probe.py) -- and 16-tile granules keep the horizontal neighbours (which share
-// most of their Gaussians) in one L2; whole tile rows per XCD (68 rows over 8 XCDs: 9 against 8)
-// were 6 % off balance.
+// cfg3, tools/order_probe.py) -- and granules keep horizontal neighbours (which share most of their
+// Gaussians) in one L2; whole tile rows per XCD (68 rows over 8 XCDs: 9 against 8) were 6 % off
+// balance.  Granule sweep at cfg3 (same box, ms per step): 4: 1.066, 8: 1.061, 16: 1.074, 32: 1.075, 64: 1.075.
 #define TGS_XCDS 8
-#define TGS_XCD_GRANULE 16
+#ifndef TGS_XCD_GRANULE
+#define TGS_XCD_GRANULE 8
+#endif
 static inline __host__ __device__ int tgs_xcd_slots(int T) {
   const int q = (T + TGS_XCD_GRANULE - 1) / TGS_XCD_GRANULE;
   return ((q + TGS_XCDS - 1) / TGS_XCDS) * TGS_XCD_GRANULE;
