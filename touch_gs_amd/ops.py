@@ -125,7 +125,7 @@ def bin_sort(cam: Camera, splats, budget: Optional[IntersectBudget] = None):
     nc = lib.tgs_tile_counter_len(cam.W, cam.H)
     counters = torch.empty(nc + 2, dtype=torch.int32, device=dev)   # per-XCD tile counters + sub-list starts | status
     tile_cursor, status = counters[:nc], counters[nc:]
-    # block -> tile schedule of K6 / K7 (longest list first inside each XCD's band); it rides on the
+    # block -> tile schedule of K6 / K7 (tiles dealt to the XCDs in granules of 8, longest list first inside each XCD); it rides on the
     # tile_start tensor object so that the (tile_start, sorted_gid) pair keeps its meaning for callers
     tile_order = torch.empty(lib.tgs_tile_order_len(cam.W, cam.H), dtype=torch.int32, device=dev)
     tile_start.tile_order = tile_order
@@ -190,7 +190,7 @@ def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_d
     nc = lib.tgs_tile_counter_len(cam.W, cam.H)
     counters = torch.empty(nc + 2, dtype=torch.int32, device=dev)   # per-XCD tile counters + sub-list starts | status
     tile_cursor, status = counters[:nc], counters[nc:]
-    # block -> tile schedule of K6 / K7 (longest list first inside each XCD's band); it rides on the
+    # block -> tile schedule of K6 / K7 (tiles dealt to the XCDs in granules of 8, longest list first inside each XCD); it rides on the
     # tile_start tensor object so that the (tile_start, sorted_gid) pair keeps its meaning for callers
     tile_order = torch.empty(lib.tgs_tile_order_len(cam.W, cam.H), dtype=torch.int32, device=dev)
     tile_start.tile_order = tile_order
