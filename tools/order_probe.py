@@ -1,5 +1,6 @@
-"""Developer probe: K6 / K7 time with the library's tile schedule (XCD x = horizontal image band x)
-against a schedule that interleaves tile rows over the XCDs (row r -> XCD r % 8), per view."""
+"""Developer probe: K6 / K7 time with the library's tile schedule against a hand-made one (here: 2-D
+granules of BW x BH tiles dealt to the XCDs), per orbit view.  The first version of this probe compared
+round 2a's schedule (one horizontal image band per XCD) with row interleaving and led to section 5.5."""
 import sys, torch
 sys.path.insert(0, '.')
 from touch_gs_amd import ops
@@ -13,15 +14,16 @@ params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAME
 model = DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=0), params)
 model.spatial_sort()
 p = model.params
-S = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+BW, BH = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (4, 2)   # 2-D granule (tiles)
 
 def interleaved(ts, TW, TH):
+    """XCD x owns the BW x BH tile blocks q (row major over the blocks) with q % 8 == x, longest list first."""
     T = TW * TH
     n = (ts[1:] - ts[:-1]).long()
     tile = torch.arange(T, device=dev)
-    x = ((tile // TW) // S) % 8
-    per = (T + 7) // 8
-    # longest first inside each XCD; surplus tiles of an XCD (rows do not divide evenly) go to the emptiest
+    q = ((tile // TW) // BH) * ((TW + BW - 1) // BW) + (tile % TW) // BW
+    x = q % 8
+    per = ts.tile_order.numel() // 8
     key = x * (1 << 40) + ((1 << 20) - n) * (1 << 20) + tile
     srt = tile[torch.argsort(key)]
     xs = x[srt]
@@ -55,9 +57,12 @@ for vi in range(8):
     k6 = lambda: ops.rasterize_fwd(view.cam, sp, sg, ts)
     k7 = lambda: ops.rasterize_bwd(view.cam, sp, gb, sg, ts, rgb, dacc, fT, v_rgb=v_img, loss=model.loss_spec(view), want_tile_loss=True)
     lib_order = ts.tile_order
-    a6, a7 = timed(k6), timed(k7)
-    ts.tile_order = interleaved(ts, *view.cam.tiles)
-    assert sorted(ts.tile_order[ts.tile_order < view.cam.num_tiles].tolist()) == list(range(view.cam.num_tiles))
+    mine = interleaved(ts, *view.cam.tiles)
+    assert sorted(mine[mine < view.cam.num_tiles].tolist()) == list(range(view.cam.num_tiles))
+    same = bool(torch.equal(mine, lib_order))
+    timed(k6, 4); timed(k7, 4)                      # warm-up
+    ts.tile_order = mine
     b6, b7 = timed(k6), timed(k7)
     ts.tile_order = lib_order
-    print(f"view {vi}: pairs {int(ts[-1])}  K6 {a6:.0f} -> {b6:.0f} us   K7 {a7:.0f} -> {b7:.0f} us", flush=True)
+    a6, a7 = timed(k6), timed(k7)                   # the library's schedule is timed SECOND
+    print(f"view {vi}: pairs {int(ts[-1])}  K6 {a6:.0f} -> {b6:.0f} us   K7 {a7:.0f} -> {b7:.0f} us   identical tables: {same}", flush=True)
