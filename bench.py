@@ -166,6 +166,8 @@ def main():
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ssim-pipeline", action="store_true",
+                    help="SSIM on a second stream pipelined by image bands behind K7 (measured slower; off by default)")
     ap.add_argument("--no-color-prefetch", action="store_true",
                     help="K1 always evaluates the SH rows itself (off: the previous step's optimizer kernel does)")
     ap.add_argument("--layout", choices=("morton", "asis"), default="morton",
@@ -201,7 +203,8 @@ def main():
     P, intr = synthetic_gaussians(N, W, H, deg, args.seed, clustered=clustered)
     params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
     cfg = ModelConfig(sh_degree=deg, sh_degree_interval=0, depth_loss_mult=0.2,
-                      depth_loss_type="DEPTH_UNCERTAINTY_WEIGHTED_LOSS", uncertainty_weight=1.0)
+                      depth_loss_type="DEPTH_UNCERTAINTY_WEIGHTED_LOSS", uncertainty_weight=1.0,
+                      pipeline_ssim=args.ssim_pipeline)
     model = DepthGaussianSplattingModel(cfg, params)
     views = [make_view(N, W, H, deg, args.seed, dev, view=v, n_views=args.views, clustered=clustered)
              for v in range(args.views)]

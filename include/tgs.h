@@ -86,6 +86,8 @@ const char* tgs_last_error(void);
 /* Number of binning groups / tiles for sizing the caller's buffers. */
 int tgs_num_groups(int N);                 /* ceil(N/TGS_GROUP) */
 int tgs_num_tiles(int W, int H);           /* ceil(W/16)*ceil(H/16) */
+int tgs_num_bands(int W, int H);           /* image bands of tgs_rasterize_bwd_band */
+int tgs_band_tiles(int W, int H, int band, int* tile0, int* tile1);   /* row-major tile range of a band */
 int tgs_tile_order_len(int W, int H);      /* 8 * 8 * ceil(ceil(tiles / 8) / 8) (one entry per K6/K7 block) */
 int tgs_tile_counter_len(int W, int H);    /* int32 entries of the tile_cursor scratch: per-XCD counter rows + sub-list starts */
 /* Bytes of scratch tgs_bin_sort needs for a given intersection capacity. */
@@ -198,6 +200,19 @@ int tgs_rasterize_bwd(const TgsCamera* cam /*[host]*/, const float* splats,
                       const TgsLossSpec* loss /*[host]*/, float* partials, float* tile_loss,
                       void* stream);
 
+/* K7 for ONE image band: the tiles [tile0, tile1) of tgs_band_tiles(W, H, band, ...) (a contiguous row-major
+ *     range; tgs_num_bands(W, H) >= 4 bands cover the image).  Needs the tile_order of tgs_bin_sort.  The
+ *     bands together write exactly what tgs_rasterize_bwd writes; a band only reads the v_rgb / v_depth /
+ *     v_alpha rows of its own tiles, so the image gradient may be produced band by band on another stream
+ *     while earlier bands composite (DepthGaussianSplattingModel: SSIM pipelined behind K7). */
+int tgs_rasterize_bwd_band(const TgsCamera* cam /*[host]*/, const float* splats,
+                      const int32_t* group_base, const int32_t* sorted_gid,
+                      const int32_t* tile_start, const int32_t* tile_order /*may be NULL*/,
+                      const float* out_rgb, const float* out_depth, const float* final_T,
+                      const float* v_rgb, const float* v_depth, const float* v_alpha,
+                      const TgsLossSpec* loss /*[host]*/, float* partials, float* tile_loss,
+                      int band, void* stream);
+
 /* K8a segmented reduction of the partials to one gradient record per Gaussian
  *     out: v_splats[N,12] = {v_x, v_y, v_depth, v_opacity, v_a, v_b, v_c, v_r, v_g, v_b, 0, 0}. */
 int tgs_reduce_partials(int N, const float* splats, const int32_t* group_base,
@@ -296,6 +311,14 @@ int tgs_adam_step(int N, int sh_stride, float* params, const float* grads, float
  * tmp: scratch[9*H*W] floats (needed when v_img != NULL). */
 int tgs_ssim_fwd_bwd(int W, int H, const float* img, const float* gt, float weight,
                      float* block_partials, float* v_img, float* scratch, void* stream);
+/* The same for the image rows [y0, y1) only (one band of a pipelined step, see tgs_rasterize_bwd_band):
+ *     v_img rows [y0, y1) are written; the SSIM map is summed over rows [count_y0, count_y1) (inside
+ *     [y0, y1); the bands of an image partition its rows) into block_partials[n_partials] (first entries =
+ *     workgroup sums, the rest zero); scratch rows [y0-5, y1+5) are overwritten.  Values are bit-identical to
+ *     the whole-image call. */
+int tgs_ssim_fwd_bwd_rows(int W, int H, const float* img, const float* gt, float weight,
+                          float* block_partials, int n_partials, float* v_img, float* scratch,
+                          int y0, int y1, int count_y0, int count_y1, void* stream);
 
 #ifdef __cplusplus
 }

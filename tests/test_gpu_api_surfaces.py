@@ -695,6 +695,61 @@ def test_nerfstudio_adapter_core_trains(dev):
     assert "psnr" in m and "depth_mse" in m
 
 
+@pytest.mark.parametrize("W,H", [(160, 96), (208, 144), (1920, 1080)])
+def test_pipelined_ssim_and_k7_bands_equal_the_sequential_step(dev, W, H):
+    """SSIM pipelined by image bands behind K7 on a second stream (ModelConfig.pipeline_ssim;
+    tgs_ssim_fwd_bwd_rows + tgs_rasterize_bwd_band): the bands partition the tiles, the band-wise SSIM
+    gradient equals the whole-image one bit for bit, and three train steps leave the same parameters and
+    Adam moments as the sequential form (whole-image SSIM, then one K7 launch)."""
+    from touch_gs_amd import ops
+    from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
+    from touch_gs_amd.optim import GaussianParams
+    from touch_gs_amd.scene import make_view, synthetic_gaussians
+    N = 4100 if W < 1000 else 60000
+    views = [make_view(N, W, H, 3, 7, dev, view=v, n_views=4) for v in range(2)]
+    P, _ = synthetic_gaussians(N, W, H, 3, 99)
+    cam = views[0].cam
+    # -- the band structure
+    bands = ops.band_rows(cam)
+    TW, TH = cam.tiles
+    assert 1 <= len(bands) <= max(4, -(-TW * TH // 8192))
+    assert bands[0][3] == 0 and bands[-1][4] == H and all(a[4] == b[3] for a, b in zip(bands, bands[1:]))
+    assert all(y0 <= c0 <= c1 <= y1 for _, y0, y1, c0, c1 in bands)
+    # -- band-wise SSIM == whole-image SSIM
+    g = torch.Generator().manual_seed(1)
+    img = torch.rand(H, W, 3, generator=g).to(dev)
+    wgt = -0.2 / (3 * H * W)
+    tot, v_full = ops.ssim_fwd_bwd(img, views[0].rgb, weight=wgt, reduce=False)
+    lib = ops._lib.load()
+    v_band = torch.full_like(v_full, float("nan"))
+    scratch = torch.empty(9 * H * W, device=dev)
+    n_p = ((W + 63) // 64) * (H // 12 + 2)
+    sums = []
+    for b, y0, y1, c0, c1 in bands:
+        bp = torch.empty(n_p, device=dev)
+        ops.check(lib.tgs_ssim_fwd_bwd_rows(W, H, ops.ptr(img), ops.ptr(views[0].rgb), ops.C.c_float(wgt), ops.ptr(bp), n_p,
+                                            ops.ptr(v_band), ops.ptr(scratch), y0, y1, c0, c1, ops._stream()), "rows")
+        sums.append(bp.double().sum())
+    assert torch.equal(v_band, v_full)
+    assert abs(float(sum(sums)) - float(tot.double().sum())) < 1e-6 * abs(float(tot.double().sum()))
+    # -- whole steps
+    def run(pipe):
+        params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
+        m = DepthGaussianSplattingModel(ModelConfig(sh_degree=3, sh_degree_interval=0, pipeline_ssim=pipe,
+                                                    pipeline_ssim_min_tiles=0), params)
+        for i in range(3):
+            m.train_step(views[i % 2])
+        torch.cuda.synchronize()
+        return m
+    a, b = run(True), run(False)
+    assert a._side_stream is not None and getattr(b, "_side_stream", None) is None
+    assert torch.equal(a.params.flat, b.params.flat) and torch.equal(a.optimizer.exp_avg_sq, b.optimizer.exp_avg_sq)
+    assert torch.equal(a.last["tile_loss"], b.last["tile_loss"])
+    la = a.loss_from(a.last["tile_loss"], a.last["ssim_sum"], views[0])
+    lb = b.loss_from(b.last["tile_loss"], b.last["ssim_sum"], views[0])
+    assert abs(float(la["main_loss"]) - float(lb["main_loss"])) < 1e-6 * abs(float(lb["main_loss"]))
+
+
 def _nerfstudio_stub():
     """A stand-in for the parts of the nerfstudio API the plugin shell touches (shape per SURVEY App. A /
     reference legacy/config_tactile.py:23-56, legacy/model_tactile.py:38-56): config containers that keep

@@ -518,8 +518,9 @@ def test_tile_order_schedule(dev, W, H):
     per = -(-(-(-T // G)) // 8) * G              # slots per XCD
     assert order.shape[0] == per * 8
     assert sorted(order[order < T].tolist()) == list(range(T)) and int((order == T).sum()) == per * 8 - T
-    n_sub = -(-per // 1024)
-    chunk = -(-per // n_sub)
+    chunk = -(-(-(-per // -(-per // 1024))) // G) * G   # <= 1024 slots, a multiple of the granule
+    n_sub = -(-per // chunk)
+    assert n_sub == ops._lib.load().tgs_num_bands(W, H)
     for x in range(8):
         mine = order[x::8]
         assert np.all((mine[mine < T] // G) % 8 == x)

@@ -44,6 +44,8 @@ SIGNATURES = {
     "tgs_num_groups": (C.c_int, [_I]),
     "tgs_num_tiles": (C.c_int, [_I, _I]),
     "tgs_tile_order_len": (C.c_int, [_I, _I]),
+    "tgs_num_bands": (C.c_int, [_I, _I]),
+    "tgs_band_tiles": (C.c_int, [_I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tgs_tile_counter_len": (C.c_int, [_I, _I]),
     "tgs_sort_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "tgs_project_fwd": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
@@ -56,6 +58,7 @@ SIGNATURES = {
                                               _P, _P, C.c_int64, _P, _P, _P, _P, _P, C.c_int32, _P]),
     "tgs_rasterize_fwd": (C.c_int, [C.POINTER(TgsCamera), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "tgs_rasterize_bwd": (C.c_int, [C.POINTER(TgsCamera)] + [_P] * 11 + [C.POINTER(TgsLossSpec), _P, _P, _P]),
+    "tgs_rasterize_bwd_band": (C.c_int, [C.POINTER(TgsCamera)] + [_P] * 11 + [C.POINTER(TgsLossSpec), _P, _P, _I, _P]),
     "tgs_reduce_partials": (C.c_int, [_I, _P, _P, C.POINTER(TgsCamera), _P, _P, _P]),
     "tgs_project_bwd": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I] + [_P] * 12),
     "tgs_project_bwd_adam": (C.c_int, [C.POINTER(TgsCamera), _I, _I, _I, _P, _P, _P, C.POINTER(TgsAdamSpec), _P, _P, _P, _P, _P, _P]),
@@ -67,6 +70,7 @@ SIGNATURES = {
     "tgs_store_small": (C.c_int, [_P, C.POINTER(C.c_float), _I, _P]),
     "tgs_adam_step": (C.c_int, [_I, _I, _P, _P, _P, _P, C.POINTER(TgsAdamSpec), C.c_float, C.c_int64, C.c_int64, _P, _P]),
     "tgs_ssim_fwd_bwd": (C.c_int, [_I, _I, _P, _P, C.c_float, _P, _P, _P, _P]),
+    "tgs_ssim_fwd_bwd_rows": (C.c_int, [_I, _I, _P, _P, C.c_float, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
 }
 
 _lib = None

@@ -436,6 +436,15 @@ extern "C" int tgs_num_tiles(int W, int H) {
 extern "C" int tgs_tile_order_len(int W, int H) {
   return TGS_XCDS * tgs_xcd_slots(tgs_num_tiles(W, H));
 }
+extern "C" int tgs_num_bands(int W, int H) { return tgs_band_count(tgs_num_tiles(W, H)); }
+extern "C" int tgs_band_tiles(int W, int H, int band, int* tile0, int* tile1) {
+  const int T = tgs_num_tiles(W, H), c = tgs_band_slots(T);
+  if (band < 0 || band >= tgs_band_count(T)) return TGS_E_ARG;
+  const long long a = (long long)band * c * TGS_XCDS, b = a + (long long)c * TGS_XCDS;
+  if (tile0) *tile0 = (int)(a < T ? a : T);
+  if (tile1) *tile1 = (int)(b < T ? b : T);
+  return TGS_OK;
+}
 extern "C" int tgs_tile_counter_len(int W, int H) { return tgs_counter_len(tgs_num_tiles(W, H)); }
 // scratch layout: pairs u64[cap] | fallback u64[2*cap] | rank i32[cap]
 extern "C" size_t tgs_sort_scratch_bytes(int64_t capacity) {
@@ -456,8 +465,9 @@ int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* gro
   // spatial order
   const bool order_in_sort = tile_order && G > 0;
   const int per = tgs_xcd_slots(T);
-  const int n_sub = (per + 1023) / 1024, chunk = (per + n_sub - 1) / n_sub;
+  const int chunk = tgs_band_slots(T), n_sub = tgs_band_count(T);
   const int n_order = order_in_sort ? TGS_XCDS * n_sub : 0;
+  (void)per;
   hipLaunchKernelGGL(k_scan_tiles, dim3(NB + ((tile_order && !order_in_sort) ? 8 : 0)), dim3(1024), 0, s, T, NB,
                      tile_cursor, tile_start, status, tile_order);
   TGS_CHECK_LAUNCH();

@@ -64,15 +64,18 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                                                   const float* __restrict__ img,
                                                   const float* __restrict__ gt,
                                                   float* __restrict__ adj /*[H,W,3,3] or null*/,
-                                                  float* __restrict__ block_partials, int n_partials, int NBLK) {
+                                                  float* __restrict__ block_partials, int n_partials, int NBLK,
+                                                  int y_lo, int y_hi, int c_lo, int c_hi) {
+  // rows [y_lo, y_hi) of the map / adjoint maps are produced (the whole image, or one band of it plus the
+  // 5-row halo its backward pass needs); rows [c_lo, c_hi) count towards the sum
   const int SEG = seg_rows(NBLK);
   constexpr int ROWF = RowBlock<3>::ROWF;
   __shared__ float sa[RB * ROWF], sb[RB * ROWF];
   __shared__ float red[NTH / TGS_WAVE];
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * SW, ys = blockIdx.y * SEG;
+  const int x0 = blockIdx.x * SW, ys = y_lo + blockIdx.y * SEG;
   const int gx = x0 + tid / 3, c = tid - (tid / 3) * 3;
-  const int ye = min(ys + SEG, H);
+  const int ye = min(ys + SEG, y_hi);
   float w[RB][5];
 #pragma unroll
   for (int p = 0; p < RB; p++)
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         const float id1 = __builtin_amdgcn_rcpf(d1), id2 = __builtin_amdgcn_rcpf(d2);
         const float m = n1 * n2 * id1 * id2;
         if (gx < W) {
-          msum += m;
+          if (gy >= c_lo && gy < c_hi) msum += m;
           if (adj) {
             const float dm_ds12 = 2.f * n1 * id1 * id2;
             const float dm_ds11 = -m * id2;
@@ -149,14 +152,14 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                                                   const float* __restrict__ img,
                                                   const float* __restrict__ gt,
                                                   const float* __restrict__ adj,
-                                                  float* __restrict__ v_img, int NBLK) {
+                                                  float* __restrict__ v_img, int NBLK, int y_lo, int y_hi) {
   const int SEG = seg_rows(NBLK);
   constexpr int ROWF = RowBlock<9>::ROWF;
   __shared__ float sadj[RB * ROWF];
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * SW, ys = blockIdx.y * SEG;
+  const int x0 = blockIdx.x * SW, ys = y_lo + blockIdx.y * SEG;
   const int gx = x0 + tid / 3;
-  const int ye = min(ys + SEG, H);
+  const int ye = min(ys + SEG, y_hi);
   float w[RB][3];
 #pragma unroll
   for (int p = 0; p < RB; p++) { w[p][0] = 0.f; w[p][1] = 0.f; w[p][2] = 0.f; }
@@ -199,33 +202,54 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 
 }  // namespace
 
-extern "C" int tgs_ssim_fwd_bwd(int W, int H, const float* img, const float* gt, float weight,
-                                float* block_partials, float* v_img, float* scratch,
-                                void* stream) {
+static int ssim_impl(int W, int H, const float* img, const float* gt, float weight,
+                     float* block_partials, int n_partials, float* v_img, float* scratch,
+                     int y0, int y1, int c0, int c1, void* stream) {
   TGS_CHECK_ARG(W > 0 && H > 0, "bad image size");
   TGS_CHECK_ARG(img && gt && block_partials, "null pointer");
   TGS_CHECK_ARG(!v_img || scratch, "gradient needs scratch");
+  TGS_CHECK_ARG(0 <= y0 && y0 <= y1 && y1 <= H && y0 <= c0 && c0 <= c1 && c1 <= y1, "bad row range");
   Win win;
   double g[WIN], sum = 0.0;
   for (int i = 0; i < WIN; i++) { g[i] = exp(-(double)((i - HALO) * (i - HALO)) / (2.0 * 1.5 * 1.5)); sum += g[i]; }
   for (int i = 0; i < WIN; i++) win.g[i] = (float)(g[i] / sum);
-  // block_partials has one entry per 16x16 tile (the buffer contract of include/tgs.h); the
-  // streaming kernels write one sum per workgroup (fewer) and zero the rest
-  const int n_partials = ((W + 15) / 16) * ((H + 15) / 16);
+  // forward rows: the gradient rows plus the 5-row halo the backward filter reads (adjoint maps)
+  const int f0 = v_img ? max(0, y0 - HALO) : y0, f1 = v_img ? min(H, y1 + HALO) : y1;
+  const int rows = f1 - f0;
+  if (rows <= 0) return TGS_OK;
+  const int sx = (W + SW - 1) / SW;
   int nblk = 4;
-  while (nblk > 2 && (long long)((W + SW - 1) / SW) * ((H + seg_rows(nblk) - 1) / seg_rows(nblk)) < 3 * 256) nblk--;
+  while (nblk > 2 && (long long)sx * ((rows + seg_rows(nblk) - 1) / seg_rows(nblk)) < 3 * 256) nblk--;
   if (const char* e = getenv("TGS_SSIM_NBLK")) nblk = max(2, min(16, atoi(e)));   // tuning override
-  // block_partials holds one entry per 16x16 tile and one workgroup sum goes into each of the first entries
-  while (nblk < 16 && (long long)((W + SW - 1) / SW) * ((H + seg_rows(nblk) - 1) / seg_rows(nblk)) > n_partials) nblk++;
+  // one workgroup sum goes into each of the first entries of block_partials, the rest is zeroed
+  while (nblk < 16 && (long long)sx * ((rows + seg_rows(nblk) - 1) / seg_rows(nblk)) > n_partials) nblk++;
+  TGS_CHECK_ARG((long long)sx * ((rows + seg_rows(nblk) - 1) / seg_rows(nblk)) <= n_partials, "block_partials too small");
   const int SEG = seg_rows(nblk);
-  const dim3 grid((W + SW - 1) / SW, (H + SEG - 1) / SEG, 1), block(NTH);
+  const dim3 block(NTH);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_ssim_fwd, grid, block, 0, s, W, H, win, img, gt, v_img ? scratch : nullptr,
-                     block_partials, n_partials, nblk);
+  hipLaunchKernelGGL(k_ssim_fwd, dim3(sx, (rows + SEG - 1) / SEG, 1), block, 0, s, W, H, win, img, gt,
+                     v_img ? scratch : nullptr, block_partials, n_partials, nblk, f0, f1, c0, c1);
   TGS_CHECK_LAUNCH();
-  if (v_img) {
-    hipLaunchKernelGGL(k_ssim_bwd, grid, block, 0, s, W, H, win, weight, img, gt, scratch, v_img, nblk);
+  if (v_img && y1 > y0) {
+    hipLaunchKernelGGL(k_ssim_bwd, dim3(sx, (y1 - y0 + SEG - 1) / SEG, 1), block, 0, s, W, H, win, weight, img, gt,
+                       scratch, v_img, nblk, y0, y1);
     TGS_CHECK_LAUNCH();
   }
   return TGS_OK;
+}
+
+extern "C" int tgs_ssim_fwd_bwd(int W, int H, const float* img, const float* gt, float weight,
+                                float* block_partials, float* v_img, float* scratch,
+                                void* stream) {
+  // block_partials has one entry per 16x16 tile (the buffer contract of include/tgs.h)
+  return ssim_impl(W, H, img, gt, weight, block_partials, ((W + 15) / 16) * ((H + 15) / 16), v_img, scratch,
+                   0, H, 0, H, stream);
+}
+
+extern "C" int tgs_ssim_fwd_bwd_rows(int W, int H, const float* img, const float* gt, float weight,
+                                     float* block_partials, int n_partials, float* v_img,
+                                     float* scratch, int y0, int y1, int count_y0, int count_y1,
+                                     void* stream) {
+  return ssim_impl(W, H, img, gt, weight, block_partials, n_partials, v_img, scratch, y0, y1, count_y0,
+                   count_y1, stream);
 }

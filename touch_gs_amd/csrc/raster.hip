@@ -507,14 +507,14 @@ extern "C" int tgs_rasterize_fwd(const TgsCamera* cam, const float* splats,
   return TGS_OK;
 }
 
-extern "C" int tgs_rasterize_bwd(const TgsCamera* cam, const float* splats,
+static int rasterize_bwd_impl(const TgsCamera* cam, const float* splats,
                                  const int32_t* group_base, const int32_t* sorted_gid,
                                  const int32_t* tile_start, const int32_t* tile_order,
                                  const float* out_rgb, const float* out_depth,
                                  const float* final_T, const float* v_rgb,
                                  const float* v_depth, const float* v_alpha,
                                  const TgsLossSpec* loss, float* partials, float* tile_loss,
-                                 void* stream) {
+                                 int band, void* stream) {
   TGS_CHECK_ARG(camera_ok(cam), "bad camera");
   TGS_CHECK_ARG(splats && group_base && sorted_gid && tile_start && out_rgb && out_depth &&
                 final_T && partials, "null pointer");
@@ -531,10 +531,40 @@ extern "C" int tgs_rasterize_bwd(const TgsCamera* cam, const float* splats,
   }
   const CamK k = make_camk(cam);
   const int T = k.TW * k.TH;
-  const int grid = TGS_XCDS * tgs_xcd_slots(T);
+  int grid = TGS_XCDS * tgs_xcd_slots(T);
+  if (band >= 0) {   // one image band: the blocks of chunk `band` of every XCD's slots
+    TGS_CHECK_ARG(tile_order, "a band launch needs the tile_order of tgs_bin_sort");
+    TGS_CHECK_ARG(band < tgs_band_count(T), "band out of range");
+    const int c = tgs_band_slots(T), s0 = band * c, s1 = min(s0 + c, tgs_xcd_slots(T));
+    tile_order += (size_t)s0 * TGS_XCDS;
+    grid = (s1 - s0) * TGS_XCDS;
+  }
   hipLaunchKernelGGL(k_raster_bwd, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T, splats,
                      group_base, sorted_gid, tile_start, out_rgb, out_depth, final_T,
                      v_rgb, v_depth, v_alpha, lk, partials, tile_loss, tile_order);
   TGS_CHECK_LAUNCH();
   return TGS_OK;
+}
+
+extern "C" int tgs_rasterize_bwd(const TgsCamera* cam, const float* splats,
+                                 const int32_t* group_base, const int32_t* sorted_gid,
+                                 const int32_t* tile_start, const int32_t* tile_order,
+                                 const float* out_rgb, const float* out_depth,
+                                 const float* final_T, const float* v_rgb,
+                                 const float* v_depth, const float* v_alpha,
+                                 const TgsLossSpec* loss, float* partials, float* tile_loss,
+                                 void* stream) {
+  return rasterize_bwd_impl(cam, splats, group_base, sorted_gid, tile_start, tile_order, out_rgb, out_depth, final_T, v_rgb, v_depth, v_alpha, loss, partials, tile_loss, -1, stream);
+}
+
+extern "C" int tgs_rasterize_bwd_band(const TgsCamera* cam, const float* splats,
+                                 const int32_t* group_base, const int32_t* sorted_gid,
+                                 const int32_t* tile_start, const int32_t* tile_order,
+                                 const float* out_rgb, const float* out_depth,
+                                 const float* final_T, const float* v_rgb,
+                                 const float* v_depth, const float* v_alpha,
+                                 const TgsLossSpec* loss, float* partials, float* tile_loss,
+                                 int band, void* stream) {
+  TGS_CHECK_ARG(band >= 0, "band < 0");
+  return rasterize_bwd_impl(cam, splats, group_base, sorted_gid, tile_start, tile_order, out_rgb, out_depth, final_T, v_rgb, v_depth, v_alpha, loss, partials, tile_loss, band, stream);
 }

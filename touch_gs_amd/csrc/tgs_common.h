@@ -23,6 +23,23 @@ static inline __host__ __device__ int tgs_xcd_slots(int T) {
   const int q = (T + TGS_XCD_GRANULE - 1) / TGS_XCD_GRANULE;
   return ((q + TGS_XCDS - 1) / TGS_XCDS) * TGS_XCD_GRANULE;
 }
+// An XCD's slots are cut into chunks of <= 1024 slots, a multiple of the granule (one register sort
+// builds a chunk's visiting order, longest list first).  Chunk c of all XCDs together covers the
+// row-major tile range [8 c chunk, 8 (c+1) chunk), an "image band" that tgs_rasterize_bwd_band can
+// launch on its own.  TGS_BANDS = minimum number of chunks: 1 -- finer chunks (4 per XCD at 1080p)
+// cost K6 / K7 6 % (longest-first only inside 256 slots).
+#define TGS_BANDS 1
+static inline __host__ __device__ int tgs_band_slots(int T) {
+  const int per = tgs_xcd_slots(T);
+  int n = (per + 1023) / 1024;
+  if (n < TGS_BANDS) n = TGS_BANDS;
+  const int c = (per + n - 1) / n;
+  return ((c + TGS_XCD_GRANULE - 1) / TGS_XCD_GRANULE) * TGS_XCD_GRANULE;
+}
+static inline __host__ __device__ int tgs_band_count(int T) {
+  const int c = tgs_band_slots(T);
+  return (tgs_xcd_slots(T) + c - 1) / c;
+}
 static inline __host__ __device__ int tgs_xcd_slot_tile(int T, int x, int i) {
   const int k = i / TGS_XCD_GRANULE;
   const int tile = (k * TGS_XCDS + x) * TGS_XCD_GRANULE + (i - k * TGS_XCD_GRANULE);

@@ -36,6 +36,12 @@ class ModelConfig:
     (SURVEY App. A.3)."""
     sh_degree: int = 3
     ssim_lambda: float = 0.2
+    # run SSIM on a second stream, pipelined by image bands behind K7 (ops.rasterize_bwd_ssim_pipelined): same
+    # results.  OFF by default -- measured slower: a band launch of K7 no longer fills the GPU (1080p: four
+    # launches of 2040 one-wave tiles take 4 x 210 us against 450 us for the whole image; 4K: 4.60 against
+    # 4.43 ms per step), although SSIM itself hides almost completely under K7 (DESIGN.md section 8)
+    pipeline_ssim: bool = False
+    pipeline_ssim_min_tiles: int = 0
     depth_loss_mult: float = 0.2          # scripts/train_block_data.sh:50
     depth_loss_type: str = "DEPTH_UNCERTAINTY_WEIGHTED_LOSS"
     uncertainty_weight: float = 1.0
@@ -225,11 +231,19 @@ class DepthGaussianSplattingModel:
         guard = None if self.budget.sync else status   # overflowed frame => optimizer kernels are no-ops
         rgb, depth_acc, fT, fidx = ops.rasterize_fwd(cam, splats, sorted_gid, tile_start)
         v_img, ssim_sum = None, None
-        if c.ssim_lambda > 0:
-            ssim_sum, v_img = ops.ssim_fwd_bwd(rgb, view.rgb, weight=-c.ssim_lambda / (3 * H * W), reduce=False)
-        partials, tile_loss = ops.rasterize_bwd(cam, splats, group_base, sorted_gid, tile_start, rgb,
-                                                depth_acc, fT, v_rgb=v_img,
-                                                loss=self.loss_spec(view), want_tile_loss=True)
+        if (c.ssim_lambda > 0 and c.pipeline_ssim and cam.num_tiles >= c.pipeline_ssim_min_tiles
+                and not torch.cuda.is_current_stream_capturing()):
+            if getattr(self, "_side_stream", None) is None:
+                self._side_stream = torch.cuda.Stream(device=rgb.device)
+            partials, tile_loss, ssim_sum = ops.rasterize_bwd_ssim_pipelined(
+                cam, splats, group_base, sorted_gid, tile_start, rgb, depth_acc, fT, view.rgb,
+                -c.ssim_lambda / (3 * H * W), self.loss_spec(view), self._side_stream)
+        else:
+            if c.ssim_lambda > 0:
+                ssim_sum, v_img = ops.ssim_fwd_bwd(rgb, view.rgb, weight=-c.ssim_lambda / (3 * H * W), reduce=False)
+            partials, tile_loss = ops.rasterize_bwd(cam, splats, group_base, sorted_gid, tile_start, rgb,
+                                                    depth_acc, fT, v_rgb=v_img,
+                                                    loss=self.loss_spec(view), want_tile_loss=True)
         if fuse_adam:
             v_xy = self.optimizer.backward_and_step(cam, deg, splats, group_base, partials, want_v_xy,
                                                     begin=begin_step, guard=guard, prefetch=prefetch)

@@ -257,15 +257,7 @@ def rasterize_bwd(cam: Camera, splats, group_base, sorted_gid, tile_start, rgb, 
     ls = None
     keep = []
     if loss is not None:
-        ls = _lib.TgsLossSpec()
-        for k in ("gt_rgb", "gt_depth", "uncertainty"):
-            t = _f32c(loss.get(k))
-            keep.append(t)
-            setattr(ls, k, ptr(t))
-        ls.l1_weight = float(loss.get("l1_weight", 0.0))
-        ls.depth_weight = float(loss.get("depth_weight", 0.0))
-        ls.uncertainty_weight = float(loss.get("uncertainty_weight", 1.0))
-        ls.eps = float(loss.get("eps", 1e-6))
+        ls = _loss_spec_struct(loss, keep)
     v_rgb, v_depth, v_alpha = _f32c(v_rgb), _f32c(v_depth), _f32c(v_alpha)
     check(lib.tgs_rasterize_bwd(C.byref(cs), ptr(splats), ptr(group_base), ptr(sorted_gid),
                                 ptr(tile_start), ptr(getattr(tile_start, "tile_order", None)),
@@ -274,6 +266,84 @@ def rasterize_bwd(cam: Camera, splats, group_base, sorted_gid, tile_start, rgb, 
                                 C.byref(ls) if ls is not None else None, ptr(partials),
                                 ptr(tile_loss), _stream()), "tgs_rasterize_bwd")
     return partials, tile_loss
+
+
+def _loss_spec_struct(loss, keep):
+    ls = _lib.TgsLossSpec()
+    for k in ("gt_rgb", "gt_depth", "uncertainty"):
+        t = _f32c(loss.get(k))
+        keep.append(t)
+        setattr(ls, k, ptr(t))
+    ls.l1_weight = float(loss.get("l1_weight", 0.0))
+    ls.depth_weight = float(loss.get("depth_weight", 0.0))
+    ls.uncertainty_weight = float(loss.get("uncertainty_weight", 1.0))
+    ls.eps = float(loss.get("eps", 1e-6))
+    return ls
+
+
+def band_rows(cam: Camera):
+    """Image bands of the K7 band launches -> list of (band, y0, y1, count_y0, count_y1): the pixel rows
+    [y0, y1) a band's tiles cover and the rows [count_y0, count_y1) it contributes to image-wide sums (a
+    partition of [0, H)).  (tgs_num_bands / tgs_band_tiles)"""
+    lib = _lib.load()
+    TW = cam.tiles[0]
+    out = []
+    t0, t1 = C.c_int(), C.c_int()
+    for b in range(lib.tgs_num_bands(cam.W, cam.H)):
+        check(lib.tgs_band_tiles(cam.W, cam.H, b, C.byref(t0), C.byref(t1)), "tgs_band_tiles")
+        if t1.value > t0.value:
+            out.append([b, 16 * (t0.value // TW), min(16 * ((t1.value - 1) // TW + 1), cam.H)])
+    for i, r in enumerate(out):
+        r += [r[1] if i else 0, out[i + 1][1] if i + 1 < len(out) else cam.H]
+    return [tuple(r) for r in out]
+
+
+def rasterize_bwd_ssim_pipelined(cam: Camera, splats, group_base, sorted_gid, tile_start, rgb, depth, fT, gt_rgb,
+                                 ssim_weight: float, loss: Optional[dict], side_stream, want_tile_loss: bool = True):
+    """SSIM (K10) and K7 pipelined by image bands on two streams: the SSIM gradient of band b is produced
+    on ``side_stream`` while K7 composites band b-1 on the current stream (K7 is VALU-bound, the SSIM
+    kernels are latency chains: they overlap almost for free), so only the first band's SSIM is exposed.
+    Bit-identical to ssim_fwd_bwd followed by rasterize_bwd.  -> (partials, tile_loss, ssim partial sums).
+    (tgs_ssim_fwd_bwd_rows, tgs_rasterize_bwd_band)"""
+    lib = _lib.load()
+    dev = splats.device
+    H, W = cam.H, cam.W
+    order = getattr(tile_start, "tile_order", None)
+    if order is None:
+        raise ValueError("the band launches need tile_start.tile_order (ops.bin_sort / project_bin_sort)")
+    bands = band_rows(cam)
+    rgb, gt_rgb = _f32c(rgb), _f32c(gt_rgb)
+    partials = torch.empty(sorted_gid.shape[0], PARTIAL_FLOATS, dtype=torch.float32, device=dev)
+    tile_loss = torch.empty(cam.num_tiles, 2, dtype=torch.float32, device=dev) if want_tile_loss else None
+    v_img = torch.empty_like(rgb)
+    scratch = torch.empty(9 * H * W, dtype=torch.float32, device=dev)
+    n_p = ((W + 63) // 64) * ((max(y1 - y0 for _, y0, y1, _, _ in bands) + 10) // 12 + 2)
+    bp = torch.empty(len(bands), n_p, dtype=torch.float32, device=dev)
+    keep = []
+    ls = _loss_spec_struct(loss, keep) if loss is not None else None
+    cs = cam.c_struct()
+    main = torch.cuda.current_stream(dev)
+    ready = torch.cuda.Event()
+    ready.record(main)                     # the rendered image is complete on the current stream
+    side_stream.wait_event(ready)
+    for t in (v_img, scratch, bp, rgb, gt_rgb):
+        t.record_stream(side_stream)
+    done = []
+    with torch.cuda.stream(side_stream):
+        for i, (b, y0, y1, c0, c1) in enumerate(bands):
+            check(lib.tgs_ssim_fwd_bwd_rows(W, H, ptr(rgb), ptr(gt_rgb), C.c_float(ssim_weight), ptr(bp[i]), n_p,
+                                            ptr(v_img), ptr(scratch), y0, y1, c0, c1, _stream()),
+                  "tgs_ssim_fwd_bwd_rows")
+            ev = torch.cuda.Event()
+            ev.record(side_stream)
+            done.append(ev)
+    for (b, *_), ev in zip(bands, done):
+        main.wait_event(ev)
+        check(lib.tgs_rasterize_bwd_band(C.byref(cs), ptr(splats), ptr(group_base), ptr(sorted_gid), ptr(tile_start),
+                                         ptr(order), ptr(rgb), ptr(depth), ptr(fT), ptr(v_img), None, None,
+                                         C.byref(ls) if ls is not None else None, ptr(partials), ptr(tile_loss),
+                                         b, _stream()), "tgs_rasterize_bwd_band")
+    return partials, tile_loss, bp
 
 
 def reduce_partials(cam: Camera, splats, group_base, partials):
