@@ -50,11 +50,14 @@ __device__ __forceinline__ AdamK adam_resolve(AdamK a) {
   return a;
 }
 
+// One Adam update.  Every multiply-add is an explicit fmaf: the same update is evaluated by several
+// kernels (k_adam, the fused K8+Adam kernel, the gathered-SH kernel of the data-parallel step) that are
+// tested to agree bit for bit, so no FMA formation is left to the compiler's per-kernel choice.
 __device__ __forceinline__ void adam1(const AdamK& a, float lr, float& p, float g, float& m, float& v) {
   g *= a.gscale;
-  m = a.b1 * m + (1.f - a.b1) * g;
-  v = a.b2 * v + (1.f - a.b2) * g * g;
-  const float denom = sqrtf(v) * a.isq_bc2 + a.eps;
-  p -= lr * (m * a.ibc1) / denom;
+  m = fmaf(a.b1, m, (1.f - a.b1) * g);
+  v = fmaf(a.b2, v, ((1.f - a.b2) * g) * g);
+  const float denom = fmaf(sqrtf(v), a.isq_bc2, a.eps);
+  p -= (lr * (m * a.ibc1)) / denom;
 }
 #endif
