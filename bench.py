@@ -393,8 +393,19 @@ def main():
                                                         "unit": out["cpu_baseline"]["unit"]}
             except Exception as ex:  # the oracle is test infrastructure; never fail the bench on it
                 out["cpu_baseline"] = {"value": None, "error": repr(ex)}
-        print(json.dumps(out), flush=True)
     dp.barrier()
+    if dp.active:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    if out is not None:
+        # the JSON line is the LAST thing on stdout: RCCL prints its version banner through C stdio, which
+        # is block-buffered on a pipe and would otherwise land behind it at process exit
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
