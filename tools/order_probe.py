@@ -7,9 +7,11 @@ from touch_gs_amd import ops
 from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
 from touch_gs_amd.optim import GaussianParams
 from touch_gs_amd.scene import make_view, synthetic_gaussians
-N, W, H, deg = 1_000_000, 1920, 1080, 3
+import os
+N, W, H, deg = (5_000_000, 3840, 2160, 3) if os.environ.get('PROBE_CFG') == 'cfg5' else (1_000_000, 1920, 1080, 3)
+SEED = 1238 if N > 1_000_000 else 1236
 dev = torch.device('cuda:0')
-P, _ = synthetic_gaussians(N, W, H, deg, 1236)
+P, _ = synthetic_gaussians(N, W, H, deg, SEED)
 params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
 model = DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=0), params)
 model.spatial_sort()
@@ -49,8 +51,8 @@ def timed(f, reps=12):
     t = sorted(a.elapsed_time(b) for a, b in evs[2:])
     return t[len(t) // 2] * 1e3
 
-for vi in range(8):
-    view = make_view(N, W, H, deg, 1236, dev, view=vi, n_views=8)
+for vi in (range(8) if N <= 1_000_000 else (0, 3)):
+    view = make_view(N, W, H, deg, SEED, dev, view=vi, n_views=8)
     sp, _, gb, ts, sg, st = ops.project_bin_sort(view.cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg)
     rgb, dacc, fT, _ = ops.rasterize_fwd(view.cam, sp, sg, ts)
     _, v_img = ops.ssim_fwd_bwd(rgb, view.rgb, weight=-0.2 / (3 * H * W), reduce=False)
