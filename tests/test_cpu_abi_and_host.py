@@ -343,3 +343,27 @@ def test_bench_byte_models_match_survey():
     assert set(bench.CONFIGS) >= {"cfg2", "cfg3", "cfg5", "clustered"} and bench.CONFIGS["cfg3"]["seed"] == 1236
     ab = bench.algorithmic_bytes(N, I, P, T, K)
     assert set(ab) == set(sb)
+
+
+def test_xcd_schedule_sizes_and_bands_host():
+    """Host-side size functions of the K6 / K7 schedule (no GPU): tgs_tile_order_len = 8 XCDs x the slots of
+    one XCD (tiles dealt in granules of 8), and the image bands of tgs_rasterize_bwd_band partition the
+    row-major tile range in order, each band <= 8 x 1024 tiles."""
+    import ctypes as C
+    from touch_gs_amd import _lib
+    lib = _lib.load()
+    for W, H in [(16, 16), (70, 50), (800, 800), (1920, 1080), (3840, 2160), (4080, 4080)]:
+        T = lib.tgs_num_tiles(W, H)
+        L = lib.tgs_tile_order_len(W, H)
+        per = -(-(-(-T // 8)) // 8) * 8
+        assert L == 8 * per and L >= T
+        nb = lib.tgs_num_bands(W, H)
+        assert nb >= 1
+        t0, t1 = C.c_int(), C.c_int()
+        nxt = 0
+        for b in range(nb):
+            assert lib.tgs_band_tiles(W, H, b, C.byref(t0), C.byref(t1)) == 0
+            assert t0.value == min(nxt, T) and t0.value <= t1.value <= T and t1.value - t0.value <= 8 * 1024
+            nxt = t1.value if t1.value > t0.value else nxt
+        assert nxt == T
+        assert lib.tgs_band_tiles(W, H, nb, C.byref(t0), C.byref(t1)) != 0
