@@ -8,7 +8,7 @@ flat gradient buffer) + fused Adam.  Inputs are resident in HBM before the timed
 `value` = optimizer iterations/s x ranks = views/s of the whole job (weak scaling: one view per
 rank per iteration).
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]        (N > 1 without WORLD_SIZE: launches its own N ranks)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 """
 from __future__ import annotations
@@ -71,36 +71,42 @@ def measured_traffic(kernel_key, N, W, H, deg):
     (profiles/*pmc_step_cfg3.json: FETCH_SIZE / WRITE_SIZE collected in separate --pmc passes on this
     same workload and corrected as MI355X_MICROARCH.md prescribes).  None if no profile matches."""
     if (N, W, H, deg) != (1_000_000, 1920, 1080, 3):
-        return None
+        return None, None
     import glob
     names = {"raster_bwd": "k_raster_bwd", "raster_fwd": "k_raster_fwd<false>", "adam": "k_adam"}
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_step_cfg3.json")), reverse=True):
         try:
             with open(path) as f:
                 d = json.load(f)
-            return int(d["hbm_bytes_per_launch_corrected"][names[kernel_key]]["total_bytes"])
+            return (int(d["hbm_bytes_per_launch_corrected"][names[kernel_key]]["total_bytes"]),
+                    os.path.relpath(path, ROOT))
         except Exception:
             continue
-    return None
+    return None, None
 
 
 def valu_utilisation(kern_ms, N, W, H, deg):
     """Second roofline for the two compositing kernels, which are VALU- not HBM-bound: VALU
     wave-instructions per launch (SQ_INSTS_VALU from the committed PMC pass on this workload)
-    divided by the measured time, against the issue limit of 1024 SIMD32s at one wave64 FMA per
-    2.57 cycles @ 2.4 GHz (tools/ubench/pk_fma.hip: 122 TFLOP/s plain v_fma_f32)."""
+    divided by the measured time, against BOTH issue limits of 1024 SIMD32s @ 2.4 GHz: one wave64
+    instruction per 2 cycles (MI355X_MICROARCH.md) and per 2.57 cycles (what a plain v_fma_f32 stream
+    reaches in tools/ubench/pk_fma.hip: 122 TFLOP/s).  The instruction counts come from the committed
+    profile named in `source`, not from this run."""
     if (N, W, H, deg) != (1_000_000, 1920, 1080, 3):
         return None
     import glob
-    peak = 1024 * 2.4e9 / 2.57
+    peak, peak_spec = 1024 * 2.4e9 / 2.57, 1024 * 2.4e9 / 2.0
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_step_cfg3.json")), reverse=True):
         try:
             with open(path) as f:
                 c = json.load(f)["counters"]
-            out = {"peak_wave_instr_per_s": round(peak, -9)}
+            out = {"peak_wave_instr_per_s": round(peak, -9), "peak_spec_2cycle_wave_instr_per_s": round(peak_spec, -9),
+                   "source": os.path.relpath(path, ROOT)}
             for key, name in (("raster_fwd", "k_raster_fwd<false>"), ("raster_bwd", "k_raster_bwd")):
                 n = c[name]["SQ_INSTS_VALU"]
-                out[key] = {"valu_wave_instr": int(n), "frac_of_issue_peak": round(n / (kern_ms[key] * 1e-3) / peak, 3)}
+                rate = n / (kern_ms[key] * 1e-3)
+                out[key] = {"valu_wave_instr": int(n), "frac_of_issue_peak": round(rate / peak, 3),
+                            "frac_of_spec_2cycle_peak": round(rate / peak_spec, 3)}
             return out
         except Exception:
             continue
@@ -152,6 +158,31 @@ def cpu_baseline(N, W, H, deg, seed, frac=None, clustered=False):
                              project_bwd=t5 - t4))
 
 
+def self_launch(n_ranks: int) -> int:
+    """`python bench.py --gpus N` with N > 1 and no rank environment: start the N ranks through
+    torch.distributed.run on 127.0.0.1 (a free port), pass their chatter to stderr and print exactly
+    the one JSON line rank 0 produced.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n_ranks)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = r.stdout.splitlines()
+    js = [l for l in lines if l.startswith("{") and l.rstrip().endswith("}")]
+    for l in lines:
+        if not js or l is not js[-1]:
+            print(l, file=sys.stderr)
+    if js:
+        print(js[-1], flush=True)
+    return r.returncode if (r.returncode != 0 or js) else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,6 +205,8 @@ def main():
                     help="memory order of the Gaussians: morton = model.spatial_sort() at start-up (the "
                          "framework's default layout), asis = the order the scene generator emits (random)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
     preset = CONFIGS[args.config]
     custom = []
     for k in ("gaussians", "width", "height", "seed"):
@@ -210,13 +243,14 @@ def main():
              for v in range(args.views)]
     for v in views:
         v.valid_count()
-    n_isect = []
+    n_isect, n_need = [], []
     for v in views:  # size the intersection buffers once; no host sync inside the timed region
         sp = ops.project_fwd(v.cam, params.means, params.log_scales, params.quats, params.opac_logit, params.sh, deg)
         b = ops.IntersectBudget()
         ops.bin_sort(v.cam, sp, b)
         n_isect.append(b.last_n)
-    model.budget = ops.IntersectBudget(capacity=int(max(n_isect) * 1.25) + 4096, sync=False)
+        n_need.append(b.last_need)   # capacity under the per-XCD split of the pair index space (tgs.h)
+    model.budget = ops.IntersectBudget(capacity=int(max(n_need) * 1.25) + 4096, sync=False)
     del sp
     torch.cuda.empty_cache()
 
@@ -342,6 +376,7 @@ def main():
         achieved = sb[dom] / (kern_ms[dom] * 1e-3) / 1e9
         achieved_layout = ab[dom] / (kern_ms[dom] * 1e-3) / 1e9
         step_bytes = sum(ab.values())
+        traffic, traffic_src = measured_traffic(dom, N, W, H, deg) if args.config == "cfg3" and not custom else (None, None)
         fwd_bwd_ms = sum(kern_ms[k] for k in names[:5] if k != "ssim")
         fwd_bwd_bytes = sum(sb[k] for k in names[:5] if k != "ssim")
         out = {
@@ -365,7 +400,9 @@ def main():
             # the *_layout figures use this build's own record sizes
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": measured_traffic(dom, N, W, H, deg) if args.config == "cfg3" and not custom else None,
+                         # HBM bytes per launch from the committed PMC passes of this workload (NOT collected in
+                         # this run: counters need their own rocprofv3 passes); `traffic_source` names the file
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": sb[dom], "bytes_model": "SURVEY 8(d)",
                          "achieved_layout": round(achieved_layout, 1), "frac_layout": round(achieved_layout / HBM_PEAK_GBS, 4),
                          "layout_bytes": ab[dom]},

@@ -126,8 +126,16 @@ int tgs_sh_bwd(int N, int sh_deg, int sh_stride, const float* dirs, const float*
  *                       block b runs on XCD b % 8; XCD x owns every 8th granule of 8 consecutive
  *                       tiles (balanced for any view) and visits its tiles longest list first inside
  *                       chunks of <= 1024; entry [i * 8 + x] = i-th visit of XCD x, T = "no tile"
- *      status[2]        {#intersections, overflow flag}; if #intersections > capacity nothing
- *                       past the scans is written, overflow=1 (caller grows and retries)
+ *      status[4]        {#intersections, overflow flag, sufficient capacity, reserved}.  The pair index
+ *                       space [0, capacity) is cut into 8 equal regions, one per XCD: every K1 workgroup
+ *                       takes its 256-Gaussian group's contiguous pair range from the region of the XCD
+ *                       it runs on, or from the first other region with room.  A frame can therefore
+ *                       overflow slightly before #intersections reaches capacity (ranges are not split
+ *                       across regions) but never when capacity >= status[2] = #intersections + 8 x the
+ *                       largest group total -- whatever XCD the workgroups happen to run on.  Size
+ *                       buffers from status[2] (written every frame), not from status[0].  On overflow
+ *                       nothing past the scans is written, overflow = 1 and status[0] = status[2]
+ *                       (caller grows to it and retries)
  *      sticky_overflow  (may be NULL) one persistent int32: set to 1 by an overflowing frame and
  *                       never cleared by the library; while it is 1 every frame starts with
  *                       status[1] = 1 (empty lists).  Together with the `skip_if_overflow` argument of

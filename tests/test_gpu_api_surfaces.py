@@ -487,8 +487,16 @@ def test_trainer_on_disk_dataset_in_reference_format(dev, tmp_path):
     ev = json.load(open(os.path.join(run, "eval.json")))
     assert {"psnr", "ssim", "depth_mse", "supervised_depth_mse"} <= set(ev["results"])
     assert len(os.listdir(tmp_path / "renders" / "rgb")) == 1 and len(os.listdir(tmp_path / "renders" / "depth")) == 1
-    # uncertainty (a variance) scales with the square of the pose factor
-    assert torch.allclose(sc.views[0].uncertainty, v0.uncertainty * sc.scale ** 2, atol=1e-3 * sc.scale ** 2 + 1e-7)
+    # uncertainty units (dataset.py docstring, UNVERIFIED-PRIOR): default "linear" = the depth image's factor;
+    # "variance" = its square; "none" = as stored.  The choice is recorded in the run's config.json.
+    assert sc.uncertainty_scaling == "linear"
+    assert torch.allclose(sc.views[0].uncertainty, v0.uncertainty * sc.scale, atol=1e-3 * sc.scale + 1e-7)
+    sv = Scene(str(root), train_split_fraction=0.8, device=dev, uncertainty_scaling="variance")
+    assert torch.allclose(sv.views[0].uncertainty, v0.uncertainty * sc.scale ** 2, atol=1e-3 * sc.scale ** 2 + 1e-7)
+    sn = Scene(str(root), train_split_fraction=0.8, device=dev, uncertainty_scaling="none")
+    assert torch.allclose(sn.views[0].uncertainty, v0.uncertainty, atol=1e-3 + 1e-7)
+    rec = json.load(open(os.path.join(run, "config.json")))["scene"]
+    assert rec["uncertainty_scaling"] == "linear" and abs(rec["uncertainty_factor"] - sc.scale) < 1e-12
 
     # the reference's run_eval step (experiment_utils/run_eval.py:37-57) with IS_REAL_WORLD exported
     # (scripts/train_bunny_real.sh:54): <exp>/<exp>_<k>.json newest first, gt_* keys, render dump
@@ -657,6 +665,26 @@ def test_bench_two_ranks_share_one_gpu(dev):
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
     assert line["dp_exchange"]["replicas_identical"] is True
     assert line["config"]["parallelism"] == "dp2"
+
+
+def test_bench_bare_command_launches_its_own_ranks(dev):
+    """`python bench.py --gpus 2` exactly as the driver invokes it (no torchrun, no rank environment):
+    bench.py starts its own two ranks (here sharing cuda:0 over gloo) and prints ONE JSON line with
+    n_gpus = 2, the exchange report and the replica check."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TGS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--config", "cfg2"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines          # nothing but the JSON line on stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["dp_exchange"]["replicas_identical"] is True
+    assert line["dp_exchange"]["all_gather_busbw_GBs"] > 0
 
 
 def test_nerfstudio_adapter_core_trains(dev):

@@ -6,8 +6,11 @@ fp64 build of the scalar C oracle (oracle/ref_raster.c) on
 * configs[4], the part one GPU runs: 5 M Gaussians, SH degree 3, 3840x2160 (seed 1238),
 
 forward (RGB / depth / final T / last contributor) on every pixel whose threshold decisions are not
-ambiguous under fp32 rounding, all five parameter gradients, and the output-preservation claim of
-the tight tile rectangle: every (tile, Gaussian) pair that the product drops
+ambiguous under fp32 rounding, all five parameter gradients, the FULL train step of configs[1] / [2]
+(fused L1 + tactile depth/uncertainty loss + SSIM with the reference's three flag sets: loss value and
+parameter gradients against O.train_loss differentiated through the C oracle), SSIM value + gradient
+image at the three image sizes (covers every segment length k_ssim_* selects), and the
+output-preservation claim of the tight tile rectangle: every (tile, Gaussian) pair that the product drops
 from the NORMATIVE App. B.4 rectangle has alpha < 1/255 at every pixel centre of its tile.
 
 The oracle lists are built from the normative B.4 rect, the HIP lists from the tight rect -- the
@@ -72,7 +75,8 @@ def both(request, dev):
     tile_np = tile.cpu().numpy()
     pos2 = ts2[tile_np] + np.maximum(bf["final_idx"], 0)
     last_gid_ref = np.where(bf["final_idx"] >= 0, g2[np.minimum(pos2, max(len(g2) - 1, 0))], -1)
-    return dict(name=request.param, N=N, W=W, H=H, R=R, cb=cb, sp=sp, radii=radii, n_hip=n_hip, n_ref=len(g2),
+    return dict(name=request.param, N=N, W=W, H=H, deg=deg, seed=seed, view=view, cam=cam, D=D, Pn=Pn, g2=g2, ts2=ts2,
+                R=R, cb=cb, sp=sp, radii=radii, n_hip=n_hip, n_ref=len(g2),
                 rgb=rgb.cpu().numpy(), depth=depth.cpu().numpy(), fT=fT.cpu().numpy(), last_hip=last_gid_hip,
                 grads=[t.cpu().double().numpy() for t in grads[:5]], pc=pc, bf=bf, margin=margin, pb=pb,
                 last_ref=last_gid_ref)
@@ -143,3 +147,98 @@ def test_gradients_match_oracle_fullsize(both):
         assert np.median(e) < 3e-5, (b["name"], name, np.median(e))
         assert np.quantile(e, 0.98) < 5e-3, (b["name"], name, np.quantile(e, 0.98))
         assert cos > 0.9999 and rel_l2 < 1e-2, (b["name"], name, cos, rel_l2)
+
+
+# ---------------------------------------------------------------------------------------------
+# the loss side of the step at full size
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("W,H", [(800, 800), (1920, 1080), (3840, 2160)])
+def test_ssim_matches_oracle_fullsize(dev, W, H):
+    """K10 at the BASELINE image sizes (the segment length of k_ssim_fwd / k_ssim_bwd depends on the image
+    size: imgloss.hip picks 12 / 34 / 45-row segments here) against the fp64 torch SSIM and its autograd."""
+    from oracle import torch_oracle as O
+    from touch_gs_amd import ops
+    g = torch.Generator().manual_seed(W + H)
+    # a smooth image + noise: SSIM well inside (0, 1), non-trivial local statistics
+    base = torch.nn.functional.interpolate(torch.rand(1, 3, H // 40 + 2, W // 40 + 2, generator=g, dtype=torch.float64),
+                                           size=(H, W), mode="bilinear", align_corners=False)[0].permute(1, 2, 0)
+    gt = base.clamp(0, 1).contiguous()
+    img = (base + 0.1 * torch.randn(H, W, 3, generator=g, dtype=torch.float64)).clamp(0, 1).contiguous()
+    img.requires_grad_(True)
+    s = O.ssim(img, gt)
+    (0.2 * (1 - s)).backward()
+    tot, v = ops.ssim_fwd_bwd(img.detach().float().to(dev), gt.float().to(dev), weight=-0.2 / (3 * H * W))
+    assert abs(tot.item() / (3 * H * W) - s.item()) < 1e-5, (tot.item() / (3 * H * W), s.item())
+    ref = img.grad.numpy()
+    got = v.cpu().double().numpy()
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() < 1e-4 * scale, np.abs(got - ref).max() / scale
+    rel_l2 = np.sqrt(((got - ref) ** 2).sum() / (ref * ref).sum())
+    assert rel_l2 < 1e-5, rel_l2
+
+
+# the reference's three flag sets: scripts/train_bunny_real.sh:52, train_block_data.sh:50 (= train_mirror.sh:49),
+# train_bunny_blender.sh:50
+FLAG_SETS = {"bunny_real": ("DEPTH_UNCERTAINTY_WEIGHTED_LOSS", 0.005, 0.01),
+             "block": ("DEPTH_UNCERTAINTY_WEIGHTED_LOSS", 0.2, 1.0),
+             "bunny_blender": ("SIMPLE_LOSS", 0.5, 1.0)}
+
+
+def test_train_step_matches_oracle_fullsize(both, dev):
+    """The fused train step (K1..K8 + K10: L1 + SSIM + tactile depth / uncertainty loss evaluated inside
+    K7) at configs[1] and configs[2]: loss terms and all five parameter gradients against
+    O.train_loss (fp64 torch) differentiated through the fp64 C oracle's compositing / projection
+    backward, for the reference's three flag sets."""
+    from oracle import torch_oracle as O
+    from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig, View
+    from touch_gs_amd.optim import GaussianParams
+    from touch_gs_amd.scene import make_view
+    b = both
+    if b["W"] > 2048:
+        pytest.skip("train-step parity runs at configs[1] and configs[2]")
+    N, W, H, deg = b["N"], b["W"], b["H"], b["deg"]
+    mv = make_view(N, W, H, deg, b["seed"], dev, view=b["view"], n_views=8)
+    view = View(cam=b["cam"], rgb=mv.rgb, depth=mv.depth, uncertainty=mv.uncertainty)
+    gt64, dgt64, unc64 = (t.cpu().double() for t in (mv.rgb, mv.depth, mv.uncertainty))
+    R, cb, pc, bf, Pn = b["R"], b["cb"], b["pc"], b["bf"], b["Pn"]
+    for tag, (ltype, mult, uw) in FLAG_SETS.items():
+        # ---- HIP: the fused step's forward + backward ----
+        D = b["D"]
+        params = GaussianParams.from_tensors(*[D[k].clone() for k in GaussianParams.NAMES])
+        cfg = ModelConfig(sh_degree=deg, sh_degree_interval=0, depth_loss_mult=mult, depth_loss_type=ltype,
+                          uncertainty_weight=uw)
+        model = DepthGaussianSplattingModel(cfg, params)
+        tile_loss, ssim_sum = model.forward_backward(view)
+        losses = {k: float(v) for k, v in model.loss_from(tile_loss, ssim_sum, view).items()}
+        ssim_hip = float(ssim_sum.sum()) / (3 * H * W)
+        got = {k: params.g[k].detach().cpu().double().numpy() for k in GaussianParams.NAMES}
+        # ---- oracle: fp64 loss on the C oracle's images, its autograd seeds the C oracle's backward ----
+        rgb_t = torch.from_numpy(bf["rgb"]).requires_grad_(True)
+        dacc_t = torch.from_numpy(bf["depth_acc"]).requires_grad_(True)
+        alpha_t = (1.0 - torch.from_numpy(bf["final_T"])).requires_grad_(True)
+        out = dict(rgb=rgb_t, depth_acc=dacc_t, alpha=alpha_t)
+        L = O.train_loss(out, gt64, dgt64, unc64, ssim_lambda=0.2, depth_loss_mult=mult, depth_loss_type=ltype,
+                         uncertainty_weight=uw)
+        L.backward()
+        L_depth = mult * float(O.depth_loss(dacc_t.detach(), alpha_t.detach(), dgt64, unc64, ltype, uw))
+        ssim_ref = float(O.ssim(rgb_t.detach(), gt64))
+        bb = R.blend_bwd(pc["xy"], pc["conic"], pc["opac"], pc["rgb"], pc["depth"], b["g2"], b["ts2"], cb, W, H,
+                         bf["final_T"], bf["final_idx"], rgb_t.grad.numpy(), dacc_t.grad.numpy(), alpha_t.grad.numpy())
+        pb = R.project_bwd(Pn["means"], Pn["log_scales"], Pn["quats"], Pn["opac_logit"], Pn["sh"], deg, cb, W, H,
+                           pc["radius"], bb["v_xy"], bb["v_conic"], bb["v_opac"], bb["v_rgb"], bb["v_depth"])
+        # ---- loss terms ----
+        total = sum(losses.values())
+        assert abs(total - float(L)) < 2e-5 * abs(float(L)), (b["name"], tag, total, float(L))
+        assert abs(losses["depth_loss"] - L_depth) < 1e-4 * abs(L_depth) + 1e-9, (b["name"], tag, losses["depth_loss"], L_depth)
+        assert abs(ssim_hip - ssim_ref) < 1e-5, (b["name"], tag, ssim_hip, ssim_ref)
+        # ---- gradients ----
+        for name, key in (("means", "v_means"), ("log_scales", "v_log_scales"), ("quats", "v_quats"),
+                          ("opac_logit", "v_opac_logit"), ("sh", "v_sh")):
+            ref = pb[key].reshape(got[name].shape)
+            scale = np.abs(ref).max()
+            e = relerr(got[name], ref, floor=1e-3 * scale)
+            cos = (ref * got[name]).sum() / np.sqrt((ref * ref).sum() * (got[name] * got[name]).sum())
+            rel_l2 = np.sqrt(((got[name] - ref) ** 2).sum() / (ref * ref).sum())
+            assert np.median(e) < 3e-5, (b["name"], tag, name, np.median(e))
+            assert np.quantile(e, 0.98) < 5e-3, (b["name"], tag, name, np.quantile(e, 0.98))
+            assert cos > 0.9999 and rel_l2 < 1e-2, (b["name"], tag, name, cos, rel_l2)

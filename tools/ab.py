@@ -34,7 +34,7 @@ view = make_view(N, W, H, deg, seed, dev, clustered=cl)
 view.valid_count()
 b = ops.IntersectBudget()
 ops.project_bin_sort(view.cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, b)
-budget = ops.IntersectBudget(capacity=int(b.last_n * 1.25) + 4096, sync=False)
+budget = ops.IntersectBudget(capacity=int(b.last_need * 1.25) + 4096, sync=False)
 ev = lambda: torch.cuda.Event(enable_timing=True)
 names = ["front", "k6", "ssim", "k7", "k8"]
 acc = {k: [] for k in names}

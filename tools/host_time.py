@@ -15,7 +15,7 @@ for pipe in (False, True):
     m.spatial_sort()
     b = ops.IntersectBudget()
     ops.project_bin_sort(views[0].cam, params.means, params.log_scales, params.quats, params.opac_logit, params.sh, deg, b)
-    m.budget = ops.IntersectBudget(capacity=int(b.last_n * 1.3) + 4096, sync=False)
+    m.budget = ops.IntersectBudget(capacity=int(b.last_need * 1.3) + 4096, sync=False)
     for i in range(30):
         m.train_step(views[i % 8], next_view=views[(i + 1) % 8])
     torch.cuda.synchronize()

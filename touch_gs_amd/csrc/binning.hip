@@ -80,13 +80,19 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int T, int NB, int32_t* __r
   }
   const bool overflow = status[1] != 0;
   if (blockIdx.x == 0 && tid == 0) {
-    // status[0]: the frame's intersection count = sum of the 8 per-XCD allocators; on overflow the
-    // capacity that would have sufficed with this frame's split over the XCDs (8 x the fullest region)
+    // status[0]: the frame's intersection count = the 8 per-XCD allocators + the pairs that found no
+    // room; status[2]: the capacity that is SUFFICIENT for this frame whatever XCD its workgroups run
+    // on, #pairs + 8 x the largest group total (tgs_binning.h).  On overflow status[0] = status[2], so
+    // that a caller that grows to status[0] x growth converges in one retry.
     const int32_t* xa = tile_count + TGS_ALLOC_OFF(T);
-    long long n = 0, mx = 0;
-    for (int x = 0; x < TGS_XCC; x++) { n += xa[x * TGS_ALLOC_STRIDE]; mx = max(mx, (long long)xa[x * TGS_ALLOC_STRIDE]); }
-    if (overflow) n = max(n, TGS_XCC * mx);
-    status[0] = (int32_t)min(n, 0x7fffffffll);
+    long long n = 0, mg = 0;
+    for (int x = 0; x < TGS_XCC; x++) {
+      n += (long long)xa[x * TGS_ALLOC_STRIDE] + xa[x * TGS_ALLOC_STRIDE + 1];
+      mg = max(mg, (long long)xa[x * TGS_ALLOC_STRIDE + 2]);
+    }
+    const long long need = n + TGS_XCC * mg;
+    status[0] = (int32_t)min(overflow ? need : n, 0x7fffffffll);
+    status[2] = (int32_t)min(need, 0x7fffffffll);
   }
   int32_t* __restrict__ sub_start = tile_count + TGS_XCC * T;
   int32_t* __restrict__ agg = sub_start + TGS_XCC * T;     // [NB] aggregate + 1 of every scan workgroup, 0 = not yet

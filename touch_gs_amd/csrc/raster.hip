@@ -19,11 +19,12 @@
 //  * backward: walks the list front to back like the forward (identical decisions, no stored
 //    last-contributor index, no T/(1-alpha) division chain); per-pixel state is (T, prefix.v)
 //    only; each lane accumulates, over its <= 4 pixels,
-//    10 sums per Gaussian (v_rgb, v_depth and the six pixel-coordinate moments of
-//    q = alpha * v_alpha); the 64-lane sums go through LDS: every lane scatters its 10 values
-//    into a padded [10][68] image, lane (part, c) adds 16 lane contributions of value c read as
-//    four ds_read_b128, two lane-swap folds (v_permlane16/32_swap) combine the four parts and value i lands in slot i
-//    of an LDS transpose buffer (15 adds + two 3-instruction lane-swap folds + 11 LDS instructions; a multiplexed DPP
+//    8 sums per Gaussian (v_rgb, v_depth, and S / Sx / Sy / Quv of q = alpha * v_alpha, from which the
+//    six pixel-coordinate moments follow linearly); the 64-lane sums go through LDS: every lane scatters
+//    its 8 values into a padded [8][68] image, lane (part, c) forms a weighted sum of 16 lane
+//    contributions read as four conflict-free ds_read_b128 (the weights turn S, Sx, Sy into the moments),
+//    two lane-swap folds (v_permlane16/32_swap) combine the four parts and term c lands in slot c
+//    of an LDS transpose buffer (16 FMAs + two 3-instruction lane-swap folds + 9 LDS instructions; a multiplexed DPP
 //    butterfly needs 37 VALU and the kernel is VALU bound); at the end of the batch lane j converts Gaussian j's moments into (v_xy, v_conic, v_opacity) and stores
 //    one 48-B partial record.  There are NO float atomics: cross-tile accumulation is a segmented
 //    sum in K8 (deterministic, and it avoids cross-XCD memory-side atomics).
@@ -35,6 +36,11 @@
 namespace {
 
 constexpr float ALPHA_MAX = 0.999f;
+// K7 runs the copy of its loop without the 0.999 clamp only for batches whose opacities all stay below
+// this bound: exp2(-s) = o e^-sigma can exceed o by rounding (sigma >= 0 only up to a few ulp of the
+// tile-centred quadratic), and the forward clamps whenever e > 0.999 -- the 1 % margin keeps the two
+// kernels' transmittance sequences bit-identical (and e == 1, T' = 0 out of the rcp).
+constexpr float CLAMP_FREE_OPACITY = 0.99f;
 constexpr float T_STOP = 1e-4f;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LOG2_255 = 7.994353436858858f;   // alpha >= 1/255  <=>  s <= log2(255)
@@ -201,6 +207,9 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
   __shared__ float4 recs[64 * 3];
   const int start = tile_start[tile], end = tile_start[tile + 1];
 
+#ifdef TGS_GID_PREFETCH
+  int gid_nxt = (start + lane < end) ? sorted_gid[start + lane] : 0;
+#endif
   for (int base = start; base < end; base += 64) {
     unsigned slot_live = 0u;
 #pragma unroll
@@ -211,8 +220,15 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
     if (base + lane < end) {
       // no register prefetch of the next batch: 12 fewer VGPRs buy two more resident waves per
       // SIMD, which hide the gather latency (and the long dependent chains of the blend) better
+#ifdef TGS_GID_PREFETCH
+      const float* r = splats + (size_t)gid_nxt * TGS_SPLAT_FLOATS;
+      const float4 q0 = ld4(r), q1 = ld4(r + 4), q2 = ld4(r + 8);
+      if (base + 64 + lane < end) gid_nxt = sorted_gid[base + 64 + lane];
+      const TileRec t = make_tile_rec(q0, q1, q2, tcx, tcy);
+#else
       const float* r = splats + (size_t)sorted_gid[base + lane] * TGS_SPLAT_FLOATS;
       const TileRec t = make_tile_rec(ld4(r), ld4(r + 4), ld4(r + 8), tcx, tcy);
+#endif
       recs[lane * 3] = t.a; recs[lane * 3 + 1] = t.b; recs[lane * 3 + 2] = t.c;
       my_mask = __float_as_uint(t.c.w);
     }
@@ -353,17 +369,59 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
   if (n == 0) return;
 
   __shared__ float4 recs[64 * 3];
-  __shared__ float4 sums[64 * 4];  // [Gaussian j][16 slots], slot i < 10 = total of value i
-  // transposed reduction scratch: row c (value index) holds the 64 lane contributions, rows padded
-  // to 68 floats so that the 16 lanes of a quarter wave, reading 16 B each from 16 different rows,
-  // touch 64 distinct banks
+  __shared__ float4 sums[64 * 4];  // [Gaussian j][16 slots], slot c < 14 = total of term c (table below)
+  // Transposed reduction scratch: row r holds the 64 lanes' values of per-lane accumulator r
+  //   r = 0..2 v_rgb, 3 v_depth, 4 S = sum q, 5 Sx = sum q over the lane's right-hand pixels (slots 1, 3),
+  //   6 Sy = sum q over its lower pixels (slots 2, 3), 7 Quv = sum q u v.
+  // Reader lane (part, c) takes 16 consecutive lane values of row ROW[c] (writer lanes 16 part .. +15) and
+  // forms a WEIGHTED sum: the pixel-coordinate moments the conversion to (v_xy, v_conic) needs are linear
+  // in S, Sx, Sy with coefficients that depend on the writer lane only (u = u0 + 8 [right], v = v0 + 8
+  // [lower], u0 = (l & 7) - 7.5, v0 = (l >> 3) - 7.5), so the blend loop accumulates 3 instead of 6
+  // values per pixel slot and the moments appear here at the price of 16 FMAs instead of 15 adds:
+  //   c  0..3  row 0..3, w = 1                          v_rgb, v_depth
+  //   c  4     S, 1            -> Q0
+  //   c  5, 6  S, u0 | Sx, 8   -> Qu  (sum of the two)
+  //   c  7, 8  S, v0 | Sy, 8   -> Qv
+  //   c  9,10  S, u0^2 | Sx, 16 u0 + 64   -> Quu
+  //   c 11,12  S, v0^2 | Sy, 16 v0 + 64   -> Qvv
+  //   c 13     Quv, 1
+  // Bank conflicts: ds_read_b128 is served in lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32)
+  // (MI355X_MICROARCH.md), NOT in quarter waves.  part = (lane >> 4) ^ [4 <= c < 12] makes every such group
+  // read ONE part of <= 8 different rows, whose 68-float stride puts them on disjoint bank quads; lanes
+  // l, l^16, l^32, l^48 still hold the four parts of one c, which is all the two folds need.
   constexpr int RED_RS = 68;
-  __shared__ float4 red4[10 * RED_RS / 4];
+  constexpr int RED_ROWS = 8;
+  __shared__ float4 red4[RED_ROWS * RED_RS / 4];
   float* red = reinterpret_cast<float*>(red4);
-  const int red_c = lane & 15, red_part = lane >> 4;
-  const float* red_rd = red + (red_c < 10 ? red_c : 0) * RED_RS + red_part * 16;
+  const int red_c = lane & 15;
+  const int red_part = (lane >> 4) ^ ((red_c >= 4 && red_c < 12) ? 1 : 0);
+  float wt[16];
+  const float* red_rd;
+  {
+    // row of term c, packed 4 bits each: c = 0 .. 15 -> 0 1 2 3 4 4 5 4 6 4 5 4 6 7 0 0
+    const unsigned long long ROWS = 0x0076454645443210ull;
+    red_rd = red + (int)((ROWS >> (4 * red_c)) & 15ull) * RED_RS + red_part * 16;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const float u0 = (float)(i & 7) - 7.5f;
+      const float v0 = (float)(2 * red_part + (i >> 3)) - 7.5f;
+      float w = 1.f;                                   // c 0..4, 13
+      w = (red_c == 5) ? u0 : w;
+      w = (red_c == 7) ? v0 : w;
+      w = (red_c == 6 || red_c == 8) ? 8.f : w;
+      w = (red_c == 9) ? u0 * u0 : w;
+      w = (red_c == 11) ? v0 * v0 : w;
+      w = (red_c == 10) ? 16.f * u0 + 64.f : w;
+      w = (red_c == 12) ? 16.f * v0 + 64.f : w;
+      w = (red_c >= 14) ? 0.f : w;
+      wt[i] = w;
+    }
+  }
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   int base = start;
+#ifdef TGS_GID_PREFETCH
+  int gid_nxt = (start + lane < end) ? sorted_gid[start + lane] : 0;
+#endif
   for (; base < end; base += 64) {
     unsigned slot_live = 0u;
 #pragma unroll
@@ -375,16 +433,23 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
     unsigned my_mask = 0u;
     __syncthreads();
     if (lane < cnt) {
+#ifdef TGS_GID_PREFETCH
+      const int gid = gid_nxt;
+#else
       const int gid = sorted_gid[base + lane];
+#endif
       const float* r = splats + (size_t)gid * TGS_SPLAT_FLOATS;
       a0 = ld4(r); a1 = ld4(r + 4);
       const float4 a2 = ld4(r + 8);
+#ifdef TGS_GID_PREFETCH
+      if (base + 64 + lane < end) gid_nxt = sorted_gid[base + 64 + lane];
+#endif
       const TileRec t = make_tile_rec(a0, a1, a2, tcx, tcy);
       recs[lane * 3] = t.a; recs[lane * 3 + 1] = t.b; recs[lane * 3 + 2] = t.c;
       my_mask = __float_as_uint(t.c.w);
       P = pair_index(group_base, gid, a2, tx, ty);
     }
-    sums[lane * 4] = z4; sums[lane * 4 + 1] = z4; sums[lane * 4 + 2] = z4;
+    sums[lane * 4] = z4; sums[lane * 4 + 1] = z4; sums[lane * 4 + 2] = z4; sums[lane * 4 + 3] = z4;
     __syncthreads();
 
     unsigned long long qm[4];
@@ -400,10 +465,10 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
       const unsigned m = (unsigned)((qm[0] >> j) & 1ull) | ((unsigned)((qm[1] >> j) & 1ull) << 1) |
                          ((unsigned)((qm[2] >> j) & 1ull) << 2) | ((unsigned)((qm[3] >> j) & 1ull) << 3);
       const float4 qa = recs[j * 3], qb = recs[j * 3 + 1], qc = recs[j * 3 + 2];
-      // acc: 0..2 v_rgb, 3 v_depth, 4 Q0 = sum q, 5 Qu, 6 Qv, 7 Quu, 8 Quv, 9 Qvv
-      float acc[10];
+      // acc: 0..2 v_rgb, 3 v_depth, 4 S = sum q, 5 Sx, 6 Sy, 7 Quv   (rows of the reduction scratch)
+      float acc[RED_ROWS];
 #pragma unroll
-      for (int c = 0; c < 10; c++) acc[c] = 0.f;
+      for (int c = 0; c < RED_ROWS; c++) acc[c] = 0.f;
       bool any = false;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -427,9 +492,9 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
           if constexpr (MAYCLAMP) q *= fmaxf(__builtin_amdgcn_exp2f(-s) * (1.0f / ALPHA_MAX), 1.0f);
           T[k] = fmaf(-al, T[k], T[k]);                // unchanged when al == 0
           acc[4] += q;
-          acc[5] = fmaf(q, pc.u[k & 1], acc[5]); acc[6] = fmaf(q, pc.v[k >> 1], acc[6]);
-          acc[7] = fmaf(q, pc.uu[k & 1], acc[7]); acc[8] = fmaf(q, pc.uv[k], acc[8]);
-          acc[9] = fmaf(q, pc.vv[k >> 1], acc[9]);
+          if (k & 1) acc[5] += q;
+          if (k >> 1) acc[6] += q;
+          acc[7] = fmaf(q, pc.uv[k], acc[7]);
           any |= go;
         }
       }
@@ -438,13 +503,17 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
         // barrier between the scatter and the transposed read -- only the compiler must keep them
         // in order, which the possible aliasing already forces
 #pragma unroll
-        for (int c = 0; c < 10; c++) red[c * RED_RS + lane] = acc[c];
+        for (int c = 0; c < RED_ROWS; c++) red[c * RED_RS + lane] = acc[c];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const float4 r0 = ld4(red_rd), r1 = ld4(red_rd + 4), r2 = ld4(red_rd + 8), r3 = ld4(red_rd + 12);
-        float O = ((r0.x + r0.y) + (r0.z + r0.w)) + ((r1.x + r1.y) + (r1.z + r1.w)) +
-                  (((r2.x + r2.y) + (r2.z + r2.w)) + ((r3.x + r3.y) + (r3.z + r3.w)));
+        // four independent chains of four
+        float o0 = r0.x * wt[0], o1 = r1.x * wt[4], o2 = r2.x * wt[8], o3 = r3.x * wt[12];
+        o0 = fmaf(r0.y, wt[1], o0); o1 = fmaf(r1.y, wt[5], o1); o2 = fmaf(r2.y, wt[9], o2); o3 = fmaf(r3.y, wt[13], o3);
+        o0 = fmaf(r0.z, wt[2], o0); o1 = fmaf(r1.z, wt[6], o1); o2 = fmaf(r2.z, wt[10], o2); o3 = fmaf(r3.z, wt[14], o3);
+        o0 = fmaf(r0.w, wt[3], o0); o1 = fmaf(r1.w, wt[7], o1); o2 = fmaf(r2.w, wt[11], o2); o3 = fmaf(r3.w, wt[15], o3);
+        float O = (o0 + o1) + (o2 + o3);
         O = fold_xor16(O);
         O = fold_xor32(O);
         if (lane < 16) reinterpret_cast<float*>(sums)[j * 16 + lane] = O;
@@ -452,18 +521,18 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
       }
     }
     };
-    // The 0.999 clamp can only bind for opacity > 0.999: batches without such a Gaussian (all of a
-    // typical scene) run a copy of the loop without the clamp (min) and its pass-through correction
+    // The 0.999 clamp can only bind for opacity > 0.999; batches without a Gaussian above 0.99 (the
+    // margin covers rounding, see CLAMP_FREE_OPACITY; almost all of a typical scene) run a copy of the loop without the clamp (min) and its pass-through correction
     // (3 VALU) -- a per-BATCH choice, so the Gaussian loop itself has no extra branch.
-    if (__ballot(lane < cnt && a0.w > ALPHA_MAX) != 0ull) walk(std::true_type{});
+    if (__ballot(lane < cnt && a0.w > CLAMP_FREE_OPACITY) != 0ull) walk(std::true_type{});
     else walk(std::false_type{});
     __syncthreads();
     if (lane < cnt) {
-      const float4 s0 = sums[lane * 4], s1 = sums[lane * 4 + 1], s2 = sums[lane * 4 + 2];
-      // s0 = {v_r, v_g, v_b, v_depth}  s1 = {Q0, Qu, Qv, Quu}  s2 = {Quv, Qvv, -, -}
+      const float4 s0 = sums[lane * 4], s1 = sums[lane * 4 + 1], s2 = sums[lane * 4 + 2], s3 = sums[lane * 4 + 3];
+      // s0 = {v_r, v_g, v_b, v_depth}  s1 = {Q0, Qu', Qu", Qv'}  s2 = {Qv", Quu', Quu", Qvv'}  s3 = {Qvv", Quv, -, -}
       const float gx = a0.x - tcx, gy = a0.y - tcy;
       const float A = a1.x, B = a1.y, Cc = a1.z;
-      const float Q0 = s1.x, Qu = s1.y, Qv = s1.z, Quu = s1.w, Quv = s2.x, Qvv = s2.y;
+      const float Q0 = s1.x, Qu = s1.y + s1.z, Qv = s1.w + s2.x, Quu = s2.y + s2.z, Qvv = s2.w + s3.x, Quv = s3.y;
       // v_sigma = -q, Delta = (gx - u, gy - v):  M* = sum v_sigma * Delta-monomials
       const float Mx = -(gx * Q0 - Qu), My = -(gy * Q0 - Qv);
       const float Mxx = -(gx * gx * Q0 - 2.f * gx * Qu + Quu);

@@ -31,9 +31,12 @@ int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* gro
 // counter buffer layout: count[8][T] | sub_start[8][T] | scan aggregates[64] | longest list[1] (+pad)
 #define TGS_XCC 8
 #define TGS_SCAN_WGS 64
-// ... | pair allocators: 8 words, one per XCD, each in a 128-B line of its own.  The pair index space
-// [0, capacity) is cut into one region per XCD and a group takes its contiguous pair range from the
-// region of the XCD it runs on.
+// ... | pair allocators: one 128-B line per XCD holding {allocated pairs, pairs that found no room,
+// largest group total seen}.  The pair index space [0, capacity) is cut into one region per XCD and a
+// group takes its contiguous pair range from the region of the XCD it runs on; if that region is
+// full (which XCD runs which workgroup is not deterministic, and with few groups the shares are very
+// uneven) it takes the range from the first other region with room.  An allocation can therefore
+// only fail when  #pairs + 8 x (largest group total) > capacity  -- the bound status[2] reports.
 #define TGS_ALLOC_STRIDE 32
 #define TGS_ALLOC_OFF(T) ((2 * TGS_XCC * (T) + TGS_SCAN_WGS + 4 + 31) / 32 * 32)
 static inline int tgs_counter_len(int T) { return TGS_ALLOC_OFF(T) + TGS_XCC * TGS_ALLOC_STRIDE; }
@@ -132,7 +135,7 @@ static __global__ __launch_bounds__(256) void k_clear_counters(int32_t* __restri
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < TGS_XCC * T) tile_cursor[i] = 0;
   if (i < TGS_SCAN_WGS + 4) tile_cursor[2 * TGS_XCC * T + i] = 0;   // look-back flags of k_scan_tiles, longest list
-  if (i < TGS_XCC) tile_cursor[TGS_ALLOC_OFF(T) + i * TGS_ALLOC_STRIDE] = 0;   // pair allocators
+  if (i < 4 * TGS_XCC) tile_cursor[TGS_ALLOC_OFF(T) + (i >> 2) * TGS_ALLOC_STRIDE + (i & 3)] = 0;   // pair allocator lines
   if (i == 0) status[0] = 0;
   if (i == 1) status[1] = sticky ? (*sticky != 0) : 0;
 }
@@ -165,8 +168,13 @@ __device__ __forceinline__ void group_count_tiles(GroupScan& S, int TW, int T, i
   const int x = xcc_id();
   // pair range of the group: one returning atomic on the XCD's allocator.  Issued first and consumed
   // last (publication below), so its round trip to the memory side overlaps the counting.
-  int local = 0;
-  if (tid == 0 && total > 0) local = atomicAdd(&tile_count[TGS_ALLOC_OFF(T) + x * TGS_ALLOC_STRIDE], total);
+  int local = 0, seen_max = 0;
+  int32_t* __restrict__ alloc = tile_count + TGS_ALLOC_OFF(T);
+  if (tid == 0 && total > 0) {
+    local = atomicAdd(&alloc[x * TGS_ALLOC_STRIDE], total);
+    // largest group total so far (a stale value only costs an unnecessary atomicMax below)
+    seen_max = __hip_atomic_load(&alloc[x * TGS_ALLOC_STRIDE + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   int32_t* __restrict__ my_count = tile_count + (size_t)x * T;
   int bx0 = 1 << 30, by0 = 1 << 30, bx1 = 0, by1 = 0;   // tile bounding box of the group's rects
 #pragma unroll
@@ -204,11 +212,25 @@ __device__ __forceinline__ void group_count_tiles(GroupScan& S, int TW, int T, i
   }
   if (tid == 0) {                                             // publication of the pair range
     const long long region = capacity / TGS_XCC;              // pairs per XCD region
-    const int base = (int)(x * region) + local;
+    int xr = x;
+    long long loc = local;
+    bool fits = loc + total <= region;
+    if (!fits) {   // rare: this XCD's region is full -- take the range from another region with room
+      atomicSub(&alloc[x * TGS_ALLOC_STRIDE], total);
+      for (int t = 1; t < TGS_XCC && !fits; t++) {
+        xr = (x + t) & (TGS_XCC - 1);
+        loc = atomicAdd(&alloc[xr * TGS_ALLOC_STRIDE], total);
+        fits = loc + total <= region;
+        if (!fits) atomicSub(&alloc[xr * TGS_ALLOC_STRIDE], total);
+      }
+      if (!fits) atomicAdd(&alloc[x * TGS_ALLOC_STRIDE + 1], total);   // still part of the frame's pair count
+    }
+    if (total > seen_max) atomicMax(&alloc[x * TGS_ALLOC_STRIDE + 2], total);
+    const int base = (int)(xr * region + loc);
     S.base = base;
-    S.fits = (long long)local + total <= region;
+    S.fits = fits;
     group_base[tgs_group_id()] = base;
-    if (!S.fits) {
+    if (!fits) {
       status[1] = 1;
       if (sticky) *sticky = 1;
     }

@@ -9,6 +9,20 @@ Seed points: points_touch.npy [M,3], points_colors.npy [M,3] in 0..255
 (utils/create_point_cloud_from_touches.py:243-244).  Poses are centred and scaled by 1/max|t|
 and depths by the same factor (legacy/dataparser_tactile.py:222-235,306,310).
 
+Uncertainty units -- UNVERIFIED-PRIOR.  The fork that loads ``uncertainty_file_path`` is absent from
+/root/reference (only the writer is there: utils/add_depth_file_path_to_transforms.py:37-50 registers it
+next to ``depth_file_path``, utils/fuse_touch_vision.py:372-376 writes both with the same uint16-mm
+encoding).  ``uncertainty_scaling`` chooses what happens to the decoded map:
+  "linear"   (default) the same factor as the depth image, depth_unit_scale_factor x dataparser scale --
+             what a loader that reuses the depth reader for the second file does (the in-tree
+             dataparser has exactly one such reader, legacy/dataparser_tactile.py:159-162,301-312);
+  "variance" the square of that factor (the map is a variance of a depth in metres,
+             utils/fuse_touch_vision.py:76-202; dimensionally consistent with residual^2 / U);
+  "none"     the decoded metres^2 values as stored.
+The choice is recorded by the trainer in config.json (``Scene.describe()``) and used identically by
+the nerfstudio plugin's dataparser (nerfstudio_plugin.py).  ``ModelConfig.depth_eps`` is in the
+units of the scaled map.
+
 Real-world evaluation (the reference exports IS_REAL_WORLD=True before run_eval,
 scripts/train_bunny_real.sh:54, and its aggregator then averages results.gt_depth_mse /
 gt_object_depth_mse, experiment_utils/get_results.py:47-51): with ``real_world`` set (default: the
@@ -36,11 +50,25 @@ def _read_rgb(path: str) -> np.ndarray:
     return np.asarray(Image.open(path).convert("RGB"), dtype=np.float32) / 255.0
 
 
+UNCERTAINTY_SCALINGS = ("linear", "variance", "none")
+
+
+def uncertainty_factor(scaling: str, depth_unit_scale_factor: float, dataparser_scale: float) -> float:
+    """Factor applied to the decoded (uint16 mm -> x 1e-3) uncertainty map; see the module docstring."""
+    f = depth_unit_scale_factor * 1e3 * dataparser_scale
+    return {"linear": f, "variance": f * f, "none": 1.0}[scaling]
+
+
 class Scene:
     def __init__(self, root: str, train_split_fraction: float = 0.9, device="cuda", scale_poses: bool = True,
                  depth_unit_scale_factor: float = 1e-3, real_world: Optional[bool] = None,
-                 gt_depth_dir: str = "realsense_depths", object_mask_dir: str = "touch_depth"):
+                 gt_depth_dir: str = "realsense_depths", object_mask_dir: str = "touch_depth",
+                 uncertainty_scaling: str = "linear"):
         self.root = root
+        if uncertainty_scaling not in UNCERTAINTY_SCALINGS:
+            raise ValueError(f"uncertainty_scaling must be one of {UNCERTAINTY_SCALINGS}")
+        self.uncertainty_scaling = uncertainty_scaling
+        self.depth_unit_scale_factor = depth_unit_scale_factor
         if real_world is None:
             real_world = os.environ.get("IS_REAL_WORLD", "").lower() in ("1", "true", "yes")
         self.real_world = real_world
@@ -65,11 +93,9 @@ class Scene:
                 depth = torch.from_numpy(from_uint16_mm(read_png16(os.path.join(root, fr["depth_file_path"])))
                                          .astype(np.float32) * (depth_unit_scale_factor * 1e3) * self.scale)
             if "uncertainty_file_path" in fr:
-                # the map is a variance of the depth in metres (utils/fuse_touch_vision.py:76-202): in the
-                # scaled scene frame it scales with the square of the depth factor, so that the
-                # residual^2 / (uncertainty_weight * U + eps) term keeps its meaning whatever the scene size
                 unc = torch.from_numpy(from_uint16_mm(read_png16(os.path.join(root, fr["uncertainty_file_path"])))
-                                       .astype(np.float32) * (depth_unit_scale_factor * 1e3 * self.scale) ** 2)
+                                       .astype(np.float32) *
+                                       uncertainty_factor(uncertainty_scaling, depth_unit_scale_factor, self.scale))
             view = View(cam=cam, rgb=torch.from_numpy(rgb).to(device).contiguous(),
                         depth=None if depth is None else depth.to(device).contiguous(),
                         uncertainty=None if unc is None else unc.to(device).contiguous())
@@ -91,6 +117,13 @@ class Scene:
         self.i_train, self.i_eval = get_train_eval_split_fraction(names, train_split_fraction)
         self._centre = np.stack([np.array(fr["transform_matrix"], dtype=np.float64)[:3, 3] for fr in frames]).mean(0) \
             if scale_poses else np.zeros(3)
+
+    def describe(self) -> dict:
+        """What the trainer records in config.json about the units of the supervision maps."""
+        return dict(dataparser_scale=self.scale, depth_unit_scale_factor=self.depth_unit_scale_factor,
+                    uncertainty_scaling=self.uncertainty_scaling,
+                    uncertainty_factor=uncertainty_factor(self.uncertainty_scaling, self.depth_unit_scale_factor,
+                                                          self.scale))
 
     def seed_points(self) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
         """points_touch.npy / points_colors.npy, moved into the scaled scene frame."""

@@ -377,8 +377,9 @@ class DepthGaussianSplattingModel:
             v.valid_count()
             b = ops.IntersectBudget()
             ops.project_bin_sort(v.cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, b)
-            need = max(need, b.last_n)
+            need = max(need, b.last_need)   # capacity under the per-XCD split, not the plain pair count
         self.budget = ops.IntersectBudget(capacity=int(need * headroom) + 4096, sync=False)
+        self.budget.sticky_word(p.flat.device)   # allocated eagerly, outside the captured region
         opt.use_device_bias_corr = True
         opt.upload_bias_corr()
         torch.cuda.synchronize()

@@ -55,8 +55,10 @@ class IntersectBudget:
         self.sync = sync and not speculative
         self.speculative = speculative
         self.growth = growth
-        self.last_status = None  # device int32[2] of the most recent frame
-        self.last_n = None
+        self.last_status = None  # device int32[2] of the most recent frame: {#intersections, overflow}
+        self.last_status4 = None  # ... and the full word {.., .., required capacity, reserved}
+        self.last_n = None       # #intersections of the last frame that was read back
+        self.last_need = None    # capacity that frame needs under the per-XCD split (>= last_n; tgs.h)
         self.sticky = None       # device int32[1], allocated on first use
 
     def sticky_word(self, device):
@@ -67,6 +69,10 @@ class IntersectBudget:
         if self.sync:
             return None
         if self.sticky is None:
+            if torch.cuda.is_current_stream_capturing():
+                # allocated inside a capture the word would live in the graph's pool and its zero-fill
+                # would be a graph node: every replay would forget an earlier overflow
+                raise RuntimeError("allocate the sticky overflow word (budget.sticky_word(device)) before graph capture")
             self.sticky = torch.zeros(1, dtype=torch.int32, device=device)
         return self.sticky
 
@@ -80,7 +86,11 @@ class IntersectBudget:
         earlier frame of a ``sync=False`` budget); raises on overflow.  Returns #intersections."""
         if self.last_status is None:
             return None
-        n, ovf = self.last_status.tolist()
+        if self.last_status4 is not None:
+            n, ovf, need, _ = self.last_status4.tolist()
+            self.last_need = max(n, need)
+        else:
+            n, ovf = self.last_status.tolist()
         self.last_n = n
         if self.sticky is not None and int(self.sticky.item()) != 0:
             ovf = 1
@@ -123,8 +133,8 @@ def bin_sort(cam: Camera, splats, budget: Optional[IntersectBudget] = None):
     group_base = torch.empty(max(G, 1), dtype=torch.int32, device=dev)
     tile_start = torch.empty(T + 1, dtype=torch.int32, device=dev)
     nc = lib.tgs_tile_counter_len(cam.W, cam.H)
-    counters = torch.empty(nc + 2, dtype=torch.int32, device=dev)   # per-XCD tile counters + sub-list starts | status
-    tile_cursor, status = counters[:nc], counters[nc:]
+    counters = torch.empty(nc + 4, dtype=torch.int32, device=dev)   # per-XCD tile counters + sub-list starts | status[4]
+    tile_cursor, status, status4 = counters[:nc], counters[nc:nc + 2], counters[nc:]
     # block -> tile schedule of K6 / K7 (tiles dealt to the XCDs in granules of 8, longest list first inside each XCD); it rides on the
     # tile_start tensor object so that the (tile_start, sorted_gid) pair keeps its meaning for callers
     tile_order = torch.empty(lib.tgs_tile_order_len(cam.W, cam.H), dtype=torch.int32, device=dev)
@@ -137,10 +147,11 @@ def bin_sort(cam: Camera, splats, budget: Optional[IntersectBudget] = None):
                                ptr(tile_cursor), ptr(sorted_gid), ptr(tile_order), cap, ptr(scratch),
                                ptr(status), ptr(budget.sticky_word(dev)), _stream()), "tgs_bin_sort")
         budget.last_status = status
+        budget.last_status4 = status4
         if not budget.sync:
             break
-        n, ovf = status.tolist()
-        budget.last_n = n
+        n, ovf, need, _ = status4.tolist()
+        budget.last_n, budget.last_need = n, max(n, need)
         if not ovf:
             break
         cap = int(n * budget.growth) + 1024
@@ -188,8 +199,8 @@ def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_d
     group_base = torch.empty(max(G, 1), dtype=torch.int32, device=dev)
     tile_start = torch.empty(T + 1, dtype=torch.int32, device=dev)
     nc = lib.tgs_tile_counter_len(cam.W, cam.H)
-    counters = torch.empty(nc + 2, dtype=torch.int32, device=dev)   # per-XCD tile counters + sub-list starts | status
-    tile_cursor, status = counters[:nc], counters[nc:]
+    counters = torch.empty(nc + 4, dtype=torch.int32, device=dev)   # per-XCD tile counters + sub-list starts | status[4]
+    tile_cursor, status, status4 = counters[:nc], counters[nc:nc + 2], counters[nc:]
     # block -> tile schedule of K6 / K7 (tiles dealt to the XCDs in granules of 8, longest list first inside each XCD); it rides on the
     # tile_start tensor object so that the (tile_start, sorted_gid) pair keeps its meaning for callers
     tile_order = torch.empty(lib.tgs_tile_order_len(cam.W, cam.H), dtype=torch.int32, device=dev)
@@ -215,10 +226,11 @@ def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_d
                                                   ptr(colors.tag_word), colors.tag, _stream()),
                   "tgs_project_bin_sort_colors")
         budget.last_status = status
+        budget.last_status4 = status4
         if not budget.sync:
             break
-        n, ovf = status.tolist()
-        budget.last_n = n
+        n, ovf, need, _ = status4.tolist()
+        budget.last_n, budget.last_need = n, max(n, need)
         if not ovf:
             break
         cap = int(n * budget.growth) + 1024

@@ -95,6 +95,8 @@ def main(argv=None):
     ap.add_argument("--depth-loss-type", type=str, default="DEPTH_UNCERTAINTY_WEIGHTED_LOSS", choices=DEPTH_LOSS_TYPES)
     ap.add_argument("--uncertainty-weight", "--uncertainty_weight", type=float, default=1.0, dest="uncertainty_weight")
     ap.add_argument("--train-split-fraction", type=float, default=0.9)
+    ap.add_argument("--uncertainty-scaling", type=str, default="linear", choices=("linear", "variance", "none"),
+                    help="units of the uncertainty map in the scaled scene (dataset.py docstring; UNVERIFIED-PRIOR)")
     ap.add_argument("--max-num-iterations", type=int, default=30000)
     ap.add_argument("--steps-per-save", type=int, default=2000)
     ap.add_argument("--steps-per-eval", type=int, default=500)
@@ -128,7 +130,7 @@ def main(argv=None):
         scene_name = f"synthetic_{N}_{W}x{H}"
     else:
         from .dataset import Scene
-        scene = Scene(args.data, args.train_split_fraction, dev)
+        scene = Scene(args.data, args.train_split_fraction, dev, uncertainty_scaling=args.uncertainty_scaling)
         views, i_train, i_eval = scene.views, list(scene.i_train), list(scene.i_eval)
         params = init_params(args.num_gaussians, K, dev, scene.seed_points(), seed=args.seed)
         scene_name = os.path.basename(os.path.normpath(args.data))
@@ -147,7 +149,8 @@ def main(argv=None):
     if dp.rank == 0:
         os.makedirs(run_dir, exist_ok=True)
         with open(os.path.join(run_dir, "config.json"), "w") as f:
-            json.dump(dict(vars(args), model=dataclasses.asdict(cfg), world_size=dp.world), f, indent=2)
+            json.dump(dict(vars(args), model=dataclasses.asdict(cfg), world_size=dp.world,
+                           scene=None if args.synthetic else scene.describe()), f, indent=2)
     if not args.densify and not args.sync_budget and (dp.world == 1 or model.optimizer.can_gather_sh()):
         # no per-step host sync; an overflow is detected late and replayed (data parallel: the ranks
         # agree on it on the device and replay the same steps)
@@ -160,13 +163,18 @@ def main(argv=None):
         # single process: tell the step which view follows (colour prefetch, model.train_step)
         nxt = None if dp.active else train_views[dp.views_for_step(step + 1, len(train_views))]
         model.train_step(view, dp if dp.active else None, next_view=nxt)
-        if dp.rank == 0 and (step + 1) % args.steps_per_eval == 0:
+        at_eval = (step + 1) % args.steps_per_eval == 0
+        at_save = (step + 1) % args.steps_per_save == 0 or step + 1 == args.max_num_iterations
+        if at_eval or at_save:
+            # EVERY rank drains its pending overflow verdicts at the same steps: a drain that finds an agreed
+            # overflow replays steps, collectives included, so a rank-0-only flush would leave the ranks'
+            # collectives unmatched (and break "every rank inspects step s - L at step s")
             model.flush()
+        if dp.rank == 0 and at_eval:
             loss = model.loss_from(model.last["tile_loss"], model.last["ssim_sum"], view)
             print(f"step {step + 1}: " + " ".join(f"{k}={float(v):.5f}" for k, v in loss.items()) +
                   f"  {(step + 1 - 0) / (time.time() - t0):.1f} it/s", flush=True)
-        if dp.rank == 0 and ((step + 1) % args.steps_per_save == 0 or step + 1 == args.max_num_iterations):
-            model.flush()
+        if dp.rank == 0 and at_save:
             torch.save(model.state_dict(), os.path.join(run_dir, f"step-{step + 1:09d}.ckpt"))
     model.flush()
     if dp.world > 1:
