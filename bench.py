@@ -158,6 +158,50 @@ def cpu_baseline(N, W, H, deg, seed, frac=None, clustered=False):
                              project_bwd=t5 - t4))
 
 
+def densify_run(N, W, H, deg, seed, dev, views, steps=600, clustered=False):
+    """The workload the reference's method actually runs for the first half of its 30 000 iterations
+    (a densifying Splatfacto), next to the steady state the headline value is quoted on:
+    the same scene and views, refinement every 100 steps from step 100 on (clone / split / cull on the
+    Splatfacto thresholds, opacity reset every 3rd refinement so that the window holds some), SH
+    degree ramp 0 -> `deg` (one band per 100 steps), sync-free intersection budget (refinements are its
+    barrier points), colour prefetch, children placed behind their parents + a full Morton re-sort every
+    4th refinement.  Everything is inside the timed window, refinements and re-sorts included."""
+    from touch_gs_amd.densify import DensifyConfig
+    from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
+    from touch_gs_amd.optim import GaussianParams
+    from touch_gs_amd.scene import synthetic_gaussians
+    P, _ = synthetic_gaussians(N, W, H, deg, seed, clustered=clustered)
+    params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
+    cfg = ModelConfig(sh_degree=deg, sh_degree_interval=100, depth_loss_mult=0.2,
+                      depth_loss_type="DEPTH_UNCERTAINTY_WEIGHTED_LOSS", uncertainty_weight=1.0, spatial_sort=True,
+                      resort_every_refines=4)
+    m = DepthGaussianSplattingModel(cfg, params)
+    m.spatial_sort()
+    m.enable_densification(DensifyConfig(warmup_length=100, refine_every=100, reset_alpha_every=3,
+                                         max_gaussians=int(1.6 * N)))
+    m.enable_speculative_budget()
+    n0 = m.params.N
+    for i in range(20):   # warm-up (no refinement before step 100)
+        m.train_step(views[i % len(views)], next_view=views[(i + 1) % len(views)])
+    m.flush()
+    torch.cuda.synchronize()
+    refines, t0 = [], time.perf_counter()
+    for i in range(20, 20 + steps):
+        m.train_step(views[i % len(views)], next_view=views[(i + 1) % len(views)])
+        if getattr(m, "last_refine", None) is not None and (not refines or refines[-1] is not m.last_refine):
+            refines.append(m.last_refine)
+    m.flush()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": round(steps / dt, 2), "unit": "iters/s", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
+            "gaussians_start": n0, "gaussians_end": m.params.N, "refinements": len(refines),
+            "cloned": sum(r["cloned"] for r in refines), "split": sum(r["split"] for r in refines),
+            "culled": sum(r["culled"] for r in refines), "opacity_resets": sum(int(r["opacity_reset"]) for r in refines),
+            "replayed_steps": getattr(m, "speculative_replays", 0), "final_sh_degree": m.active_sh_degree(),
+            "workload": "same scene and views; refine every 100 steps from step 100, SH ramp 1 band / 100 steps, "
+                        "sync-free budget, colour prefetch; refinements and re-sorts inside the timed window"}
+
+
 def self_launch(n_ranks: int) -> int:
     """`python bench.py --gpus N` with N > 1 and no rank environment: start the N ranks through
     torch.distributed.run on 127.0.0.1 (a free port), pass their chatter to stderr and print exactly
@@ -197,6 +241,8 @@ def main():
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-densify-run", action="store_true",
+                    help="skip the densifying-training measurement reported as `train_densify` (N = 1 only)")
     ap.add_argument("--ssim-pipeline", action="store_true",
                     help="SSIM on a second stream pipelined by image bands behind K7 (measured slower; off by default)")
     ap.add_argument("--no-color-prefetch", action="store_true",
@@ -422,6 +468,14 @@ def main():
             out["dp_exchange"]["replicas_identical"] = replicas_identical
             if comm:
                 out["dp_exchange"].update(comm)
+        if dp.world == 1 and not args.no_densify_run:
+            try:
+                del sp, partials, rgb, dacc
+                torch.cuda.empty_cache()
+                out["train_densify"] = densify_run(N, W, H, deg, args.seed, dev, views, clustered=clustered,
+                                                   steps=min(600, max(args.steps * 3, 150)))
+            except Exception as ex:  # noqa: BLE001 -- a secondary measurement never fails the headline line
+                out["train_densify"] = {"value": None, "error": repr(ex)}
         if dp.world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(N, W, H, deg, args.seed, clustered=clustered)

@@ -97,10 +97,14 @@ size_t tgs_sort_scratch_bytes(int64_t capacity);
  *     + `spherical_harmonics`; INRIA preprocess, App. A.1; spec App. B.1-B.5).
  * in : means[N,3] log_scales[N,3] quats[N,4] (w,x,y,z un-normalised) opac_logit[N]
  *      sh[N,sh_stride,3] (NULL or sh_deg<0 => colours taken from `colors_in`[N,3] or zero)
- * out: splats[N,12] = {x, y, depth, opacity, conic a, b, c, r, g, b, rect, 0} where rect (uint32
- *      bits) = x0 | y0<<8 | w<<16 | h<<24 is the Gaussian's tile rectangle: the App. B.4 rect
- *      intersected with the tiles in which alpha can reach 1/255 (output preserving; 0 = none);
+ * out: splats[N,12] = {x - 16 x0, y - 16 y0, depth, opacity, conic a, b, c, r, g, b, rect, 0} where
+ *      rect (uint32 bits) = x0 | y0<<8 | w<<16 | h<<24 is the Gaussian's tile rectangle: the App. B.4
+ *      rect intersected with the tiles in which alpha can reach 1/255 (output preserving; 0 = none);
  *      culled Gaussians have conic 0.  Image sides are limited to 4080 px (255 tiles).
+ *      Slots 0, 1 hold the screen position (App. B.2, pixel units) RELATIVE to the origin of the tile
+ *      rect, evaluated in compensated fp32 arithmetic: ~1e-5 px instead of the 2.4e-4 px ulp of an
+ *      absolute 4K coordinate (absolute position = slot + 16 * {x0, y0}).  Callers that build records
+ *      themselves (tgs_bin_sort + tgs_rasterize_*) follow the same convention.
  *      radii[N] (may be NULL) = the App. B.3 3-sigma pixel radius, 0 if culled. */
 int tgs_project_fwd(const TgsCamera* cam /*[host]*/, int N, const float* means,
                     const float* log_scales, const float* quats, const float* opac_logit,

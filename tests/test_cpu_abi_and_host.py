@@ -299,6 +299,73 @@ def test_densify_screen_size_rules_cpu():
     assert info["culled"] == 2 and info["cloned"] == 3 and info["split"] == 0      # culled: 7, 6; clones: 0, 1, 2
 
 
+def test_refine_places_children_behind_their_parents_cpu():
+    """DensityController.refine builds the refined store with one gather: survivors keep their relative
+    order (values and Adam moments bit for bit), a clone sits directly behind its source, the
+    n_split_samples replacements of a split parent occupy its place, new rows start with zero moments,
+    and the split samples are mean + R (noise * scale) with scale / 1.6 for the documented noise
+    assignment -- so a Morton-ordered buffer stays ordered without the argsort the trainer used to run."""
+    from touch_gs_amd.densify import DensifyConfig, DensityController, quat_to_rotmat
+    from touch_gs_amd.optim import FusedAdam, GaussianParams
+    g = torch.Generator().manual_seed(3)
+    N, K = 600, 4
+    vals = dict(means=torch.randn(N, 3, generator=g), log_scales=torch.randn(N, 3, generator=g) * 0.5 - 4,
+                quats=torch.randn(N, 4, generator=g), opac_logit=torch.randn(N, generator=g) * 2,
+                sh=torch.randn(N, K, 3, generator=g))
+    gp = GaussianParams.from_tensors(*[vals[k] for k in GaussianParams.NAMES])
+    opt = FusedAdam(gp, dict(means=1e-4, log_scales=1e-3, quats=1e-3, opac_logit=1e-2, sh_dc=1e-3, sh_rest=1e-4))
+    opt.exp_avg.copy_(torch.randn(gp.flat.shape, generator=g))
+    opt.exp_avg_sq.copy_(torch.rand(gp.flat.shape, generator=g))
+    opt.t = 7
+    cfg = DensifyConfig(warmup_length=0, refine_every=10, densify_grad_thresh=0.5, densify_size_thresh=0.02,
+                        reset_alpha_every=0, n_split_samples=2)
+    dc = DensityController(cfg, N, "cpu")
+    dc.grad_norm_sum = torch.rand(N, generator=g) * 2
+    dc.vis_count = torch.ones(N)
+    step = 10
+    hot = dc.grad_norm_sum > cfg.densify_grad_thresh
+    big = torch.exp(gp.log_scales).max(-1).values > cfg.densify_size_thresh
+    cull = torch.sigmoid(gp.opac_logit) < cfg.cull_alpha_thresh
+    split, clone = hot & big & ~cull, hot & ~big & ~cull
+    keep = ~cull & ~split
+    old = {k: getattr(gp, k).clone() for k in GaussianParams.NAMES}
+    m_old = {k: v.clone() for k, v in GaussianParams.views_of(opt.exp_avg, N, K).items()}
+    new_p, new_o, info = dc.refine(gp, opt, step)
+    S = cfg.n_split_samples
+    assert info["cloned"] == int(clone.sum()) and info["split"] == int(split.sum()) and info["culled"] == int(cull.sum())
+    assert new_p.N == int(keep.sum() + clone.sum() + S * split.sum()) and new_o.t == 7
+    m_new = GaussianParams.views_of(new_o.exp_avg, new_p.N, K)
+    noise = torch.randn(S * int(split.sum()), 3, generator=torch.Generator().manual_seed(1_000_003 * (step + 1)))
+    pos, j_split = 0, 0
+    for i in range(N):
+        if keep[i]:
+            for k in GaussianParams.NAMES:
+                assert torch.equal(getattr(new_p, k)[pos], old[k][i]) and torch.equal(m_new[k][pos], m_old[k][i])
+            pos += 1
+            if clone[i]:
+                for k in GaussianParams.NAMES:
+                    assert torch.equal(getattr(new_p, k)[pos], old[k][i]) and not m_new[k][pos].any()
+                pos += 1
+        elif split[i]:
+            R = quat_to_rotmat(old["quats"][i:i + 1])[0]
+            for s_ in range(S):
+                nz = noise[s_ * int(split.sum()) + j_split]
+                want = old["means"][i] + R @ (nz * torch.exp(old["log_scales"][i]))
+                assert torch.allclose(new_p.means[pos], want, atol=1e-6)
+                assert torch.allclose(new_p.log_scales[pos], old["log_scales"][i] - math.log(1.6), atol=1e-6)
+                assert torch.equal(new_p.quats[pos], old["quats"][i]) and not m_new["means"][pos].any()
+                pos += 1
+            j_split += 1
+    assert pos == new_p.N
+    # the statistics restart at the new size
+    assert dc.vis_count.shape[0] == new_p.N and not dc.vis_count.any()
+    # an overflowed frame (guard[1] != 0) contributes nothing to the statistics
+    dc.accumulate(torch.ones(new_p.N, 2), torch.ones(new_p.N, dtype=torch.int32), 64, 64, guard=torch.tensor([5, 1], dtype=torch.int32))
+    assert not dc.vis_count.any() and not dc.grad_norm_sum.any() and not dc.max_radius.any()
+    dc.accumulate(torch.ones(new_p.N, 2), torch.ones(new_p.N, dtype=torch.int32), 64, 64, guard=torch.tensor([5, 0], dtype=torch.int32))
+    assert dc.vis_count.sum() == new_p.N
+
+
 def test_morton_order_and_permute_cpu():
     """optim.morton_order sorts along a 3-D Z-order curve (neighbours in memory are neighbours in space)
     and GaussianParams.permute_ moves every segment of every flat buffer consistently."""

@@ -439,23 +439,21 @@ def test_step_graph_replay_equals_eager_steps(dev):
     assert torch.equal(graphed.params.flat, eager.params.flat)
 
 
-def test_trainer_on_disk_dataset_in_reference_format(dev, tmp_path):
-    """End to end on the on-disk contract the reference's plumbing produces (SURVEY App. D):
-    transforms.json (fl_x.., per-frame OpenGL camera->world, depth_file_path, uncertainty_file_path),
-    8-bit RGB PNGs, 16-bit millimetre depth / uncertainty PNGs, touch seed points -> Scene loader ->
-    trainer -> eval.json + render dump."""
+def _write_reference_scene(root, dev, N, W, H, deg, n_views=6, seed=11):
+    """A scene directory in the format the reference's plumbing leaves behind:
+    transforms.json with per-frame file_path / OpenGL camera->world transform_matrix / depth_file_path /
+    uncertainty_file_path (utils/add_depth_file_path_to_transforms.py:37-50), 8-bit RGB PNGs, 16-bit
+    millimetre depth + uncertainty PNGs (utils/fuse_touch_vision.py:372-376), touch seed points
+    (utils/create_point_cloud_from_touches.py:243-244).  Returns the camera centres."""
     import json, os
     from PIL import Image
-    from touch_gs_amd import plumbing, train
-    from touch_gs_amd.dataset import Scene
+    from touch_gs_amd import plumbing
     from touch_gs_amd.scene import make_view
-    N, W, H, deg = 3000, 96, 64, 1
-    root = tmp_path / "scene"
     for d in ("images", "fused_output_dir", "fused_output_dir_uncertainty"):
         os.makedirs(root / d)
     frames, centres = [], []
-    for i in range(6):
-        v = make_view(N, W, H, deg, 11, dev, view=i, n_views=6)
+    for i in range(n_views):
+        v = make_view(N, W, H, deg, seed, dev, view=i, n_views=n_views)
         Image.fromarray((v.rgb.clamp(0, 1) * 255).to(torch.uint8).cpu().numpy()).save(root / "images" / f"{i}.png")
         plumbing.write_png16(str(root / "fused_output_dir" / f"{i}.png"), plumbing.to_uint16_mm(v.depth.cpu().numpy().astype(np.float64)))
         plumbing.write_png16(str(root / "fused_output_dir_uncertainty" / f"{i}.png"),
@@ -469,6 +467,22 @@ def test_trainer_on_disk_dataset_in_reference_format(dev, tmp_path):
     rng = np.random.default_rng(0)
     np.save(root / "points_touch.npy", rng.uniform(-0.5, 0.5, (200, 3)) + np.array([0, 0, 4.0]))
     np.save(root / "points_colors.npy", rng.uniform(0, 255, (200, 3)))
+    return centres
+
+
+def test_trainer_on_disk_dataset_in_reference_format(dev, tmp_path):
+    """End to end on the on-disk contract the reference's plumbing produces (SURVEY App. D):
+    transforms.json (fl_x.., per-frame OpenGL camera->world, depth_file_path, uncertainty_file_path),
+    8-bit RGB PNGs, 16-bit millimetre depth / uncertainty PNGs, touch seed points -> Scene loader ->
+    trainer -> eval.json + render dump."""
+    import json, os
+    from PIL import Image
+    from touch_gs_amd import plumbing, train
+    from touch_gs_amd.dataset import Scene
+    from touch_gs_amd.scene import make_view
+    N, W, H, deg = 3000, 96, 64, 1
+    root = tmp_path / "scene"
+    centres = _write_reference_scene(root, dev, N, W, H, deg)
 
     sc = Scene(str(root), train_split_fraction=0.8, device=dev)
     assert len(sc.views) == 6 and len(sc.i_train) == 5 and len(sc.i_eval) == 1
@@ -809,12 +823,128 @@ def _nerfstudio_stub():
             t = lambda v: torch.tensor([[v]])
             self.fx, self.fy, self.cx, self.cy, self.width, self.height = t(fx), t(fy), t(cx), t(cy), t(width), t(height)
 
+    # -- data side: a stand-in for nerfstudio's own nerfstudio-data parser (what the plugin's parser extends):
+    #    frames sorted by file_path, train/eval split by fraction, poses centred and scaled to +-1, the depth
+    #    file list + unit factor in metadata (the behaviour of reference legacy/dataparser_tactile.py:150-312)
+    @dataclasses.dataclass
+    class NerfstudioDataParserConfig:
+        _target: type = None
+        data: str = None
+        depth_unit_scale_factor: float = 1e-3
+        train_split_fraction: float = 0.9
+        load_3D_points: bool = False
+
+        def setup(self):
+            return self._target(self)
+
+    class DataparserOutputs(Cfg):
+        pass
+
+    class BatchCameras:
+        def __init__(self, c2w, fx, fy, cx, cy, W, H):
+            n = c2w.shape[0]
+            self.camera_to_worlds = c2w
+            f = lambda v: torch.full((n, 1), float(v))
+            self.fx, self.fy, self.cx, self.cy = f(fx), f(fy), f(cx), f(cy)
+            self.width, self.height = torch.full((n, 1), W), torch.full((n, 1), H)
+
+        def __getitem__(self, i):
+            return Cameras(self.camera_to_worlds[i:i + 1], float(self.fx[i]), float(self.fy[i]), float(self.cx[i]),
+                           float(self.cy[i]), int(self.width[i]), int(self.height[i]))
+
+    class Nerfstudio:
+        def __init__(self, config):
+            self.config = config
+
+        def get_dataparser_outputs(self, split="train"):
+            return self._generate_dataparser_outputs(split)
+
+        def _generate_dataparser_outputs(self, split="train"):
+            import json, math, os
+            root = str(self.config.data)
+            meta = json.load(open(os.path.join(root, "transforms.json")))
+            frames = sorted(meta["frames"], key=lambda fr: fr["file_path"])
+            n = len(frames)
+            n_train = math.ceil(n * self.config.train_split_fraction)
+            i_train = np.linspace(0, n - 1, n_train, dtype=int)
+            idx = i_train if split == "train" else np.setdiff1d(np.arange(n), i_train)
+            c2w = torch.tensor(np.stack([np.asarray(fr["transform_matrix"], np.float64) for fr in frames]))
+            c2w[:, :3, 3] -= c2w[:, :3, 3].mean(0)
+            scale = 1.0 / float(c2w[:, :3, 3].abs().max())
+            c2w[:, :3, 3] *= scale
+            sel = [frames[i] for i in idx]
+            return DataparserOutputs(
+                image_filenames=[os.path.join(root, fr["file_path"]) for fr in sel],
+                cameras=BatchCameras(c2w[idx][:, :3, :].float(), meta["fl_x"], meta["fl_y"], meta["cx"], meta["cy"], meta["w"], meta["h"]),
+                dataparser_scale=scale,
+                metadata={"depth_filenames": [os.path.join(root, fr["depth_file_path"]) for fr in sel] if "depth_file_path" in sel[0] else None,
+                          "depth_unit_scale_factor": self.config.depth_unit_scale_factor})
+
+    class InputDataset(torch.utils.data.Dataset):
+        exclude_batch_keys_from_device = ["image", "mask"]
+
+        def __init__(self, dataparser_outputs, scale_factor=1.0):
+            self._dataparser_outputs = dataparser_outputs
+            self.metadata = dataparser_outputs.metadata
+            self.cameras = dataparser_outputs.cameras
+
+        def __len__(self):
+            return len(self._dataparser_outputs.image_filenames)
+
+        def get_metadata(self, data):
+            return {}
+
+        def __getitem__(self, i):
+            from PIL import Image
+            img = torch.from_numpy(np.asarray(Image.open(self._dataparser_outputs.image_filenames[i]).convert("RGB"),
+                                              dtype=np.float32) / 255.0)
+            data = {"image_idx": i, "image": img}
+            data.update(self.get_metadata(data))
+            return data
+
+    class FullImageDatamanager:
+        dataset_type = InputDataset
+
+        def __class_getitem__(cls, item):
+            return type(f"FullImageDatamanager[{item.__name__}]", (cls,), {"dataset_type": item})
+
+        def __init__(self, config):
+            self.config = config
+            self.train_dataparser_outputs = config.dataparser.setup().get_dataparser_outputs("train")
+            self.train_dataset = self.dataset_type(self.train_dataparser_outputs)
+
+        def next_train(self, step):
+            i = step % len(self.train_dataset)
+            return self.train_dataset.cameras[i], self.train_dataset[i]
+
+    class FullImageDatamanagerConfig(Cfg):
+        def setup(self):
+            return self._target(self)
+
+    import enum
+
+    class TrainingCallbackLocation(enum.Enum):
+        BEFORE_TRAIN_ITERATION = 1
+        AFTER_TRAIN_ITERATION = 2
+
+    class TrainingCallback:
+        def __init__(self, where_to_run, func, update_every_num_iters=None, iters=None, args=None, kwargs=None):
+            self.where_to_run, self.func, self.args, self.kwargs = where_to_run, func, args or [], kwargs or {}
+
+        def run_callback_at_location(self, step, location):
+            if location in self.where_to_run:
+                self.func(*self.args, **self.kwargs, step=step)
+
     layout = {"nerfstudio.configs.base_config": dict(ViewerConfig=Cfg),
+              "nerfstudio.data.datasets.base_dataset": dict(InputDataset=InputDataset),
+              "nerfstudio.engine.callbacks": dict(TrainingCallback=TrainingCallback, TrainingCallbackLocation=TrainingCallbackLocation),
               "nerfstudio.engine.trainer": dict(TrainerConfig=Cfg),
               "nerfstudio.plugins.types": dict(MethodSpecification=Cfg),
               "nerfstudio.cameras.cameras": dict(Cameras=Cameras),
-              "nerfstudio.data.datamanagers.full_images_datamanager": dict(FullImageDatamanagerConfig=Cfg),
-              "nerfstudio.data.dataparsers.nerfstudio_dataparser": dict(NerfstudioDataParserConfig=Cfg),
+              "nerfstudio.data.datamanagers.full_images_datamanager": dict(FullImageDatamanagerConfig=FullImageDatamanagerConfig,
+                                                                           FullImageDatamanager=FullImageDatamanager),
+              "nerfstudio.data.dataparsers.nerfstudio_dataparser": dict(NerfstudioDataParserConfig=NerfstudioDataParserConfig,
+                                                                        Nerfstudio=Nerfstudio),
               "nerfstudio.engine.optimizers": dict(AdamOptimizerConfig=Cfg),
               "nerfstudio.engine.schedulers": dict(ExponentialDecaySchedulerConfig=Cfg),
               "nerfstudio.models.base_model": dict(Model=Model, ModelConfig=NSModelConfig),
@@ -877,6 +1007,98 @@ def test_nerfstudio_plugin_shell_executes_against_a_stub(dev):
             losses.append(float(loss))
         assert losses[-1] < 0.95 * losses[0], losses
         assert "psnr" in model.get_metrics_dict(model.get_outputs(cams), batch)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+        importlib.reload(plug)
+
+
+def test_nerfstudio_plugin_trains_with_touch_supervision_from_disk(dev, tmp_path):
+    """The plugin's data path and refinement callbacks, executed against the stand-in API on a scene
+    directory in the reference's format: the method spec's datamanager (FullImageDatamanager[TactileDepthDataset]
+    over TactileDataParser) delivers batch["depth_image"] and batch["uncertainty"] in scene units (uint16 mm x
+    1e-3 x dataparser scale, legacy/dataparser_tactile.py:65-66,229-235,301-312), so the tactile loss is
+    applied (depth_loss > 0); a nerfstudio-style loop that runs the model's training callbacks around
+    every iteration densifies the Gaussians (N changes, the Adam states follow)."""
+    import importlib, sys
+    import touch_gs_amd.nerfstudio_plugin as plug
+    from touch_gs_amd.scene import make_view
+    N, W, H, deg = 3000, 96, 64, 1
+    root = tmp_path / "scene"
+    _write_reference_scene(root, dev, N, W, H, deg)
+    mods, Cameras = _nerfstudio_stub()
+    saved = {k: sys.modules.get(k) for k in mods}
+    sys.modules.update(mods)
+    try:
+        plug = importlib.reload(plug)
+        spec = plug.depth_gaussian_splatting
+        dmc = spec.config.pipeline.datamanager
+        dmc.dataparser.data = str(root)
+        dmc.dataparser.train_split_fraction = 0.8
+        dm = dmc.setup()
+        assert type(dm.train_dataset).__name__ == "TactileDepthDataset" and len(dm.train_dataset) == 5
+        outs = dm.train_dataparser_outputs
+        assert outs.metadata["uncertainty_filenames"][1].endswith("fused_output_dir_uncertainty/1.png")
+        cam0, batch0 = dm.next_train(0)
+        assert batch0["depth_image"].shape == (H, W, 1) and batch0["uncertainty"].shape == (H, W, 1)
+        v0 = make_view(N, W, H, deg, 11, dev, view=0, n_views=6)
+        sc = outs.dataparser_scale
+        assert torch.allclose(batch0["depth_image"][..., 0], v0.depth.cpu() * sc, atol=1e-3 * sc + 1e-6)   # mm quantisation
+        assert torch.allclose(batch0["uncertainty"][..., 0], v0.uncertainty.cpu() * sc, atol=1e-3 * sc + 1e-6)
+        assert (batch0["depth_image"] == 0).float().mean() > 0.2          # unsupervised pixels stay 0
+
+        mc = spec.config.pipeline.model
+        mc.sh_degree, mc.sh_degree_interval = deg, 4
+        mc.depth_loss_mult, mc.uncertainty_weight = 0.005, 0.01          # scripts/train_bunny_real.sh:52
+        mc.warmup_length, mc.refine_every, mc.densify_grad_thresh = 4, 4, 1e-7   # refine early, on any gradient
+        seeds = torch.from_numpy(np.load(root / "points_touch.npy")).float()
+        centre = torch.tensor(np.stack([np.asarray(f["transform_matrix"])[:3, 3] for f in
+                                        __import__("json").load(open(root / "transforms.json"))["frames"]]).mean(0)).float()
+        pts = (torch.cat([seeds, (torch.rand(2000, 3) - 0.5) * 3 + torch.tensor([0, 0, 4.0])]) - centre) * sc
+        model = mc.setup(scene_box=None, num_train_data=5, seed_points=(pts, torch.rand(pts.shape[0], 3) * 255))
+        groups = model.get_param_groups()
+        opts = {k: torch.optim.Adam(v, lr=spec.config.optimizers[k]["optimizer"].lr * 10, eps=1e-15) for k, v in groups.items()}
+
+        class Attrs:   # TrainingCallbackAttributes: the callbacks reach the optimizers through .optimizers.optimizers
+            class optimizers:
+                pass
+        Attrs.optimizers.optimizers = opts
+        callbacks = model.get_training_callbacks(Attrs)
+        Loc = sys.modules["nerfstudio.engine.callbacks"].TrainingCallbackLocation
+        n0, depth_losses, seen_n, degs = model.gaussians.num_points, [], set(), []
+        for step in range(10):
+            for cb in callbacks:
+                cb.run_callback_at_location(step, Loc.BEFORE_TRAIN_ITERATION)
+            cam, batch = dm.next_train(step)
+            batch = {k: (v.to(dev) if hasattr(v, "to") else v) for k, v in batch.items()}
+            out = model.get_outputs(cam)
+            ld = model.get_loss_dict(out, batch)
+            depth_losses.append(float(ld["depth_loss"]))
+            degs.append(model.gaussians.active_sh_degree())
+            for o in opts.values():
+                o.zero_grad()
+            sum(ld.values()).backward()
+            for o in opts.values():
+                o.step()
+            for cb in callbacks:
+                cb.run_callback_at_location(step, Loc.AFTER_TRAIN_ITERATION)
+            seen_n.add(model.gaussians.num_points)
+        assert all(d > 0 for d in depth_losses), depth_losses          # the touch supervision reaches the loss
+        assert degs[0] == 0 and degs[-1] == 1                           # SH ramp driven by the step callback
+        info = model.refiner.last_info
+        assert info is not None and info["after"] != info["before"] and len(seen_n) > 1, (info, seen_n)
+        n1 = model.gaussians.num_points
+        assert n1 != n0
+        # the registered parameters, the optimizer's parameter list and its Adam state all follow the refinement
+        for k, o in opts.items():
+            p = model.gaussians.params[k]
+            assert p.shape[0] == n1 and o.param_groups[0]["params"][0] is p and model.gauss_params[k] is p
+            st = o.state[p]
+            assert st["exp_avg"].shape == p.shape and st["exp_avg_sq"].shape == p.shape
+        assert len({id(q) for o in opts.values() for q in o.state}) == 6     # no stale state entries
     finally:
         for k, v in saved.items():
             if v is None:

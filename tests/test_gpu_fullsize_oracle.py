@@ -62,7 +62,10 @@ def both(request, dev):
     # ---- oracle (fp64, normative B.4 lists) ----
     R = RefC("f64")
     n64 = lambda t: t.double().numpy()
-    cb = R.cam_block(np.asarray(cam.viewmat, np.float64).reshape(4, 4), cam.fx, cam.fy, cam.cx, cam.cy, bg=cam.bg)
+    # identical inputs: the C ABI takes the camera as fp32 (TgsCamera), so the oracle gets exactly those values
+    f32 = lambda v: float(np.float32(v))
+    cb = R.cam_block(np.asarray(cam.viewmat, np.float32).astype(np.float64).reshape(4, 4), f32(cam.fx), f32(cam.fy),
+                     f32(cam.cx), f32(cam.cy), bg=tuple(f32(c) for c in cam.bg))
     Pn = {k: n64(v) for k, v in P.items()}
     pc = R.project_fwd(Pn["means"], Pn["log_scales"], Pn["quats"], Pn["opac_logit"], Pn["sh"], deg, cb, W, H)
     g2, ts2 = R.bin_sort(pc["rect"], pc["tiles_hit"], pc["depth"], W, H)
@@ -89,19 +92,12 @@ def test_forward_matches_oracle_fullsize(both):
     er = relerr(b["rgb"], b["bf"]["rgb"], floor=1e-2)
     ed = relerr(b["depth"], b["bf"]["depth_acc"], floor=1e-2)
     eT = np.abs(b["fT"] - b["bf"]["final_T"])
-    if b["W"] <= 2048:
-        assert er[clear].max() < TOL and ed[clear].max() < TOL and eT[clear].max() < TOL, \
-            (b["name"], er[clear].max(), ed[clear].max(), eT[clear].max())
-    else:
-        # 4K: pixel coordinates up to 3840 carry an fp32 ulp of 2.4e-4 px, i.e. up to ~1e-3 relative on
-        # the alpha of a sub-pixel Gaussian -- the sum of ~100 contributions per pixel sits AT the 1e-4
-        # bar (measured: 99.8 % of the clear pixels within 1e-4, q99.9 = 1.2e-4, independent of the
-        # decision margin).  Any fp32 rasterizer shares this floor; the bound here is statistical.
-        for e, name in ((er, "rgb"), (ed, "depth"), (eT[..., None], "final_T")):
-            v = e[clear]
-            assert (v < TOL).mean() > 0.995, (b["name"], name, (v < TOL).mean())
-            assert np.quantile(v, 0.9999) < 5e-4, (b["name"], name, np.quantile(v, 0.9999))
-    assert (b["last_hip"][clear] == b["last_ref"][clear]).mean() > (0.9999 if b["W"] > 2048 else 1.0 - 1e-12)
+    # the same deterministic bound at every size, 4K included: K1 carries the screen position in compensated
+    # arithmetic relative to the Gaussian's tile rect (project.hip), so the 2.4e-4 px ulp of an absolute 4K
+    # coordinate no longer reaches the image (round 2 could only assert this statistically at 4K)
+    assert er[clear].max() < TOL and ed[clear].max() < TOL and eT[clear].max() < TOL, \
+        (b["name"], er[clear].max(), ed[clear].max(), eT[clear].max())
+    assert (b["last_hip"][clear] == b["last_ref"][clear]).mean() > 1.0 - 1e-12
     # decision-ambiguous pixels may flip one alpha_min / T_stop level contribution
     assert np.abs(b["rgb"] - b["bf"]["rgb"]).max() < 0.02
     # radius / visibility: integer decisions agree except within fp32 noise of an integer boundary
@@ -145,7 +141,7 @@ def test_gradients_match_oracle_fullsize(both):
         cos = (ref * got).sum() / np.sqrt((ref * ref).sum() * (got * got).sum())
         rel_l2 = np.sqrt(((got - ref) ** 2).sum() / (ref * ref).sum())
         assert np.median(e) < 3e-5, (b["name"], name, np.median(e))
-        assert np.quantile(e, 0.98) < 5e-3, (b["name"], name, np.quantile(e, 0.98))
+        assert np.quantile(e, 0.98) < 1e-3, (b["name"], name, np.quantile(e, 0.98))
         assert cos > 0.9999 and rel_l2 < 1e-2, (b["name"], name, cos, rel_l2)
 
 

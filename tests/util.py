@@ -65,7 +65,9 @@ def splat_fields(splats, radii=None):
     s = splats.detach().cpu()
     r = s[:, 10].contiguous().view(torch.int32).long() & 0xFFFFFFFF
     x0, y0, w, h = r & 255, (r >> 8) & 255, (r >> 16) & 255, (r >> 24) & 255
-    out = dict(xy=s[:, 0:2].double(), depth=s[:, 2].double(), opac=s[:, 3].double(),
+    # slots 0, 1 = screen position relative to the rect origin (16 x0, 16 y0): include/tgs.h
+    xy = s[:, 0:2].double() + 16.0 * torch.stack([x0, y0], 1).double()
+    out = dict(xy=xy, xy_rel=s[:, 0:2].double(), depth=s[:, 2].double(), opac=s[:, 3].double(),
                conic=s[:, 4:7].double(), rgb=s[:, 7:10].double(),
                rect=torch.stack([x0, y0, x0 + w, y0 + h], 1), hits=w * h,
                visible=s[:, 4] > 0)

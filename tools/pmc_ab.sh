@@ -1,15 +1,17 @@
 #!/bin/bash
-# SQ counters of K6 / K7 for several builds of the library on the same box:
-#   bash tools/pmc_ab.sh build_ab/base.so build_ab/v2.so ...   -> gpurun_out/pmc_ab_<name>.txt
+# SQ counters of K6 / K7 (tools/pmc_run.py: cfg3, view 0, generator row order -- the workload of the
+# committed profiles/*pmc_step_cfg3.json) for one or more builds of the library on the same box:
+#   bash tools/pmc_ab.sh touch_gs_amd/lib/libtgs_hip.so [build_ab/x.so ...]   -> gpurun_out/pmc_ab_<name>.txt
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
 for lib in "$@"; do
   name=$(basename $lib .so)
   i=0
   for set in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" \
-             "SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE"; do
+             "SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY GRBM_GUI_ACTIVE"; do
     rm -rf /tmp/pmcab_${name}_$i
-    TGS_LIB_PATH=$PWD/$lib rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmcab_${name}_$i -- python tools/pmc_run.py 2 > /tmp/pmcab.log 2>&1
+    TGS_LIB_PATH=$PWD/$lib timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmcab_${name}_$i -- python tools/pmc_run.py 2 > /tmp/pmcab_${name}_$i.log 2>&1 || tail -3 /tmp/pmcab_${name}_$i.log
     i=$((i+1))
   done
   python - "$name" <<'PY' > gpurun_out/pmc_ab_$name.txt

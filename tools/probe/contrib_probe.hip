@@ -25,7 +25,9 @@ __global__ __launch_bounds__(256) void k_probe(int W, int H, int TW, float pix_c
   unsigned long long c_pair_any = 0, c_after = 0, c_pair_reach = 0;
   for (int i = s; i < e; i++) {
     const float* r = splats + (size_t)sorted_gid[i] * 12;
-    const float dx = r[0] - fx, dy = r[1] - fy;
+    // record slots 0, 1 are relative to the origin of the Gaussian's tile rect (include/tgs.h)
+    const unsigned rect = __float_as_uint(r[10]);
+    const float dx = r[0] + 16.f * (float)(rect & 255u) - fx, dy = r[1] + 16.f * (float)((rect >> 8) & 255u) - fy;
     const float sig = 0.5f * (r[4] * dx * dx + r[6] * dy * dy) + r[5] * dx * dy;
     const float al = fminf(0.999f, r[3] * __expf(-sig));
     const bool reach = inside && sig >= 0.f && al >= 1.f / 255.f;

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
@@ -39,17 +40,11 @@ DEF_KERNEL(log, "v_log_f32_e32 %0, %0", OUT_RW, "v"(b))
 DEF_KERNEL(sqrt, "v_sqrt_f32_e32 %0, %0", OUT_RW, "v"(b))
 DEF_KERNEL(cmp_vcc, "v_cmp_le_f32_e32 vcc, %0, %1", OUT_RW, "v"(b) : "vcc")
 DEF_KERNEL(cmp_sgpr, "v_cmp_lt_f32_e64 s[20:21], %0, %1", OUT_RW, "v"(b) : "s20", "s21")
-DEF_KERNEL(cmp_cnd_vcc, "v_cmp_le_f32_e32 vcc, %0, %1\n v_cndmask_b32_e32 %0, %0, %2, vcc", OUT_RW, "v"(b), "v"(c) : "vcc")
-DEF_KERNEL(cnd_vcc, "v_cndmask_b32_e32 %0, %0, %1, vcc", OUT_RW, "v"(b) : "vcc")
 DEF_KERNEL(cnd_sgpr, "v_cndmask_b32_e64 %0, %0, %1, s[20:21]", OUT_RW, "v"(b) : "s20", "s21")
-DEF_KERNEL(cmp_sand_cnd, "v_cmp_lt_f32_e64 s[20:21], %0, %1\n s_and_b64 s[20:21], s[20:21], vcc\n v_cndmask_b32_e64 %0, 0, %0, s[20:21]", OUT_RW, "v"(b) : "s20", "s21", "vcc")
 DEF_KERNEL(pl16, "v_permlane16_swap_b32_e32 %0, %1", OUT_RW, "v"(b))
 DEF_KERNEL(pl32, "v_permlane32_swap_b32_e32 %0, %1", OUT_RW, "v"(b))
 DEF_KERNEL(dpp_add, "v_add_f32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", OUT_RW, "v"(b))
 DEF_KERNEL(fma_exp_mix, "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_exp_f32_e32 %0, %0", OUT_RW, "v"(b), "v"(c))
-DEF_KERNEL(snop, "s_nop 0", OUT_RW, "v"(b))
-DEF_KERNEL(salu, "s_and_b64 s[20:21], s[22:23], vcc", OUT_RW, "v"(b) : "s20", "s21")
-DEF_KERNEL(fma_salu_mix, "v_fma_f32 %0, %0, %1, %2\n s_and_b64 s[20:21], s[22:23], vcc", OUT_RW, "v"(b), "v"(c) : "s20", "s21")
 
 // dependent chain: every instruction consumes the previous result (latency with ONE wave per SIMD)
 __global__ __launch_bounds__(64) void k_dep_fma(float* out, int iters, float seed) {
@@ -74,24 +69,29 @@ struct Test { const char* name; kern_t k; int per_iter; };
 
 static double run(kern_t k, float* out, int blocks, int threads, int iters) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL(k, dim3(blocks), dim3(threads), 0, 0, out, iters, 0.5f); hipDeviceSynchronize();
-  hipEventRecord(e0);
   hipLaunchKernelGGL(k, dim3(blocks), dim3(threads), 0, 0, out, iters, 0.5f);
-  hipEventRecord(e1); hipEventSynchronize(e1);
-  float ms; hipEventElapsedTime(&ms, e0, e1);
-  return ms;
+  if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(hipGetLastError())); exit(1); }
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; rep++) {     // best of three: the first launches run while the clock still ramps
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(threads), 0, 0, out, iters, 0.5f);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    best = ms < best ? ms : best;
+  }
+  return best;
 }
 
 int main(int argc, char** argv) {
   float* out; (void)hipMalloc(&out, 1 << 26);
-  const int iters = 4000;
+  const int iters = 60000;
 #define T(NAME, N) {#NAME, k_##NAME, N}
   Test tests[] = {T(fma3, 16), T(fma_samesrc, 16), T(fmac, 16), T(fma_sgpr, 16), T(mul, 16), T(add, 16), T(min, 16), T(mov, 16),
                   T(exp, 16), T(exp_neg, 16), T(rcp, 16), T(log, 16), T(sqrt, 16), T(cmp_vcc, 16), T(cmp_sgpr, 16),
-                  T(cmp_cnd_vcc, 32), T(cnd_vcc, 16), T(cnd_sgpr, 16), T(cmp_sand_cnd, 48), T(pl16, 16), T(pl32, 16),
-                  T(dpp_add, 16), T(fma_exp_mix, 64), T(snop, 16), T(salu, 16), T(fma_salu_mix, 32)};
+                  T(cnd_sgpr, 16), T(pl16, 16), T(pl32, 16),
+                  T(dpp_add, 16), T(fma_exp_mix, 64),};
   // waves per SIMD: blocks of 256 threads = 4 waves = one per SIMD; B blocks per CU resident -> B waves per SIMD
-  for (int wps : {1, 2, 4, 8}) {
+  for (int wps : {1, 4}) {
     printf("--- %d wave(s) per SIMD (256 CUs x %d blocks of 256 threads, one round) ---\n", wps, wps);
     double base = 0;
     for (auto& t : tests) {
@@ -100,6 +100,7 @@ int main(int argc, char** argv) {
       const double inst_per_simd = (double)wps * iters * t.per_iter;   // wave-instructions each SIMD executes
       const double cyc = ms * 1e-3 * 2.4e9 / inst_per_simd;
       if (!strcmp(t.name, "fma3")) base = cyc;
+      fflush(stdout);
       printf("%-14s %8.3f ms  %6.2f nominal cyc / wave-instr / SIMD   x%.2f of v_fma\n", t.name, ms, cyc, cyc / base);
     }
   }

@@ -37,9 +37,9 @@ template <int CH>
 struct RowBlock {
   static constexpr int ROWF = (SW + 2 * HALO) * CH;             // floats per staged row
   static constexpr int NIT = (RB * ROWF + NTH - 1) / NTH;
+  template <int B = 8>
   static __device__ __forceinline__ void stage(const float* __restrict__ src, float* __restrict__ lds,
                                                int W, int H, int x0, int r0, int tid) {
-    constexpr int B = 8;
 #pragma unroll 1
     for (int it0 = 0; it0 < NIT; it0 += B) {
       float v[B];
@@ -55,6 +55,33 @@ struct RowBlock {
       for (int u = 0; u < B; u++) {
         const int i = tid + NTH * (it0 + u);
         if (i < RB * ROWF) lds[i] = v[u];
+      }
+    }
+  }
+  // Two images of the same geometry in one pass: the loads of both are in flight together, which halves
+  // the number of load -> wait round trips per block (the forward kernel is a chain of them).
+  static __device__ __forceinline__ void stage2(const float* __restrict__ src_a, const float* __restrict__ src_b,
+                                                float* __restrict__ lds_a, float* __restrict__ lds_b,
+                                                int W, int H, int x0, int r0, int tid) {
+    constexpr int B = 7;
+#pragma unroll 1
+    for (int it0 = 0; it0 < NIT; it0 += B) {
+      float va[B], vb[B];
+#pragma unroll
+      for (int u = 0; u < B; u++) {
+        const int i = tid + NTH * (it0 + u);
+        const int j = i / ROWF, e = i - j * ROWF;
+        const int gy = r0 + j, gxf = (x0 - HALO) * CH + e;
+        va[u] = 0.f; vb[u] = 0.f;
+        if (it0 + u < NIT && i < RB * ROWF && gy >= 0 && gy < H && gxf >= 0 && gxf < W * CH) {
+          const size_t o = (size_t)gy * W * CH + gxf;
+          va[u] = src_a[o]; vb[u] = src_b[o];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < B; u++) {
+        const int i = tid + NTH * (it0 + u);
+        if (it0 + u < NIT && i < RB * ROWF) { lds_a[i] = va[u]; lds_b[i] = vb[u]; }
       }
     }
   }
@@ -89,8 +116,12 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     {
       // no register prefetch of the next block: the window already holds 55 VGPRs per thread and
       // the other resident workgroups of the CU cover the load latency
-      RowBlock<3>::stage(img, sa, W, H, x0, r0, tid);
-      RowBlock<3>::stage(gt, sb, W, H, x0, r0, tid);
+#ifdef TGS_SSIM_STAGE_SEPARATE
+      RowBlock<3>::stage<8>(img, sa, W, H, x0, r0, tid);
+      RowBlock<3>::stage<8>(gt, sb, W, H, x0, r0, tid);
+#else
+      RowBlock<3>::stage2(img, gt, sa, sb, W, H, x0, r0, tid);   // NIT = 13: two rounds of 7 + 7 loads
+#endif
     }
     __syncthreads();
 #pragma unroll
@@ -168,7 +199,12 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     if (r0 - HALO >= ye) break;
     __syncthreads();
     {
-      RowBlock<9>::stage(adj, sadj, W, H, x0, r0, tid);
+      // 38 loads per thread and block: three rounds of 13 in flight (the kernel has registers to spare)
+#ifdef TGS_SSIM_STAGE_SEPARATE
+      RowBlock<9>::stage<8>(adj, sadj, W, H, x0, r0, tid);
+#else
+      RowBlock<9>::stage<13>(adj, sadj, W, H, x0, r0, tid);
+#endif
     }
     __syncthreads();
 #pragma unroll

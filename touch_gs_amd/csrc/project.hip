@@ -108,6 +108,57 @@ struct NextView {
   int32_t tag_value;
 };
 
+// ---------------------------------------------------------------------------------------------
+// Screen position to ~1e-5 px: double-float (hi + lo) evaluation of  u = fx X/Z + cx.
+// In plain fp32 the view transform, the quotient and the absolute pixel coordinate each carry an error
+// of about one ulp of a number of size |u| -- 1.2e-4 px at 1080p, 2.4e-4 px at 4K -- which reaches the
+// composited image at the 1e-4 level (alpha of a sub-pixel Gaussian is that sensitive to its centre).
+// K1 is HBM-bound, so ~150 extra VALU per Gaussian are free: products and sums are carried with
+// their rounding errors (FMA-based two-product, two-sum), and the record stores the position
+// RELATIVE to the origin of the Gaussian's own tile rectangle (16 x0, 16 y0), a number of a few tens
+// of pixels whose fp32 ulp is ~1e-6 px.  The compositing kernels subtract the (exactly
+// representable) tile centre relative to the same origin.
+// The `asm` statements pin each product / sum as computed: -ffp-contract=fast would otherwise fuse a
+// product into a later add and break the error-free transformations.
+// ---------------------------------------------------------------------------------------------
+struct DF { float hi, lo; };
+__device__ __forceinline__ float df_pin(float v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ DF two_prod(float a, float b) {
+  const float p = df_pin(a * b);
+  return {p, fmaf(a, b, -p)};
+}
+__device__ __forceinline__ DF two_sum(float a, float b) {
+  const float s = df_pin(a + b);
+  const float bb = df_pin(s - a);
+  const float ea = df_pin(a - df_pin(s - bb)), eb = df_pin(b - bb);
+  return {s, df_pin(ea + eb)};
+}
+// r . m + t
+__device__ __forceinline__ DF df_affine(const float* r, const float* m, float t) {
+  const DF p1 = two_prod(r[0], m[0]), p2 = two_prod(r[1], m[1]), p3 = two_prod(r[2], m[2]);
+  const DF s1 = two_sum(p1.hi, p2.hi), s2 = two_sum(s1.hi, p3.hi), s3 = two_sum(s2.hi, t);
+  return {s3.hi, ((p1.lo + p2.lo) + p3.lo) + ((s1.lo + s2.lo) + s3.lo)};
+}
+// f * (X / Z) + c  ->  (hi, lo) with hi + lo accurate to ~2^-45 relative
+__device__ __forceinline__ DF df_project(float f, DF X, DF Z, float c) {
+  const float q = df_pin(X.hi / Z.hi);                            // correctly rounded quotient
+  const float r = fmaf(-q, Z.hi, X.hi);                          // exact remainder
+  const float ql = (r + fmaf(-q, Z.lo, X.lo)) * __builtin_amdgcn_rcpf(Z.hi);
+  const DF p = two_prod(f, q);
+  const float pl = fmaf(f, ql, p.lo);
+  const DF d = two_sum(p.hi, c);
+  return {d.hi, d.lo + pl};
+}
+// screen position of mean m relative to the tile-rect origin (16 x0, 16 y0)
+__device__ __forceinline__ void screen_pos_rel(const CamK& cam, const float* m, unsigned rect, float& xr, float& yr) {
+  const DF X = df_affine(cam.R, m, cam.t[0]), Y = df_affine(cam.R + 3, m, cam.t[1]), Z = df_affine(cam.R + 6, m, cam.t[2]);
+  const DF u = df_project(cam.fx, X, Z, cam.cx), v = df_project(cam.fy, Y, Z, cam.cy);
+  int x0, y0, w, h;
+  unpack_rect(rect, x0, y0, w, h);
+  xr = df_pin(u.hi - (float)(x0 * TGS_BLOCK)) + u.lo;
+  yr = df_pin(v.hi - (float)(y0 * TGS_BLOCK)) + v.lo;
+}
+
 struct Geom {  // everything the forward and backward share for one Gaussian
   float tx, ty, tz;
   float Rq[9];      // rotation of the normalised quaternion
@@ -244,8 +295,17 @@ __device__ __forceinline__ void project_fwd_body(
   }
   if (radius == 0) { ca = 0.f; cb = 0.f; cc = 0.f; }  // conic != 0  <=>  passed the App. B culls
   tz = G.tz;
+  // record slots 0, 1: the screen position relative to the origin of the Gaussian's tile rect, from the
+  // compensated evaluation (the tile decisions above keep using the plain fp32 x2, y2: they carry a
+  // 0.02 px margin).  Gaussians behind the near plane keep (0, 0): they are in no list.
+  float xs = x2, ys = y2;
+#ifndef TGS_AB_PLAIN_XY   // same-box A/B switch (tools/abn.py): plain fp32 position, still rect-relative
+  if (G.tz > cam.near_plane) screen_pos_rel(cam, m, rect, xs, ys);
+#else
+  { int rx0, ry0, rw, rh; unpack_rect(rect, rx0, ry0, rw, rh); xs = x2 - 16.f * rx0; ys = y2 - 16.f * ry0; }
+#endif
   float* o = splats + (size_t)g * TGS_SPLAT_FLOATS;
-  st4(o, make_float4(x2, y2, G.tz, opac));
+  st4(o, make_float4(xs, ys, G.tz, opac));
   st4(o + 4, make_float4(ca, cb, cc, rgb[0]));
   if constexpr (!FUSED) st4(o + 8, make_float4(rgb[1], rgb[2], __uint_as_float(rect), 0.f));
   else { c1 = rgb[1]; c2 = rgb[2]; }   // third 16-B store follows once the group scan is known

@@ -79,9 +79,19 @@ struct TileRec {
   float4 c;  // g b - mask(bits)      ds_read_b128 x2 + ds_read_b64 off one base address)
 };
 
-__device__ __forceinline__ TileRec make_tile_rec(float4 r0, float4 r1, float4 r2, float tcx, float tcy) {
-  // r0 = {x, y, depth, opac}  r1 = {a, b, c, r}  r2 = {g, b, rect, off}
-  const float gx = r0.x - tcx, gy = r0.y - tcy;
+// Gaussian centre relative to the centre of tile (tx, ty).  The record holds the screen position
+// relative to the origin of the Gaussian's own tile rect (K1, project.hip: a small number, so its fp32
+// ulp is ~1e-6 px instead of the 2.4e-4 px of an absolute 4K coordinate); the tile centre relative to
+// that origin, 16 (tx - x0) + 7.5 + pix_center, is exact.
+__device__ __forceinline__ void centre_rel(float4 r0, float4 r2, int tx, int ty, float pix_center, float& gx, float& gy) {
+  const unsigned rect = __float_as_uint(r2.z);
+  const int dx = tx - (int)(rect & 255u), dy = ty - (int)((rect >> 8) & 255u);
+  gx = r0.x - ((float)(dx * TGS_BLOCK) + (7.5f + pix_center));
+  gy = r0.y - ((float)(dy * TGS_BLOCK) + (7.5f + pix_center));
+}
+
+__device__ __forceinline__ TileRec make_tile_rec(float4 r0, float4 r1, float4 r2, float gx, float gy) {
+  // r0 = {x - 16 x0, y - 16 y0, depth, opac}  r1 = {a, b, c, r}  r2 = {g, b, rect, off};  (gx, gy) = centre_rel()
   const float A = r1.x, B = r1.y, Cc = r1.z;
   const float L = -__log2f(r0.w);
   TileRec t;
@@ -188,8 +198,6 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
   if (tile >= T_total) return;
   const int lane = threadIdx.x;
   const int ty = tile / cam.TW, tx = tile - ty * cam.TW;
-  const float tcx = (float)(tx * TGS_BLOCK + 8) - 0.5f + cam.pix_center;  // tile centre
-  const float tcy = (float)(ty * TGS_BLOCK + 8) - 0.5f + cam.pix_center;
   const PixConst pc = make_pix_const(lane);
   int pxi[4], pyi[4];
   float smax[4];
@@ -224,11 +232,13 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
       const float* r = splats + (size_t)gid_nxt * TGS_SPLAT_FLOATS;
       const float4 q0 = ld4(r), q1 = ld4(r + 4), q2 = ld4(r + 8);
       if (base + 64 + lane < end) gid_nxt = sorted_gid[base + 64 + lane];
-      const TileRec t = make_tile_rec(q0, q1, q2, tcx, tcy);
 #else
       const float* r = splats + (size_t)sorted_gid[base + lane] * TGS_SPLAT_FLOATS;
-      const TileRec t = make_tile_rec(ld4(r), ld4(r + 4), ld4(r + 8), tcx, tcy);
+      const float4 q0 = ld4(r), q1 = ld4(r + 4), q2 = ld4(r + 8);
 #endif
+      float gx, gy;
+      centre_rel(q0, q2, tx, ty, cam.pix_center, gx, gy);
+      const TileRec t = make_tile_rec(q0, q1, q2, gx, gy);
       recs[lane * 3] = t.a; recs[lane * 3 + 1] = t.b; recs[lane * 3 + 2] = t.c;
       my_mask = __float_as_uint(t.c.w);
     }
@@ -300,8 +310,6 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
   if (tile >= T_total) return;
   const int lane = threadIdx.x;
   const int ty = tile / cam.TW, tx = tile - ty * cam.TW;
-  const float tcx = (float)(tx * TGS_BLOCK + 8) - 0.5f + cam.pix_center;
-  const float tcy = (float)(ty * TGS_BLOCK + 8) - 0.5f + cam.pix_center;
   const PixConst pc = make_pix_const(lane);
   const int start = tile_start[tile], end = tile_start[tile + 1];
   const int n = end - start;
@@ -444,7 +452,10 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
 #ifdef TGS_GID_PREFETCH
       if (base + 64 + lane < end) gid_nxt = sorted_gid[base + 64 + lane];
 #endif
-      const TileRec t = make_tile_rec(a0, a1, a2, tcx, tcy);
+      float gx, gy;
+      centre_rel(a0, a2, tx, ty, cam.pix_center, gx, gy);
+      a0.x = gx; a0.y = gy;                       // kept for the conversion of the moments below
+      const TileRec t = make_tile_rec(a0, a1, a2, gx, gy);
       recs[lane * 3] = t.a; recs[lane * 3 + 1] = t.b; recs[lane * 3 + 2] = t.c;
       my_mask = __float_as_uint(t.c.w);
       P = pair_index(group_base, gid, a2, tx, ty);
@@ -530,7 +541,7 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
     if (lane < cnt) {
       const float4 s0 = sums[lane * 4], s1 = sums[lane * 4 + 1], s2 = sums[lane * 4 + 2], s3 = sums[lane * 4 + 3];
       // s0 = {v_r, v_g, v_b, v_depth}  s1 = {Q0, Qu', Qu", Qv'}  s2 = {Qv", Quu', Quu", Qvv'}  s3 = {Qvv", Quv, -, -}
-      const float gx = a0.x - tcx, gy = a0.y - tcy;
+      const float gx = a0.x, gy = a0.y;           // centre relative to the tile centre (set while staging)
       const float A = a1.x, B = a1.y, Cc = a1.z;
       const float Q0 = s1.x, Qu = s1.y + s1.z, Qv = s1.w + s2.x, Quu = s2.y + s2.z, Qvv = s2.w + s3.x, Quv = s3.y;
       // v_sigma = -q, Delta = (gx - u, gy - v):  M* = sum v_sigma * Delta-monomials

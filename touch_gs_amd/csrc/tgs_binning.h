@@ -173,7 +173,11 @@ __device__ __forceinline__ void group_count_tiles(GroupScan& S, int TW, int T, i
   if (tid == 0 && total > 0) {
     local = atomicAdd(&alloc[x * TGS_ALLOC_STRIDE], total);
     // largest group total so far (a stale value only costs an unnecessary atomicMax below)
+#ifndef TGS_AB_NO_GROUP_MAX   // same-box A/B switch
     seen_max = __hip_atomic_load(&alloc[x * TGS_ALLOC_STRIDE + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    seen_max = 1 << 30;
+#endif
   }
   int32_t* __restrict__ my_count = tile_count + (size_t)x * T;
   int bx0 = 1 << 30, by0 = 1 << 30, bx1 = 0, by1 = 0;   // tile bounding box of the group's rects

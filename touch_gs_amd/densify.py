@@ -5,8 +5,9 @@ absent nerfstudio fork): every ``refine_every`` steps Gaussians whose average sc
 gradient exceeds ``densify_grad_thresh`` are cloned (small) or split into ``n_split_samples``
 (large); Gaussians that are nearly transparent or too large are culled; every
 ``reset_alpha_every * refine_every`` steps opacities are clamped down.  The parameter buffer is the
-flat SoA store of ``optim.GaussianParams``, so refinement = one gather of the surviving rows + one
-append, and the Adam moments move with their rows (new rows start at zero).
+flat SoA store of ``optim.GaussianParams``, so refinement = ONE gather per tensor into the new layout --
+every spawned row directly behind its parent, which keeps a spatially ordered buffer ordered without a
+re-sort -- and the Adam moments move with their rows (new rows start at zero).
 
 Data-parallel: the three per-Gaussian statistics are reduced across ranks (sum, sum, max -- the C2
 collective of SURVEY 2.2) and the split sampler is seeded from the step, so every replica takes
@@ -64,14 +65,20 @@ class DensityController:
         self.max_radius = torch.zeros(n, device=device)
 
     @torch.no_grad()
-    def accumulate(self, v_xy: torch.Tensor, radii: torch.Tensor, W: int, H: int):
+    def accumulate(self, v_xy: torch.Tensor, radii: torch.Tensor, W: int, H: int, guard: Optional[torch.Tensor] = None):
         """Per-step statistics: |screen gradient| in NDC-like units (x 0.5 max(W,H), as Splatfacto
-        does), visibility count and the largest normalised screen radius."""
+        does), visibility count and the largest normalised screen radius.  ``guard``: the frame's
+        binning status word (device int32[2]); a frame whose overflow flag is set contributes nothing
+        (it rendered empty lists and will be replayed -- the sync-free budget of the trainer), decided on
+        the device without a host read."""
         vis = radii > 0
+        if guard is not None:
+            vis = vis & (guard[1] == 0)
         g = v_xy.norm(dim=-1) * (0.5 * max(W, H))
         self.grad_norm_sum += torch.where(vis, g, torch.zeros_like(g))
         self.vis_count += vis.float()
-        self.max_radius = torch.maximum(self.max_radius, radii.float() / float(max(W, H)))
+        self.max_radius = torch.maximum(self.max_radius, torch.where(vis, radii.float() / float(max(W, H)),
+                                                                     torch.zeros_like(self.max_radius)))
 
     @torch.no_grad()
     def sync(self, dp) -> None:
@@ -111,48 +118,53 @@ class DensityController:
                 too_big = too_big | (self.max_radius > c.cull_screen_size)
             cull = cull | too_big
         keep = ~cull & ~split  # split parents are replaced by their samples
+        clone = clone & ~cull
+        split = split & ~cull
         names = GaussianParams.NAMES
         cur = {k: getattr(params, k) for k in names}
         mom = {k: (GaussianParams.views_of(optimizer.exp_avg, N, K)[k], GaussianParams.views_of(optimizer.exp_avg_sq, N, K)[k])
                for k in names}
-
-        parts = {k: [cur[k][keep]] for k in names}
-        m_parts = {k: [mom[k][0][keep]] for k in names}
-        v_parts = {k: [mom[k][1][keep]] for k in names}
-
-        def append(rows, overrides=None):
-            n_new = int(rows.shape[0])
-            if n_new == 0:
-                return
-            for k in names:
-                val = cur[k][rows] if overrides is None or k not in overrides else overrides[k]
-                parts[k].append(val)
-                m_parts[k].append(torch.zeros_like(val))
-                v_parts[k].append(torch.zeros_like(val))
-
-        clone_idx = torch.nonzero(clone & ~cull).squeeze(1)
-        append(clone_idx)
-        split_idx = torch.nonzero(split & ~cull).squeeze(1)
-        if split_idx.numel():
+        # New layout: every surviving row stays in place relative to the others and the rows it spawns
+        # (its clone, or its n_split_samples replacements) follow it immediately.  A spatially ordered buffer
+        # (model.spatial_sort) therefore stays spatially ordered -- children sit within a few scales of their
+        # parent -- without re-sorting: one exclusive scan gives every old row its first destination, and
+        # ONE gather per parameter tensor builds the refined store (the previous form gathered the
+        # survivors, concatenated the new rows behind them and then needed an argsort + a second gather
+        # of parameters and both Adam moments to restore the order).
+        S = c.n_split_samples
+        cnt = keep.long() + clone.long() + S * split.long()
+        first = torch.cumsum(cnt, 0) - cnt                   # destination of old row i's first output row
+        n_new = int(cnt.sum().item())
+        src = torch.repeat_interleave(torch.arange(N, device=dev), cnt, output_size=n_new)   # new row -> old row
+        within = torch.arange(n_new, device=dev) - first[src]                                  # 0, 1, .. inside the run
+        is_new = (within >= keep.long()[src])                # clones (within == 1) and all split samples
+        new = {k: cur[k][src] for k in names}
+        m_new = {k: mom[k][0][src] for k in names}
+        v_new = {k: mom[k][1][src] for k in names}
+        clone_n, split_n = int(clone.sum().item()), int(split.sum().item())
+        if split_n:
+            # sample s of the j-th split parent (in row order) draws noise row s * split_n + j: the same
+            # assignment as the append-at-the-end form, so both produce the same set of Gaussians
+            spos = torch.nonzero(split[src]).squeeze(1)
+            rank_of = torch.cumsum(split.long(), 0) - 1      # j of every split parent
             g = torch.Generator(device="cpu").manual_seed(1_000_003 * (step + 1))
-            S = c.n_split_samples
-            idx = split_idx.repeat(S)
-            noise = torch.randn(idx.shape[0], 3, generator=g).to(dev)
-            R = quat_to_rotmat(cur["quats"][idx])
-            sc = torch.exp(cur["log_scales"][idx])
-            offs = torch.einsum("nij,nj->ni", R, noise * sc)
-            append(idx, dict(means=cur["means"][idx] + offs,
-                             log_scales=cur["log_scales"][idx] - math.log(1.6)))
-        new = {k: torch.cat(parts[k]) for k in names}
-        n_new = new["means"].shape[0]
+            noise = torch.randn(S * split_n, 3, generator=g).to(dev)
+            nz = noise[within[spos] * split_n + rank_of[src[spos]]]
+            R = quat_to_rotmat(new["quats"][spos])
+            sc = torch.exp(new["log_scales"][spos])
+            new["means"][spos] += torch.einsum("nij,nj->ni", R, nz * sc)
+            new["log_scales"][spos] -= math.log(1.6)
+        for k in names:                                      # new rows start with zero moments
+            m_new[k][is_new] = 0
+            v_new[k][is_new] = 0
         new_params = GaussianParams.from_tensors(*[new[k] for k in names])
         new_opt = FusedAdam(new_params, optimizer.lrs, optimizer.betas, optimizer.eps)
         new_opt.t = optimizer.t
         mv = GaussianParams.views_of(new_opt.exp_avg, n_new, K)
         vv = GaussianParams.views_of(new_opt.exp_avg_sq, n_new, K)
         for k in names:
-            mv[k].copy_(torch.cat(m_parts[k]))
-            vv[k].copy_(torch.cat(v_parts[k]))
+            mv[k].copy_(m_new[k])
+            vv[k].copy_(v_new[k])
         # opacity reset
         reset = c.reset_alpha_every > 0 and (step // c.refine_every) % c.reset_alpha_every == 0 and step > 0
         if reset:
@@ -161,7 +173,7 @@ class DensityController:
             mv["opac_logit"].zero_()
             vv["opac_logit"].zero_()
         self.reset_stats(n_new, dev)
-        info = dict(before=N, after=n_new, cloned=int(clone_idx.numel()), split=int(split_idx.numel()),
+        info = dict(before=N, after=n_new, cloned=clone_n, split=split_n,
                     culled=int(cull.sum()), opacity_reset=bool(reset))
         return new_params, new_opt, info
 

@@ -62,6 +62,8 @@ class ModelConfig:
     # keep the Gaussians in 3-D Morton order (model.spatial_sort() after every densification); the
     # trainer and bench.py switch it on, library users keep their own row order by default
     spatial_sort: bool = False
+    # full Morton re-sort every this many refinements (in between, refine() keeps children next to parents)
+    resort_every_refines: int = 10
 
     def lr_means_at(self, step: int) -> float:
         """ExponentialDecay schedule: lr_init * (lr_final / lr_init) ** min(step / max_steps, 1)."""
@@ -284,6 +286,7 @@ class DepthGaussianSplattingModel:
             density.max_radius = density.max_radius[perm]
         self._graphs = {}
         self._prefetch_ready = None
+        self._refines_since_sort = 0
         return perm
 
     def enable_densification(self, cfg=None):
@@ -293,7 +296,10 @@ class DepthGaussianSplattingModel:
 
     # -- sync-free intersection budget ---------------------------------------------------------
     def enable_speculative_budget(self, capacity: int = 0, max_in_flight: int = 4) -> None:
-        """Train without the per-step read-back of the intersection count (no densification).  Every
+        """Train without the per-step read-back of the intersection count.  Densification: every
+        refinement is a barrier -- the pending verdicts are settled (and overflowed steps replayed) before
+        the Gaussians change, overflowed frames add nothing to the refinement statistics, and the
+        capacity follows the Gaussian count afterwards.  Every
         step's status word is copied to pinned host memory asynchronously and looked at a few steps
         later.  Data parallel (factored exchange only): the ranks agree on the overflow verdict on the
         device (the flag rides in the pad of the all-gathered colour block, ops.dp_agree_overflow), the
@@ -304,8 +310,6 @@ class DepthGaussianSplattingModel:
         guarded optimizer kernels into no-ops, so when the host notices it clears the word, grows the
         buffers, rewinds its step counters and replays the affected views -- the model ends up exactly
         where the synchronous budget would have put it (tests/test_gpu_api_surfaces.py)."""
-        if getattr(self, "density", None) is not None:
-            raise RuntimeError("the speculative budget does not combine with densification")
         self.budget = ops.IntersectBudget(capacity=capacity, sync=False, speculative=True)
         self._pending = collections.deque()
         self._max_in_flight = max_in_flight
@@ -423,9 +427,9 @@ class DepthGaussianSplattingModel:
         fuse = (not distributed) and self.fuse_adam and opt.can_fuse_with_backward(deg)
         factored = distributed and self.dp_factored_sh and opt.can_gather_sh()
         density = getattr(self, "density", None)
-        if self.budget.speculative and (density is not None or (distributed and not factored)):
-            raise RuntimeError("the speculative intersection budget does not combine with densification or with the "
-                               "dense (flat all-reduce) data-parallel exchange")
+        if self.budget.speculative and distributed and not factored:
+            raise RuntimeError("the speculative intersection budget does not combine with the dense (flat all-reduce) "
+                               "data-parallel exchange")
         self._dp = dp if distributed else None
         block = None
         if factored:
@@ -437,7 +441,7 @@ class DepthGaussianSplattingModel:
             block = self._color_block
         colors = pre if (pre is not None and fuse and pre.matches(view.cam, self.params.N, deg)) else None
         arm = None
-        if fuse and next_view is not None and density is None and self.active_sh_degree(self.step + 1) == deg:
+        if fuse and next_view is not None and self.active_sh_degree(self.step + 1) == deg:
             bufs = getattr(self, "_prefetch_bufs", None)
             N, dev = self.params.N, self.params.flat.device
             if bufs is None or bufs[0].N != N or bufs[0].colors.device != dev:
@@ -448,7 +452,9 @@ class DepthGaussianSplattingModel:
                               colors=colors, prefetch=arm)
         self._prefetch_ready = arm
         if density is not None:
-            density.accumulate(self.last["v_xy"], self.last["radii"], view.cam.W, view.cam.H)
+            # a frame that overflowed its intersection buffer (sync-free budget) rendered nothing and will be
+            # replayed: it must not count as a view (guard = its status word, evaluated on the device)
+            density.accumulate(self.last["v_xy"], self.last["radii"], view.cam.W, view.cam.H, guard=self.last["guard"])
         if factored:
             dguard = None
             if self.budget.speculative:   # agree the overflow verdict across ranks before anything touches the model
@@ -469,14 +475,34 @@ class DepthGaussianSplattingModel:
         elif not fuse:
             self.optimizer.step(guard=self.last["guard"])
         self.step += 1
-        if self.budget.speculative and density is None:
+        if self.budget.speculative:
             self._speculative_track(view, distributed)
-        if density is not None and density.due(self.step):
+        if density is not None and density.due(self.step) and getattr(self, "_refined_at", None) != self.step:
+            if self.budget.speculative:
+                # barrier: settle every pending overflow verdict first (a drain that finds one replays the
+                # affected steps -- possibly including this one, whose replay then refines; `_refined_at`
+                # keeps the outer call from refining a second time)
+                self.flush()
+                if getattr(self, "_refined_at", None) == self.step:
+                    return
+            n_before = self.params.N
             self.params, self.optimizer, self.last_refine = density.refine(self.params, self.optimizer, self.step, dp)
-            self.budget = ops.IntersectBudget()  # the intersection count changes with N
+            self._refined_at = self.step
+            if self.budget.speculative:   # the intersection count follows N; a wrong guess only costs a replay
+                grow = max(1.0, self.params.N / max(n_before, 1)) * 1.15
+                self.budget = ops.IntersectBudget(capacity=int(self.budget.capacity * grow) + 4096, sync=False,
+                                                  speculative=True)
+            else:
+                self.budget = ops.IntersectBudget()  # the intersection count changes with N
             self._prefetch_ready = None
+            self._graphs = {}
             if self.config.spatial_sort:
-                self.spatial_sort()              # the appended clones / splits go back to their neighbours
+                # refine() puts every spawned row directly behind its parent, so the buffer stays spatially
+                # ordered; the full re-sort (argsort + gathers of parameters and both moment buffers) only
+                # corrects the slow drift of the means, every `resort_every_refines` refinements
+                self._refines_since_sort = getattr(self, "_refines_since_sort", 0) + 1
+                if self._refines_since_sort >= self.config.resort_every_refines:
+                    self.spatial_sort()
 
     # -- checkpoint -----------------------------------------------------------------------------
     def state_dict(self):

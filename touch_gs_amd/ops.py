@@ -516,6 +516,16 @@ def spherical_harmonics(degrees_to_use: int, viewdirs: torch.Tensor, coeffs: tor
     return _SphericalHarmonics.apply(degrees_to_use, viewdirs, coeffs)
 
 
+def record_xy(splats: torch.Tensor) -> torch.Tensor:
+    """Absolute screen positions [N,2] from splat records: slots 0, 1 store the position relative to the
+    origin (16 x0, 16 y0) of the Gaussian's packed tile rect in slot 10 (include/tgs.h; K1 evaluates
+    it in compensated arithmetic, so the relative value is good to ~1e-5 px -- the sum returned here is
+    rounded to fp32 like any absolute coordinate)."""
+    r = splats[:, 10].contiguous().view(torch.int32)
+    org = torch.stack([r & 255, (r >> 8) & 255], 1).to(torch.float32) * 16.0
+    return (splats[:, 0:2] + org).contiguous()
+
+
 class _ProjectGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3d, scales, glob_scale, quats, cam):
@@ -528,7 +538,7 @@ class _ProjectGaussians(torch.autograd.Function):
         splats, radii = project_fwd(cam, means3d, log_scales, quats, zero, None, -1, want_radii=True)
         ctx.cam = cam
         ctx.save_for_backward(means3d, log_scales, quats, zero, splats)
-        xys = splats[:, 0:2].contiguous()
+        xys = record_xy(splats)
         depths = splats[:, 2].contiguous()
         conics = splats[:, 4:7].contiguous()
         ctx.mark_non_differentiable(radii)
@@ -600,7 +610,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         vis = (radii > 0) & (x1 > x0) & (y1 > y0)
         packed = torch.where(vis, x0 | (y0 << 8) | ((x1 - x0) << 16) | ((y1 - y0) << 24), torch.zeros_like(x0))
         packed = torch.where(packed >= 2 ** 31, packed - 2 ** 32, packed).to(torch.int32)
-        splats = torch.cat([xys.to(torch.float32), depths.reshape(N, 1).to(torch.float32), op,
+        # record slots 0, 1 hold the position relative to the origin of the tile rect (include/tgs.h)
+        org = torch.stack([x0, y0], 1).to(torch.float32) * 16.0
+        org = torch.where(vis[:, None], org, torch.zeros_like(org))
+        splats = torch.cat([xys.to(torch.float32) - org, depths.reshape(N, 1).to(torch.float32), op,
                             conics.to(torch.float32), colors.to(torch.float32),
                             packed.reshape(N, 1).view(torch.float32),
                             torch.zeros(N, 1, dtype=torch.float32, device=dev)], dim=1).contiguous()

@@ -111,7 +111,9 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-spatial-sort", action="store_true",
                     help="keep the Gaussians in their initial row order instead of 3-D Morton order")
-    ap.add_argument("--densify", action="store_true", help="Splatfacto-style clone/split/cull refinement")
+    ap.add_argument("--densify", dest="densify", action="store_true", default=True,
+                    help="Splatfacto-style clone/split/cull refinement (default: on, as in the method the reference trains)")
+    ap.add_argument("--no-densify", dest="densify", action="store_false", help="fixed set of Gaussians")
     ap.add_argument("--refine-every", type=int, default=100)
     ap.add_argument("--warmup-length", type=int, default=500)
     args = ap.parse_args(argv)
@@ -151,7 +153,7 @@ def main(argv=None):
         with open(os.path.join(run_dir, "config.json"), "w") as f:
             json.dump(dict(vars(args), model=dataclasses.asdict(cfg), world_size=dp.world,
                            scene=None if args.synthetic else scene.describe()), f, indent=2)
-    if not args.densify and not args.sync_budget and (dp.world == 1 or model.optimizer.can_gather_sh()):
+    if not args.sync_budget and (dp.world == 1 or model.optimizer.can_gather_sh()):
         # no per-step host sync; an overflow is detected late and replayed (data parallel: the ranks
         # agree on it on the device and replay the same steps)
         model.enable_speculative_budget()
