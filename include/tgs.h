@@ -193,7 +193,12 @@ int tgs_project_bin_sort_colors(const TgsCamera* cam /*[host]*/, int N, const fl
 int tgs_rasterize_fwd(const TgsCamera* cam /*[host]*/, const float* splats,
                       const int32_t* sorted_gid, const int32_t* tile_start,
                       const int32_t* tile_order, float* out_rgb, float* out_depth, float* final_T,
-                      int32_t* final_idx, void* stream);
+                      int32_t* final_idx, uint64_t* slot_ok /*may be NULL*/, void* stream);
+/* slot_ok[4 * tgs_slot_ok_len(W, H, capacity)] (optional): per batch of 64 list positions of a tile, four
+ * 64-bit maps (one per 8x8 quadrant) of the Gaussians that changed the quadrant's state in the forward.
+ * Handed to tgs_rasterize_bwd* (same splats and lists) the backward skips the other (Gaussian, quadrant)
+ * evaluations; the results are bit-identical with and without it. */
+size_t tgs_slot_ok_len(int W, int H, int64_t capacity);
 
 /* K7  compositing backward with the tactile depth/uncertainty loss fused in  (stands behind
  *     gsplat `rasterize_gaussians` bwd; spec App. B.7).
@@ -210,7 +215,7 @@ int tgs_rasterize_bwd(const TgsCamera* cam /*[host]*/, const float* splats,
                       const float* out_rgb, const float* out_depth, const float* final_T,
                       const float* v_rgb, const float* v_depth, const float* v_alpha,
                       const TgsLossSpec* loss /*[host]*/, float* partials, float* tile_loss,
-                      void* stream);
+                      const uint64_t* slot_ok /*may be NULL*/, void* stream);
 
 /* K7 for ONE image band: the tiles [tile0, tile1) of tgs_band_tiles(W, H, band, ...) (a contiguous row-major
  *     range; tgs_num_bands(W, H) >= 4 bands cover the image).  Needs the tile_order of tgs_bin_sort.  The
@@ -223,7 +228,7 @@ int tgs_rasterize_bwd_band(const TgsCamera* cam /*[host]*/, const float* splats,
                       const float* out_rgb, const float* out_depth, const float* final_T,
                       const float* v_rgb, const float* v_depth, const float* v_alpha,
                       const TgsLossSpec* loss /*[host]*/, float* partials, float* tile_loss,
-                      int band, void* stream);
+                      int band, const uint64_t* slot_ok /*may be NULL*/, void* stream);
 
 /* K8a segmented reduction of the partials to one gradient record per Gaussian
  *     out: v_splats[N,12] = {v_x, v_y, v_depth, v_opacity, v_a, v_b, v_c, v_r, v_g, v_b, 0, 0}. */

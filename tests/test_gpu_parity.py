@@ -256,6 +256,32 @@ def test_fused_loss_matches_autograd_path(dev):
             assert (got - ref).abs().max().item() < 2e-4 * scale, (loss_type, name)
 
 
+def test_slot_ok_bitmaps_do_not_change_the_backward(dev, monkeypatch):
+    """TGS_SLOT_OK (off by default): K6 records which Gaussians changed the state of each 8x8 quadrant, K7
+    skips the other (Gaussian, quadrant) evaluations -- the partial gradients are bit-identical."""
+    from touch_gs_amd import ops
+    P, cam = scene(20000, 320, 208, 3, 77)
+    acam = amd_cam(cam)
+    D = to_dev(P, dev)
+    g = torch.Generator().manual_seed(3)
+    v = [torch.randn(208, 320, 3, generator=g).to(dev), torch.randn(208, 320, generator=g).to(dev),
+         torch.randn(208, 320, generator=g).to(dev)]
+    res = []
+    for on in (False, True):
+        monkeypatch.setattr(ops, "SLOT_OK", on)
+        sp, _, gb, ts, sg, st = ops.project_bin_sort(acam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], 3)
+        rgb, depth, fT, _ = ops.rasterize_fwd(acam, sp, sg, ts)
+        assert (ts.slot_ok is not None) == on
+        partials, _ = ops.rasterize_bwd(acam, sp, gb, sg, ts, rgb, depth, fT, *v)
+        grads = ops.project_bwd(acam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], 3, sp, gb, partials)
+        res.append([rgb, depth, fT] + list(grads[:5]))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    if res:   # some quadrant evaluations were really skipped
+        words = ts.slot_ok.view(-1)
+        assert int((words != 0).sum()) > 0
+
+
 def test_deterministic_bitwise(dev):
     from touch_gs_amd import ops
     P, cam = scene(5000, 200, 120, 3, 61)

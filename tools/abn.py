@@ -84,11 +84,15 @@ def main():
     a = ap.parse_args()
     code = WORKER % dict(root=ROOT, cfg=a.cfg, views=a.views, morton=int(a.morton))
     for r in range(a.rounds):
-        for lib in a.libs:
+        for spec in a.libs:     # "lib.so" or "lib.so@ENV=VAL,ENV2=VAL2" (environment switches of the same build)
+            lib, _, envs = spec.partition("@")
             env = dict(os.environ, TGS_LIB_PATH=os.path.abspath(lib))
+            for kv in filter(None, envs.split(",")):
+                k, _, v = kv.partition("=")
+                env[k] = v
             out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
             line = [l for l in out.stdout.splitlines() if l.startswith("{")]
-            print(os.path.basename(lib), line[-1] if line else out.stderr[-800:], flush=True)
+            print(os.path.basename(spec), line[-1] if line else out.stderr[-800:], flush=True)
 
 
 if __name__ == "__main__":

@@ -299,11 +299,7 @@ __device__ __forceinline__ void project_fwd_body(
   // compensated evaluation (the tile decisions above keep using the plain fp32 x2, y2: they carry a
   // 0.02 px margin).  Gaussians behind the near plane keep (0, 0): they are in no list.
   float xs = x2, ys = y2;
-#ifndef TGS_AB_PLAIN_XY   // same-box A/B switch (tools/abn.py): plain fp32 position, still rect-relative
-  if (G.tz > cam.near_plane) screen_pos_rel(cam, m, rect, xs, ys);
-#else
-  { int rx0, ry0, rw, rh; unpack_rect(rect, rx0, ry0, rw, rh); xs = x2 - 16.f * rx0; ys = y2 - 16.f * ry0; }
-#endif
+  if (G.tz > cam.near_plane) screen_pos_rel(cam, m, rect, xs, ys);   // free: K1+count 185 us with and without (same box)
   float* o = splats + (size_t)g * TGS_SPLAT_FLOATS;
   st4(o, make_float4(xs, ys, G.tz, opac));
   st4(o + 4, make_float4(ca, cb, cc, rgb[0]));

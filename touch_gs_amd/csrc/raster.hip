@@ -166,6 +166,14 @@ __device__ __forceinline__ float eval_s(const float4& a, const float4& b, const 
   return s;
 }
 
+// Entry of the per-batch quadrant bitmaps K6 leaves for K7 (4 x 64 bits per batch of 64 list
+// positions): batches of one tile start at positions start, start + 64, ..; (position >> 6) + tile is
+// strictly increasing over the batches of a tile and from one tile to the next, hence unique, and
+// < (#intersections >> 6) + #tiles + 1.
+__device__ __forceinline__ size_t slot_ok_index(int batch_pos, int tile) {
+  return (size_t)(batch_pos >> 6) + (size_t)tile;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K6 forward
 // ---------------------------------------------------------------------------------------------
@@ -177,23 +185,27 @@ __device__ __forceinline__ float eval_s(const float4& a, const float4& b, const 
 //   returns the contributing alpha (0 if skipped or if this Gaussian stops the pixel).
 //   MAYCLAMP = false: the caller knows that no Gaussian of the batch has opacity > 0.999, so
 //          exp2(-s) = o e^-sigma <= 0.999 and min(0.999, .) is the identity -- bit-identical, one VALU less.
-template <bool MAYCLAMP = true>
-__device__ __forceinline__ float blend_step(float s, float& T, float& smax, float& Tnew, bool& go) {
+//   okb  : (WANT_OK) lane mask of the pixels that passed the alpha >= 1/255 test while live -- the ballot
+//          sits next to the compare so that it IS the compare's scalar result (no extra VALU)
+template <bool MAYCLAMP = true, bool WANT_OK = false>
+__device__ __forceinline__ float blend_step(float s, float& T, float& smax, float& Tnew, bool& go,
+                                            unsigned long long& okb) {
   const float e = __builtin_amdgcn_exp2f(-s);
   const float al = MAYCLAMP ? fminf(ALPHA_MAX, e) : e;
   const bool ok = s <= smax;
+  if constexpr (WANT_OK) okb = __builtin_amdgcn_ballot_w64(ok);
   Tnew = fmaf(-al, T, T);
   go = ok & (Tnew > T_STOP);
-  smax = (ok & !go) ? -3.0e38f : smax;  // stop: T' <= 1e-4, this Gaussian excluded
+  smax = (ok != go) ? -3.0e38f : smax;  // stop (ok and not go; go implies ok): T' <= 1e-4, this Gaussian excluded
   return go ? al : 0.f;
 }
 
-template <bool WANT_IDX>
+template <bool WANT_IDX, bool WANT_OK>
 __global__ __launch_bounds__(64) void k_raster_fwd(
     CamK cam, int T_total, const float* __restrict__ splats, const int32_t* __restrict__ sorted_gid,
     const int32_t* __restrict__ tile_start, float* __restrict__ out_rgb,
     float* __restrict__ out_depth, float* __restrict__ final_T, int32_t* __restrict__ final_idx,
-    const int32_t* __restrict__ tile_order) {
+    const int32_t* __restrict__ tile_order, unsigned long long* __restrict__ slot_ok) {
   const int tile = tile_order ? tile_order[blockIdx.x] : xcd_tile(blockIdx.x, T_total);
   if (tile >= T_total) return;
   const int lane = threadIdx.x;
@@ -215,9 +227,6 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
   __shared__ float4 recs[64 * 3];
   const int start = tile_start[tile], end = tile_start[tile + 1];
 
-#ifdef TGS_GID_PREFETCH
-  int gid_nxt = (start + lane < end) ? sorted_gid[start + lane] : 0;
-#endif
   for (int base = start; base < end; base += 64) {
     unsigned slot_live = 0u;
 #pragma unroll
@@ -227,15 +236,10 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
     unsigned my_mask = 0u;
     if (base + lane < end) {
       // no register prefetch of the next batch: 12 fewer VGPRs buy two more resident waves per
-      // SIMD, which hide the gather latency (and the long dependent chains of the blend) better
-#ifdef TGS_GID_PREFETCH
-      const float* r = splats + (size_t)gid_nxt * TGS_SPLAT_FLOATS;
-      const float4 q0 = ld4(r), q1 = ld4(r + 4), q2 = ld4(r + 8);
-      if (base + 64 + lane < end) gid_nxt = sorted_gid[base + 64 + lane];
-#else
+      // SIMD, which hide the gather latency (and the long dependent chains of the blend) better;
+      // prefetching only the next batch's ids (1 VGPR) measured K7 -1 %, K6 +1 % (round 3): not kept
       const float* r = splats + (size_t)sorted_gid[base + lane] * TGS_SPLAT_FLOATS;
       const float4 q0 = ld4(r), q1 = ld4(r + 4), q2 = ld4(r + 8);
-#endif
       float gx, gy;
       centre_rel(q0, q2, tx, ty, cam.pix_center, gx, gy);
       const TileRec t = make_tile_rec(q0, q1, q2, gx, gy);
@@ -250,6 +254,11 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
 #pragma unroll
     for (int k = 0; k < 4; k++)
       qm[k] = ((slot_live >> k) & 1u) ? __ballot((my_mask >> k) & 1u) : 0ull;
+    // okm[k]: bit j = some pixel of quadrant k passed the alpha >= 1/255 test on Gaussian j while live,
+    // i.e. Gaussian j changed the state of quadrant k (contribution or stop).  The backward walks the
+    // same list with the same decisions and skips every (Gaussian, quadrant) whose bit is clear: ~7 % of
+    // the quadrant evaluations at cfg3 reach only pixels that have already stopped.
+    unsigned long long okm[4] = {0ull, 0ull, 0ull, 0ull};
     unsigned long long rem = qm[0] | qm[1] | qm[2] | qm[3];
     while (rem) {
       const int j = __builtin_ctzll(rem);
@@ -263,14 +272,20 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
         if (m & (1u << k)) {  // wave-uniform
           const float s = eval_s(qa, qb, pc, k);
           float Tn; bool go;
-          const float al = blend_step(s, T[k], smax[k], Tn, go);
+          unsigned long long okb = 0ull;
+          const float al = blend_step<true, WANT_OK>(s, T[k], smax[k], Tn, go, okb);
           const float w = al * T[k];
           Cr[k] = fmaf(w, qb.w, Cr[k]); Cg[k] = fmaf(w, qc.x, Cg[k]);
           Cb[k] = fmaf(w, qc.y, Cb[k]); D[k] = fmaf(w, qb.z, D[k]);
           T[k] = go ? Tn : T[k];
           if (WANT_IDX) last[k] = go ? pos : last[k];
+          if constexpr (WANT_OK) okm[k] |= (okb != 0ull) ? (1ull << j) : 0ull;
         }
       }
+    }
+    if (WANT_OK && lane == 0) {
+      unsigned long long* o = slot_ok + 4 * slot_ok_index(base, tile);
+      o[0] = okm[0]; o[1] = okm[1]; o[2] = okm[2]; o[3] = okm[3];
     }
   }
 #pragma unroll
@@ -305,7 +320,7 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
     const float* __restrict__ final_T, const float* __restrict__ v_rgb,
     const float* __restrict__ v_depth, const float* __restrict__ v_alpha, LossK loss,
     float* __restrict__ partials, float* __restrict__ tile_loss,
-    const int32_t* __restrict__ tile_order) {
+    const int32_t* __restrict__ tile_order, const unsigned long long* __restrict__ slot_ok) {
   const int tile = tile_order ? tile_order[blockIdx.x] : xcd_tile(blockIdx.x, T_total);
   if (tile >= T_total) return;
   const int lane = threadIdx.x;
@@ -427,9 +442,6 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
   }
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   int base = start;
-#ifdef TGS_GID_PREFETCH
-  int gid_nxt = (start + lane < end) ? sorted_gid[start + lane] : 0;
-#endif
   for (; base < end; base += 64) {
     unsigned slot_live = 0u;
 #pragma unroll
@@ -441,17 +453,10 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
     unsigned my_mask = 0u;
     __syncthreads();
     if (lane < cnt) {
-#ifdef TGS_GID_PREFETCH
-      const int gid = gid_nxt;
-#else
       const int gid = sorted_gid[base + lane];
-#endif
       const float* r = splats + (size_t)gid * TGS_SPLAT_FLOATS;
       a0 = ld4(r); a1 = ld4(r + 4);
       const float4 a2 = ld4(r + 8);
-#ifdef TGS_GID_PREFETCH
-      if (base + 64 + lane < end) gid_nxt = sorted_gid[base + 64 + lane];
-#endif
       float gx, gy;
       centre_rel(a0, a2, tx, ty, cam.pix_center, gx, gy);
       a0.x = gx; a0.y = gy;                       // kept for the conversion of the moments below
@@ -467,6 +472,11 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
 #pragma unroll
     for (int k = 0; k < 4; k++)
       qm[k] = ((slot_live >> k) & 1u) ? __ballot((my_mask >> k) & 1u) : 0ull;
+    if (slot_ok) {   // quadrants in which the forward saw no live pixel reach alpha >= 1/255: nothing to do
+      const unsigned long long* o = slot_ok + 4 * slot_ok_index(base, tile);
+#pragma unroll
+      for (int k = 0; k < 4; k++) qm[k] &= __builtin_nontemporal_load(o + k);
+    }
     auto walk = [&](auto mayclamp) {
     constexpr bool MAYCLAMP = decltype(mayclamp)::value;
     unsigned long long rem = qm[0] | qm[1] | qm[2] | qm[3];
@@ -486,7 +496,8 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
         if (m & (1u << k)) {  // wave-uniform
           const float s = eval_s(qa, qb, pc, k);
           float Tn; bool go;
-          const float al = blend_step<MAYCLAMP>(s, T[k], smax[k], Tn, go);   // 0 unless this Gaussian contributes
+          unsigned long long okb;
+          const float al = blend_step<MAYCLAMP>(s, T[k], smax[k], Tn, go, okb);   // 0 unless this Gaussian contributes
           const float w = al * T[k];
           // alpha / (1 - alpha) = alpha T / T'  (T' = T (1 - alpha) is already there; w = 0 if skipped)
           const float kap = w * __builtin_amdgcn_rcpf(Tn);
@@ -570,19 +581,20 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
 extern "C" int tgs_rasterize_fwd(const TgsCamera* cam, const float* splats,
                                  const int32_t* sorted_gid, const int32_t* tile_start,
                                  const int32_t* tile_order, float* out_rgb, float* out_depth,
-                                 float* final_T, int32_t* final_idx, void* stream) {
+                                 float* final_T, int32_t* final_idx, uint64_t* slot_ok, void* stream) {
   TGS_CHECK_ARG(camera_ok(cam), "bad camera");
   TGS_CHECK_ARG(splats && sorted_gid && tile_start && out_rgb && out_depth && final_T,
                 "null pointer");
   const CamK k = make_camk(cam);
   const int T = k.TW * k.TH;
   const int grid = TGS_XCDS * tgs_xcd_slots(T);
-  if (final_idx)
-    hipLaunchKernelGGL(k_raster_fwd<true>, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T,
-                       splats, sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx, tile_order);
-  else
-    hipLaunchKernelGGL(k_raster_fwd<false>, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T,
-                       splats, sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx, tile_order);
+#define TGS_LAUNCH_FWD(IDX, OK)                                                                          \
+  hipLaunchKernelGGL((k_raster_fwd<IDX, OK>), dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T, splats, \
+                     sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx, tile_order,          \
+                     (unsigned long long*)slot_ok)
+  if (final_idx) { if (slot_ok) TGS_LAUNCH_FWD(true, true); else TGS_LAUNCH_FWD(true, false); }
+  else { if (slot_ok) TGS_LAUNCH_FWD(false, true); else TGS_LAUNCH_FWD(false, false); }
+#undef TGS_LAUNCH_FWD
   TGS_CHECK_LAUNCH();
   return TGS_OK;
 }
@@ -594,7 +606,7 @@ static int rasterize_bwd_impl(const TgsCamera* cam, const float* splats,
                                  const float* final_T, const float* v_rgb,
                                  const float* v_depth, const float* v_alpha,
                                  const TgsLossSpec* loss, float* partials, float* tile_loss,
-                                 int band, void* stream) {
+                                 int band, const uint64_t* slot_ok, void* stream) {
   TGS_CHECK_ARG(camera_ok(cam), "bad camera");
   TGS_CHECK_ARG(splats && group_base && sorted_gid && tile_start && out_rgb && out_depth &&
                 final_T && partials, "null pointer");
@@ -621,7 +633,8 @@ static int rasterize_bwd_impl(const TgsCamera* cam, const float* splats,
   }
   hipLaunchKernelGGL(k_raster_bwd, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T, splats,
                      group_base, sorted_gid, tile_start, out_rgb, out_depth, final_T,
-                     v_rgb, v_depth, v_alpha, lk, partials, tile_loss, tile_order);
+                     v_rgb, v_depth, v_alpha, lk, partials, tile_loss, tile_order,
+                     (const unsigned long long*)slot_ok);
   TGS_CHECK_LAUNCH();
   return TGS_OK;
 }
@@ -633,8 +646,8 @@ extern "C" int tgs_rasterize_bwd(const TgsCamera* cam, const float* splats,
                                  const float* final_T, const float* v_rgb,
                                  const float* v_depth, const float* v_alpha,
                                  const TgsLossSpec* loss, float* partials, float* tile_loss,
-                                 void* stream) {
-  return rasterize_bwd_impl(cam, splats, group_base, sorted_gid, tile_start, tile_order, out_rgb, out_depth, final_T, v_rgb, v_depth, v_alpha, loss, partials, tile_loss, -1, stream);
+                                 const uint64_t* slot_ok, void* stream) {
+  return rasterize_bwd_impl(cam, splats, group_base, sorted_gid, tile_start, tile_order, out_rgb, out_depth, final_T, v_rgb, v_depth, v_alpha, loss, partials, tile_loss, -1, slot_ok, stream);
 }
 
 extern "C" int tgs_rasterize_bwd_band(const TgsCamera* cam, const float* splats,
@@ -644,7 +657,13 @@ extern "C" int tgs_rasterize_bwd_band(const TgsCamera* cam, const float* splats,
                                  const float* final_T, const float* v_rgb,
                                  const float* v_depth, const float* v_alpha,
                                  const TgsLossSpec* loss, float* partials, float* tile_loss,
-                                 int band, void* stream) {
+                                 int band, const uint64_t* slot_ok, void* stream) {
   TGS_CHECK_ARG(band >= 0, "band < 0");
-  return rasterize_bwd_impl(cam, splats, group_base, sorted_gid, tile_start, tile_order, out_rgb, out_depth, final_T, v_rgb, v_depth, v_alpha, loss, partials, tile_loss, band, stream);
+  return rasterize_bwd_impl(cam, splats, group_base, sorted_gid, tile_start, tile_order, out_rgb, out_depth, final_T, v_rgb, v_depth, v_alpha, loss, partials, tile_loss, band, slot_ok, stream);
+}
+
+extern "C" size_t tgs_slot_ok_len(int W, int H, int64_t capacity) {
+  if (capacity < 0) capacity = 0;
+  const size_t T = (size_t)((W + TGS_BLOCK - 1) / TGS_BLOCK) * (size_t)((H + TGS_BLOCK - 1) / TGS_BLOCK);
+  return (size_t)(capacity >> 6) + T + 2;
 }

@@ -31,12 +31,14 @@ int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* gro
 // counter buffer layout: count[8][T] | sub_start[8][T] | scan aggregates[64] | longest list[1] (+pad)
 #define TGS_XCC 8
 #define TGS_SCAN_WGS 64
-// ... | pair allocators: one 128-B line per XCD holding {allocated pairs, pairs that found no room,
-// largest group total seen}.  The pair index space [0, capacity) is cut into one region per XCD and a
+// ... | pair allocators: one 128-B line per XCD holding {allocated pairs, pairs that found no room}.  The pair index space [0, capacity) is cut into one region per XCD and a
 // group takes its contiguous pair range from the region of the XCD it runs on; if that region is
 // full (which XCD runs which workgroup is not deterministic, and with few groups the shares are very
 // uneven) it takes the range from the first other region with room.  An allocation can therefore
-// only fail when  #pairs + 8 x (largest group total) > capacity  -- the bound status[2] reports.
+// only fail when  #pairs + 8 x (largest group total) > capacity  -- the bound status[2] reports
+// (k_scan_tiles reads the group totals off the records of each group's last Gaussian: a per-group
+// atomicMax on the allocator lines cost the front half 25 us at cfg3, memory-side atomics on one line
+// serialise at ~13 ns each).
 #define TGS_ALLOC_STRIDE 32
 #define TGS_ALLOC_OFF(T) ((2 * TGS_XCC * (T) + TGS_SCAN_WGS + 4 + 31) / 32 * 32)
 static inline int tgs_counter_len(int T) { return TGS_ALLOC_OFF(T) + TGS_XCC * TGS_ALLOC_STRIDE; }
@@ -168,17 +170,9 @@ __device__ __forceinline__ void group_count_tiles(GroupScan& S, int TW, int T, i
   const int x = xcc_id();
   // pair range of the group: one returning atomic on the XCD's allocator.  Issued first and consumed
   // last (publication below), so its round trip to the memory side overlaps the counting.
-  int local = 0, seen_max = 0;
+  int local = 0;
   int32_t* __restrict__ alloc = tile_count + TGS_ALLOC_OFF(T);
-  if (tid == 0 && total > 0) {
-    local = atomicAdd(&alloc[x * TGS_ALLOC_STRIDE], total);
-    // largest group total so far (a stale value only costs an unnecessary atomicMax below)
-#ifndef TGS_AB_NO_GROUP_MAX   // same-box A/B switch
-    seen_max = __hip_atomic_load(&alloc[x * TGS_ALLOC_STRIDE + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    seen_max = 1 << 30;
-#endif
-  }
+  if (tid == 0 && total > 0) local = atomicAdd(&alloc[x * TGS_ALLOC_STRIDE], total);
   int32_t* __restrict__ my_count = tile_count + (size_t)x * T;
   int bx0 = 1 << 30, by0 = 1 << 30, bx1 = 0, by1 = 0;   // tile bounding box of the group's rects
 #pragma unroll
@@ -229,7 +223,6 @@ __device__ __forceinline__ void group_count_tiles(GroupScan& S, int TW, int T, i
       }
       if (!fits) atomicAdd(&alloc[x * TGS_ALLOC_STRIDE + 1], total);   // still part of the frame's pair count
     }
-    if (total > seen_max) atomicMax(&alloc[x * TGS_ALLOC_STRIDE + 2], total);
     const int base = (int)(xr * region + loc);
     S.base = base;
     S.fits = fits;
