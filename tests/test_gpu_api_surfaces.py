@@ -37,8 +37,13 @@ def test_gsplat_shaped_ops_match_fused_path_and_oracle(dev):
     D2 = {k: v.detach().clone().requires_grad_(True) for k, v in D.items()}
     rgb2, dacc2, alpha2, radii2 = ops.render(D2["means"], D2["log_scales"], D2["quats"], D2["opac_logit"], D2["sh"], acam, deg)
     assert torch.equal(radii, radii2)
-    assert torch.allclose(rgb, rgb2, atol=2e-5) and torch.allclose(alpha, alpha2, atol=2e-5)
-    assert torch.allclose(depth_im, dacc2, atol=2e-4, rtol=1e-4)
+    # the two-op path hands ABSOLUTE fp32 screen positions across the gsplat-shaped API (xys: 7.6e-6 px off the
+    # fused path's rect-relative, compensated ones at x ~ 160): the images agree to 2e-5 except where that
+    # difference flips an alpha >= 1/255 / T <= 1e-4 decision of a single pixel (seen: 1 pixel, 1.6e-4)
+    d_rgb, d_a = (rgb - rgb2).abs().amax(-1), (alpha - alpha2).abs()
+    assert int((d_rgb > 2e-5).sum()) <= 3 and int((d_a > 2e-5).sum()) <= 3, (int((d_rgb > 2e-5).sum()), int((d_a > 2e-5).sum()))
+    assert d_rgb.max().item() < 2e-3 and d_a.max().item() < 2e-3
+    assert int(((depth_im - dacc2).abs() > 2e-4 + 1e-4 * dacc2.abs()).sum()) <= 3
     # --- gradients through the two-op path equal the fused path's ---
     g = torch.Generator().manual_seed(3)
     w = torch.randn(H, W, 3, generator=g).to(dev)
@@ -251,6 +256,21 @@ assert int(lo) == int(hi) and dm.params.N != N, (int(lo), int(hi), N)
 dp.assert_replicas_identical(dm.params.flat)
 dp.assert_replicas_identical(dm.optimizer.exp_avg_sq)
 dp.barrier()
+# ... and with the sync-free budget on top (refinements are its barrier points; a forced overflow is
+# replayed, overflowed frames add nothing to the refinement statistics): same Gaussians, bit for bit
+ds = fresh()
+ds.enable_densification(DensifyConfig(warmup_length=2, refine_every=4, densify_grad_thresh=1e-5,
+                                      densify_size_thresh=0.02, cull_alpha_thresh=0.01, reset_alpha_every=0))
+ds.enable_speculative_budget(capacity=3000, max_in_flight=2)
+for step in range(9):
+    ds.train_step(views[dp.views_for_step(step, 4)], dp)
+ds.flush()
+torch.cuda.synchronize()
+assert ds.speculative_replays > 0 and ds.step == dm.step == 9
+assert ds.params.N == dm.params.N and torch.equal(ds.params.flat, dm.params.flat), (ds.params.N, dm.params.N)
+assert torch.equal(ds.optimizer.exp_avg_sq, dm.optimizer.exp_avg_sq)
+dp.assert_replicas_identical(ds.params.flat)
+dp.barrier()
 if dp.rank == 0: print("DP_OK", d)
 '''
 
@@ -269,6 +289,28 @@ def test_data_parallel_train_step_two_ranks_one_gpu(dev, tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", "29633", str(script), root],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_trainer_two_ranks_overflow_before_eval_boundary(dev, tmp_path):
+    """the trainer CLI with two ranks (sharing the GPU over gloo), the sync-free budget forced to
+    overflow (TGS_SPEC_CAPACITY), refinement every 4 steps and eval / save boundaries every 5: every rank
+    drains its pending verdicts at the same steps (a rank-0-only flush left the replayed collectives
+    unmatched), so the run completes, refines, and ends with identical replicas (train.main asserts it)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TGS_DIST_BACKEND="gloo", TGS_SPEC_CAPACITY="3000", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = tmp_path / "out"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29671", "-m", "touch_gs_amd.train",
+                        "--synthetic", "4000", "160", "96", "--sh-degree", "1", "--max-num-iterations", "14",
+                        "--steps-per-eval", "5", "--steps-per-save", "10", "--warmup-length", "4", "--refine-every", "4",
+                        "--output-dir", str(out)],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "step 5:" in r.stdout and "step 10:" in r.stdout
+    line = [l for l in r.stdout.splitlines() if l.startswith("{") and "psnr" in l]
+    assert line and json.loads(line[-1])["psnr"] > 0
+    assert "speculative replays" in r.stdout and "refinements" in r.stdout, r.stdout[-1500:]
 
 
 @pytest.mark.parametrize("deg,interval,clamp", [(3, 0, False), (1, 0, False), (3, 1000, False), (3, 2, False),

@@ -156,15 +156,19 @@ def main(argv=None):
     if not args.sync_budget and (dp.world == 1 or model.optimizer.can_gather_sh()):
         # no per-step host sync; an overflow is detected late and replayed (data parallel: the ranks
         # agree on it on the device and replay the same steps)
-        model.enable_speculative_budget()
+        # TGS_SPEC_CAPACITY: test hook -- an initial capacity far too small forces the overflow / replay path
+        model.enable_speculative_budget(capacity=int(os.environ.get("TGS_SPEC_CAPACITY", "0")))
     train_views = [views[i] for i in i_train]
     eval_views = [views[i] for i in i_eval] or train_views[:1]
     t0 = time.time()
+    seen_refine, n_refines = None, 0
     for step in range(model.step, args.max_num_iterations):
         view = train_views[dp.views_for_step(step, len(train_views))]
         # single process: tell the step which view follows (colour prefetch, model.train_step)
         nxt = None if dp.active else train_views[dp.views_for_step(step + 1, len(train_views))]
         model.train_step(view, dp if dp.active else None, next_view=nxt)
+        if getattr(model, "_refined_at", None) == model.step and seen_refine != model.step:
+            seen_refine, n_refines = model.step, n_refines + 1
         at_eval = (step + 1) % args.steps_per_eval == 0
         at_save = (step + 1) % args.steps_per_save == 0 or step + 1 == args.max_num_iterations
         if at_eval or at_save:
@@ -181,6 +185,9 @@ def main(argv=None):
     model.flush()
     if dp.world > 1:
         dp.assert_replicas_identical(model.params.flat)
+    if dp.rank == 0:
+        print(f"gaussians {model.params.N}  refinements {n_refines}  speculative replays "
+              f"{getattr(model, 'speculative_replays', 0)}", flush=True)
     if dp.rank == 0:
         results = evaluate(model, eval_views)
         # the reference's aggregator indexes results['lpips'] unconditionally
