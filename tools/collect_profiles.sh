@@ -13,7 +13,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
 rm -rf /tmp/prof_ks
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > /tmp/ks.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-densify-run > /tmp/ks.log 2>&1
 cp $(ls /tmp/prof_ks/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" \

@@ -5,7 +5,7 @@ TAG=$1; shift
 export TMPDIR=/tmp
 cd ${GRAFT_REPO_ROOT:-.}
 rm -rf /tmp/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > /tmp/ks_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-densify-run "$@" > /tmp/ks_$TAG.log 2>&1
 mkdir -p gpurun_out
 cp $(ls /tmp/prof_$TAG/*/*kernel_stats.csv | head -1) gpurun_out/kstats_$TAG.csv
 python - <<PY
