@@ -72,6 +72,35 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int T, int NB, int32_t* __r
   __shared__ int wave_mg[16];
   __shared__ int s_base;
   const int tid = threadIdx.x;
+  if ((int)blockIdx.x == (int)gridDim.x - 1) {
+    // The LAST workgroup writes the status word, beside the scan (it needs nothing from it):
+    // status[0]: the frame's intersection count = the 8 per-XCD allocators + the pairs that found no
+    // room; status[2]: the capacity that is SUFFICIENT for this frame whatever XCD its workgroups run
+    // on, #pairs + 8 x the largest group total (tgs_binning.h).  A group's total = in-group offset of its
+    // last Gaussian (record slot 11) + that Gaussian's tile count (rect in slot 10).  On overflow
+    // status[0] = status[2], so that a caller that grows to status[0] x growth converges in one retry.
+    int mg = 0;
+    const int G = (N + TGS_GROUP - 1) / TGS_GROUP;
+    for (int g = tid; g < G; g += 1024) {
+      const float* rec = splats + (size_t)min(g * TGS_GROUP + TGS_GROUP - 1, N - 1) * TGS_SPLAT_FLOATS;
+      int x0, y0, w, h;
+      unpack_rect(__float_as_uint(rec[10]), x0, y0, w, h);
+      mg = max(mg, __float_as_int(rec[11]) + w * h);
+    }
+    mg = wave_max_i(mg);
+    if ((tid & 63) == 0) wave_mg[tid >> 6] = mg;
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 16; w++) mg = max(mg, wave_mg[w]);
+      const int32_t* xa = tile_count + TGS_ALLOC_OFF(T);
+      long long n = 0;
+      for (int x = 0; x < TGS_XCC; x++) n += (long long)xa[x * TGS_ALLOC_STRIDE] + xa[x * TGS_ALLOC_STRIDE + 1];
+      const long long need = n + (long long)TGS_XCC * mg;
+      status[0] = (int32_t)min(status[1] != 0 ? need : n, 0x7fffffffll);
+      status[2] = (int32_t)min(need, 0x7fffffffll);
+    }
+    return;
+  }
   if ((int)blockIdx.x >= NB) {
     // K6 / K7 schedule when no sort launch follows (no Gaussians: every list is empty): the XCD's
     // slots in spatial order
@@ -133,34 +162,6 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int T, int NB, int32_t* __r
     }
   }
   if (b == NB - 1 && tid == 0) tile_start[T] = s_base + tot;
-  if (b == 0) {
-    // status[0]: the frame's intersection count = the 8 per-XCD allocators + the pairs that found no
-    // room; status[2]: the capacity that is SUFFICIENT for this frame whatever XCD its workgroups run
-    // on, #pairs + 8 x the largest group total (tgs_binning.h).  A group's total = in-group offset of its
-    // last Gaussian (record slot 11) + that Gaussian's tile count (rect in slot 10).  On overflow
-    // status[0] = status[2], so that a caller that grows to status[0] x growth converges in one retry.
-    // Done last: the other scan workgroups only wait for this one's aggregate, published above.
-    int mg = 0;
-    const int G = (N + TGS_GROUP - 1) / TGS_GROUP;
-    for (int g = tid; g < G; g += 1024) {
-      const float* rec = splats + (size_t)min(g * TGS_GROUP + TGS_GROUP - 1, N - 1) * TGS_SPLAT_FLOATS;
-      int x0, y0, w, h;
-      unpack_rect(__float_as_uint(rec[10]), x0, y0, w, h);
-      mg = max(mg, __float_as_int(rec[11]) + w * h);
-    }
-    mg = wave_max_i(mg);
-    if ((tid & 63) == 0) wave_mg[tid >> 6] = mg;
-    __syncthreads();
-    if (tid == 0) {
-      for (int w = 1; w < 16; w++) mg = max(mg, wave_mg[w]);
-      const int32_t* xa = tile_count + TGS_ALLOC_OFF(T);
-      long long n = 0;
-      for (int x = 0; x < TGS_XCC; x++) n += (long long)xa[x * TGS_ALLOC_STRIDE] + xa[x * TGS_ALLOC_STRIDE + 1];
-      const long long need = n + (long long)TGS_XCC * mg;
-      status[0] = (int32_t)min(overflow ? need : n, 0x7fffffffll);
-      status[2] = (int32_t)min(need, 0x7fffffffll);
-    }
-  }
 }
 
 // K3b: scatter (gid, depth bits) into the tile bins.  slot = tile_start + arrival rank.
@@ -489,7 +490,7 @@ int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* gro
   const int chunk = tgs_band_slots(T), n_sub = tgs_band_count(T);
   const int n_order = order_in_sort ? TGS_XCDS * n_sub : 0;
   (void)per;
-  hipLaunchKernelGGL(k_scan_tiles, dim3(NB + ((tile_order && !order_in_sort) ? 8 : 0)), dim3(1024), 0, s, T, NB,
+  hipLaunchKernelGGL(k_scan_tiles, dim3(NB + ((tile_order && !order_in_sort) ? 8 : 0) + 1), dim3(1024), 0, s, T, NB,
                      tile_cursor, tile_start, status, tile_order, splats, N);
   TGS_CHECK_LAUNCH();
   if (G > 0) {
