@@ -152,7 +152,7 @@ class DensityController:
             nz = noise[within[spos] * split_n + rank_of[src[spos]]]
             R = quat_to_rotmat(new["quats"][spos])
             sc = torch.exp(new["log_scales"][spos])
-            new["means"][spos] += torch.einsum("nij,nj->ni", R, nz * sc)
+            new["means"][spos] += (R * (nz * sc)[:, None, :]).sum(-1)      # R (noise * scale), without a BLAS call
             new["log_scales"][spos] -= math.log(1.6)
         for k in names:                                      # new rows start with zero moments
             m_new[k][is_new] = 0
