@@ -78,8 +78,9 @@ def measured_traffic(kernel_key, N, W, H, deg):
         try:
             with open(path) as f:
                 d = json.load(f)
-            return (int(d["hbm_bytes_per_launch_corrected"][names[kernel_key]]["total_bytes"]),
-                    os.path.relpath(path, ROOT))
+            h = d["hbm_bytes_per_launch_corrected"]
+            key = next(k for k in h if k.startswith(names[kernel_key].split("<")[0]) and "<true" not in k)
+            return int(h[key]["total_bytes"]), os.path.relpath(path, ROOT)
         except Exception:
             continue
     return None, None
@@ -102,8 +103,8 @@ def valu_utilisation(kern_ms, N, W, H, deg):
                 c = json.load(f)["counters"]
             out = {"peak_wave_instr_per_s": round(peak, -9), "peak_spec_2cycle_wave_instr_per_s": round(peak_spec, -9),
                    "source": os.path.relpath(path, ROOT)}
-            for key, name in (("raster_fwd", "k_raster_fwd<false>"), ("raster_bwd", "k_raster_bwd")):
-                n = c[name]["SQ_INSTS_VALU"]
+            for key, name in (("raster_fwd", "k_raster_fwd"), ("raster_bwd", "k_raster_bwd")):
+                n = c[next(k for k in c if k.startswith(name) and "<true" not in k)]["SQ_INSTS_VALU"]
                 rate = n / (kern_ms[key] * 1e-3)
                 out[key] = {"valu_wave_instr": int(n), "frac_of_issue_peak": round(rate / peak, 3),
                             "frac_of_spec_2cycle_peak": round(rate / peak_spec, 3)}
