@@ -282,6 +282,24 @@ def test_slot_ok_bitmaps_do_not_change_the_backward(dev, monkeypatch):
         assert int((words != 0).sum()) > 0
 
 
+@pytest.mark.parametrize("N,W,H,seed,clamp", [(20000, 320, 208, 78, False), (3000, 100, 70, 79, True), (60000, 256, 256, 80, False)])
+def test_k6_block_form_is_bit_identical(dev, monkeypatch, N, W, H, seed, clamp):
+    """The 4x4-block form of K6 (every DPP row of the wave walks its own block's list, TGS_K6_BLOCKS=1) against
+    the quadrant form: same eval / blend on the same pixels in the same list order -> images, final T and the
+    last-contributor index equal bit for bit (a block wrongly culled would show up as a missing contribution)."""
+    from touch_gs_amd import ops
+    P, cam = (clamp_scene if clamp else scene)(N, W, H, 3, seed)
+    acam = amd_cam(cam)
+    D = to_dev(P, dev)
+    sp, _, gb, ts, sg, st = ops.project_bin_sort(acam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], 3)
+    res = []
+    for on in ("0", "1"):
+        monkeypatch.setenv("TGS_K6_BLOCKS", on)
+        res.append(ops.rasterize_fwd(acam, sp, sg, ts, want_idx=True))
+    for a, b in zip(*res):
+        assert torch.equal(a, b), (a.float() - b.float()).abs().max().item()
+
+
 def test_deterministic_bitwise(dev):
     from touch_gs_amd import ops
     P, cam = scene(5000, 200, 120, 3, 61)

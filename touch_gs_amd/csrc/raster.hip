@@ -6,7 +6,8 @@
 // gsplat `rasterize_gaussians` (App. A.2) -- but RGB and depth are composited in ONE pass instead
 // of the two full rasterizations Splatfacto issues.
 //
-// MI355X mapping (not a warp-shaped CUDA tiling):
+// MI355X mapping (not a warp-shaped CUDA tiling; the forward's default since round 3 is the 4x4-block form
+// further down, k_raster_fwd_blocks -- this describes the quadrant form, which the backward uses):
 //  * one wave64 owns one 16x16 tile.  Lane l owns 4 pixels, one per 8x8 quadrant ("slot" k):
 //    (x, y) = (8*(k&1) + (l&7), 8*(k>>1) + (l>>3)).  No workgroup barriers, no cross-wave traffic.
 //  * the tile's Gaussian list is staged 64 records at a time through LDS.  While staging, lane j
@@ -30,6 +31,7 @@
 //    sum in K8 (deterministic, and it avoids cross-XCD memory-side atomics).
 //  * blockIdx -> tile mapping gives each XCD a contiguous band of tiles so the gathered splat
 //    records of neighbouring tiles stay in that XCD's 4 MB L2.
+#include <stdlib.h>
 #include <type_traits>
 #include "tgs_common.h"
 
@@ -90,6 +92,7 @@ __device__ __forceinline__ void centre_rel(float4 r0, float4 r2, int tx, int ty,
   gy = r0.y - ((float)(dy * TGS_BLOCK) + (7.5f + pix_center));
 }
 
+template <bool QUAD_MASK = true>
 __device__ __forceinline__ TileRec make_tile_rec(float4 r0, float4 r1, float4 r2, float gx, float gy) {
   // r0 = {x - 16 x0, y - 16 y0, depth, opac}  r1 = {a, b, c, r}  r2 = {g, b, rect, off};  (gx, gy) = centre_rel()
   const float A = r1.x, B = r1.y, Cc = r1.z;
@@ -108,7 +111,7 @@ __device__ __forceinline__ TileRec make_tile_rec(float4 r0, float4 r1, float4 r2
   // centres (interior point if the centre projects inside, else the best point on the 4 edges).
   unsigned mask = 0u;
   const float slack = LOG2_255 + 1e-3f;
-  if (L < LOG2_255) {
+  if (QUAD_MASK && L < LOG2_255) {
     const float c0 = t.a.x, c1 = t.a.y, c2 = t.a.z, c3 = t.a.w, c4 = t.b.x, c5 = t.b.y;
     // approximate reciprocals suffice: the test carries a 1e-3 slack and only decides skipping
     const float ic3 = __builtin_amdgcn_rcpf(c3), ic5 = __builtin_amdgcn_rcpf(c5);
@@ -286,6 +289,191 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
     if (WANT_OK && lane == 0) {
       unsigned long long* o = slot_ok + 4 * slot_ok_index(base, tile);
       o[0] = okm[0]; o[1] = okm[1]; o[2] = okm[2]; o[3] = okm[3];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (pxi[k] < cam.W && pyi[k] < cam.H) {
+      const size_t p = (size_t)pyi[k] * cam.W + pxi[k];
+      out_rgb[3 * p] = Cr[k] + T[k] * cam.bg[0];
+      out_rgb[3 * p + 1] = Cg[k] + T[k] * cam.bg[1];
+      out_rgb[3 * p + 2] = Cb[k] + T[k] * cam.bg[2];
+      out_depth[p] = D[k];
+      final_T[p] = T[k];
+      if (WANT_IDX) final_idx[p] = last[k];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6, 4x4-block form (round 3)
+// ---------------------------------------------------------------------------------------------
+// The quadrant form above evaluates a Gaussian on a whole 8x8 quadrant as soon as it reaches one of its
+// pixels: 63 % of the evaluated lanes are pixels the Gaussian does not touch.  A wave
+// instruction covers 64 pixels whatever the mask, so finer culling needs DIFFERENT Gaussians in different
+// parts of one instruction.  Here the four 16-lane rows of the wave (DPP rows) own the four 4x4 blocks
+// of the current quadrant and every row walks its OWN block's list: per batch of 64 staged Gaussians a
+// 16-bit block mask per Gaussian (exact: the u-extent of the ellipse {alpha >= 1/255} over each block
+// row's v-range against the blocks' pixel-centre rectangles) is compacted into 16 index lists in LDS;
+// quadrant s then runs max(len of its 4 lists) iterations -- never more than the quadrant form's
+// |union| -- in which lane l reads the Gaussian its row is at (per-lane LDS address, padded with a null
+// record).  No per-Gaussian bit scan and no quadrant tests: ~3 scalar instructions per iteration
+// instead of ~10.  Same eval_s / blend_step on the same pixel constants in the same list order: the
+// images are bit-identical to the quadrant form (test_k6_block_form_is_bit_identical).
+// Only the forward can do this: the backward's per-Gaussian sums would have to be accumulated across
+// rows and iterations (5.1: ds_add_f32 costs 194 cycles).
+__device__ __forceinline__ unsigned row_bits(float ulo, float uhi) {
+  // blocks bx (pixel centres u in [4 bx - 7.5, 4 bx - 4.5]) that meet [ulo, uhi]: bx in [lo, h1 - 1];
+  // an empty range (h1 <= lo) gives 0 by itself
+  const int lo = min(max((int)ceilf(fminf(fmaf(ulo, 0.25f, 1.125f), 8.f)), 0), 4);
+  const int h1 = min(max((int)floorf(fmaxf(fmaf(uhi, 0.25f, 2.875f), -8.f)), 0), 4);   // hi + 1
+  return ((1u << h1) - 1u) & ~((1u << lo) - 1u);
+}
+
+// 16-bit mask of the 4x4 blocks (bit 4 by + bx) in which alpha >= 1/255 can hold at a pixel centre.
+// (gx, gy) = centre relative to the tile centre, (A, B, C) = conic, L = -log2(opacity).
+__device__ __forceinline__ unsigned block_mask16(float gx, float gy, float A, float B, float C, float L) {
+  if (!(L < LOG2_255)) return 0u;
+  // region: A du^2 + 2 B du dv + C dv^2 <= t2,  t2 = 2 ln(255 o) (+ slack)
+  const float t2 = 2.0f * (LOG2_255 + 2e-3f - L) * 0.6931471805599453f;
+  const float M = 0.02f;                                      // margin in pixels (rounding of the roots)
+  const float iA = __builtin_amdgcn_rcpf(A), iC = __builtin_amdgcn_rcpf(C);
+  const float det = fmaxf(A * C - B * B, 1e-30f);
+  const float dumax = sqrtf(t2 * C * __builtin_amdgcn_rcpf(det));   // horizontal half extent of the ellipse
+  const float vr = gy - B * iC * dumax, vl = gy + B * iC * dumax;    // rows of its rightmost / leftmost point
+  // On the line v the ellipse spans  du = (-B dv -+ sqrt(B^2 dv^2 - A (C dv^2 - t2))) / A.  Its right end
+  // u_hi(v) is concave in v with its maximum at vr, so over a block row's v-range [v0, v1] the rightmost
+  // point lies on the line v = clamp(vr, v0, v1) (likewise the leftmost on clamp(vl, v0, v1)): two line
+  // evaluations per block row give the exact u-range of (ellipse n strip).  A line the ellipse does not
+  // reach gives sqrt(negative) = NaN, which fminf / fmaxf replace by +-3e38: an empty range in row_bits.
+  unsigned mask = 0u;
+#pragma unroll
+  for (int row = 0; row < 4; row++) {
+    const float v0 = (float)(4 * row) - 7.5f, v1 = v0 + 3.f;
+    const float dvh = fminf(fmaxf(vr, v0), v1) - gy, dvl = fminf(fmaxf(vl, v0), v1) - gy;
+    const float hbh = B * dvh, hbl = B * dvl;
+    const float rh = __builtin_amdgcn_sqrtf(fmaf(hbh, hbh, -A * fmaf(C * dvh, dvh, -t2)));
+    const float rl = __builtin_amdgcn_sqrtf(fmaf(hbl, hbl, -A * fmaf(C * dvl, dvl, -t2)));
+    const float hi = fmaf(rh - hbh, iA, gx), lo = fmaf(-hbl - rl, iA, gx);
+    // NaN (row not reached) must give an empty range: fminf / fmaxf return the non-NaN operand
+    mask |= row_bits(fminf(lo - M, 3.0e38f), fmaxf(hi + M, -3.0e38f)) << (4 * row);
+  }
+  return mask;
+}
+
+#ifndef TGS_BLK_U
+#define TGS_BLK_U 2        // list entries (iterations) per index read; a quadrant's trip count is rounded up to it
+#endif
+constexpr int BLK_U = TGS_BLK_U;
+typedef std::conditional<BLK_U == 4, unsigned int, std::conditional<BLK_U == 2, unsigned short, unsigned char>::type>::type BLK_T;
+
+template <bool WANT_IDX>
+__global__ __launch_bounds__(64) void k_raster_fwd_blocks(
+    CamK cam, int T_total, const float* __restrict__ splats, const int32_t* __restrict__ sorted_gid,
+    const int32_t* __restrict__ tile_start, float* __restrict__ out_rgb,
+    float* __restrict__ out_depth, float* __restrict__ final_T, int32_t* __restrict__ final_idx,
+    const int32_t* __restrict__ tile_order) {
+  const int tile = tile_order ? tile_order[blockIdx.x] : xcd_tile(blockIdx.x, T_total);
+  if (tile >= T_total) return;
+  const int lane = threadIdx.x;
+  const int ty = tile / cam.TW, tx = tile - ty * cam.TW;
+  // lane -> pixel: DPP row g = lane >> 4 owns block (g & 1, g >> 1) of the quadrant, lane & 15 = pixel in it
+  const int g = lane >> 4, lx = 4 * (g & 1) + (lane & 3), ly = 4 * (g >> 1) + ((lane >> 2) & 3);
+  PixConst pc;
+  pc.u[0] = (float)lx - 7.5f; pc.u[1] = pc.u[0] + 8.f;
+  pc.v[0] = (float)ly - 7.5f; pc.v[1] = pc.v[0] + 8.f;
+#pragma unroll
+  for (int i = 0; i < 2; i++) { pc.uu[i] = pc.u[i] * pc.u[i]; pc.vv[i] = pc.v[i] * pc.v[i]; }
+#pragma unroll
+  for (int k = 0; k < 4; k++) pc.uv[k] = pc.u[k & 1] * pc.v[k >> 1];
+  int pxi[4], pyi[4];
+  float smax[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    pxi[k] = tx * TGS_BLOCK + 8 * (k & 1) + lx;
+    pyi[k] = ty * TGS_BLOCK + 8 * (k >> 1) + ly;
+    smax[k] = ((pxi[k] < cam.W) && (pyi[k] < cam.H)) ? LOG2_255 : -3.0e38f;
+  }
+  float T[4] = {1.f, 1.f, 1.f, 1.f};
+  float Cr[4] = {0.f, 0.f, 0.f, 0.f}, Cg[4] = {0.f, 0.f, 0.f, 0.f}, Cb[4] = {0.f, 0.f, 0.f, 0.f};
+  float D[4] = {0.f, 0.f, 0.f, 0.f};
+  int last[4] = {-1, -1, -1, -1};
+
+  __shared__ float4 recs[65 * 3];                 // 64 staged Gaussians + the null record (alpha = 0)
+  __shared__ unsigned int lists4[16 * 16];        // 16 lists of 64 one-byte indices, padded with 64 = null
+  unsigned char* lists = reinterpret_cast<unsigned char*>(lists4);
+  if (lane == 0) {
+    recs[64 * 3] = make_float4(3.0e38f, 0.f, 0.f, 0.f);
+    recs[64 * 3 + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    recs[64 * 3 + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int start = tile_start[tile], end = tile_start[tile + 1];
+  // my row's list in quadrant k: block (2 (k & 1) + (g & 1), 2 (k >> 1) + (g >> 1))
+  int myblock[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) myblock[k] = 4 * (2 * (k >> 1) + (g >> 1)) + 2 * (k & 1) + (g & 1);
+
+  unsigned live16 = 0xffffu;
+  for (int base = start; base < end; base += 64) {
+    // live blocks: bit 4 by + bx = some pixel of the block is still live.  A stale (larger) set only costs
+    // iterations on stopped pixels, so the 16 block tests are refreshed every 4th batch; the exit test
+    // (nothing live in the tile) runs on every batch.
+    unsigned long long lv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) lv[k] = __ballot(smax[k] > 0.f);
+    if ((lv[0] | lv[1] | lv[2] | lv[3]) == 0ull) break;
+    if ((((base - start) >> 6) & 3) == 0) {
+      live16 = 0u;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          live16 |= ((lv[k] >> (16 * r)) & 0xffffull) ? (1u << (4 * (2 * (k >> 1) + (r >> 1)) + 2 * (k & 1) + (r & 1))) : 0u;
+    }
+    __syncthreads();
+    unsigned my_mask = 0u;
+    if (base + lane < end) {
+      const float* r = splats + (size_t)sorted_gid[base + lane] * TGS_SPLAT_FLOATS;
+      const float4 q0 = ld4(r), q1 = ld4(r + 4), q2 = ld4(r + 8);
+      float gx, gy;
+      centre_rel(q0, q2, tx, ty, cam.pix_center, gx, gy);
+      const TileRec t = make_tile_rec<false>(q0, q1, q2, gx, gy);
+      recs[lane * 3] = t.a; recs[lane * 3 + 1] = t.b; recs[lane * 3 + 2] = t.c;
+      my_mask = block_mask16(gx, gy, q1.x, q1.y, q1.z, -__log2f(q0.w)) & live16;
+    }
+    reinterpret_cast<uint4*>(lists4)[lane] = make_uint4(0x40404040u, 0x40404040u, 0x40404040u, 0x40404040u);
+    __syncthreads();
+    int cnt[16];
+#pragma unroll
+    for (int b = 0; b < 16; b++) {
+      const bool in = (my_mask >> b) & 1u;
+      const unsigned long long bal = __ballot(in);
+      cnt[b] = __popcll(bal);
+      if (in) lists[b * 64 + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (unsigned char)lane;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int b0 = 8 * (k >> 1) + 2 * (k & 1);                 // blocks b0, b0 + 1, b0 + 4, b0 + 5
+      const int n = max(max(cnt[b0], cnt[b0 + 1]), max(cnt[b0 + 4], cnt[b0 + 5]));
+      const BLK_T* mylist = reinterpret_cast<const BLK_T*>(lists4) + myblock[k] * (64 / BLK_U);
+      for (int i4 = 0; BLK_U * i4 < n; i4++) {
+        const unsigned idx4 = mylist[i4];
+#pragma unroll
+        for (int e = 0; e < BLK_U; e++) {
+          const int j = (idx4 >> (8 * e)) & 0xffu;               // 64 = null record: s = 3e38, alpha = 0
+          const float4 qa = recs[j * 3], qb = recs[j * 3 + 1], qc = recs[j * 3 + 2];
+          const float s = eval_s(qa, qb, pc, k);
+          float Tn; bool go;
+          unsigned long long okb = 0ull;
+          const float al = blend_step<true, false>(s, T[k], smax[k], Tn, go, okb);
+          const float w = al * T[k];
+          Cr[k] = fmaf(w, qb.w, Cr[k]); Cg[k] = fmaf(w, qc.x, Cg[k]);
+          Cb[k] = fmaf(w, qc.y, Cb[k]); D[k] = fmaf(w, qb.z, D[k]);
+          T[k] = go ? Tn : T[k];
+          if (WANT_IDX) last[k] = go ? (base - start + j) : last[k];
+        }
+      }
     }
   }
 #pragma unroll
@@ -592,6 +780,20 @@ extern "C" int tgs_rasterize_fwd(const TgsCamera* cam, const float* splats,
   hipLaunchKernelGGL((k_raster_fwd<IDX, OK>), dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T, splats, \
                      sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx, tile_order,          \
                      (unsigned long long*)slot_ok)
+  // default: the 4x4-block form (-14.5 % at cfg3, bit-identical images); TGS_K6_BLOCKS=0 selects the quadrant
+  // form (read per call: tests and same-box A/B runs switch it), which also serves the slot_ok bitmaps
+  const char* e_blocks = getenv("TGS_K6_BLOCKS");
+  const int use_blocks = e_blocks ? atoi(e_blocks) : 1;
+  if (use_blocks && !slot_ok) {   // 4x4-block form (bit-identical images)
+    if (final_idx)
+      hipLaunchKernelGGL(k_raster_fwd_blocks<true>, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T, splats,
+                         sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx, tile_order);
+    else
+      hipLaunchKernelGGL(k_raster_fwd_blocks<false>, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T, splats,
+                         sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx, tile_order);
+    TGS_CHECK_LAUNCH();
+    return TGS_OK;
+  }
   if (final_idx) { if (slot_ok) TGS_LAUNCH_FWD(true, true); else TGS_LAUNCH_FWD(true, false); }
   else { if (slot_ok) TGS_LAUNCH_FWD(false, true); else TGS_LAUNCH_FWD(false, false); }
 #undef TGS_LAUNCH_FWD
