@@ -367,8 +367,11 @@ __device__ __forceinline__ unsigned block_mask16(float gx, float gy, float A, fl
 constexpr int BLK_U = TGS_BLK_U;
 typedef std::conditional<BLK_U == 4, unsigned int, std::conditional<BLK_U == 2, unsigned short, unsigned char>::type>::type BLK_T;
 
+#ifndef TGS_BLK_WAVES
+#define TGS_BLK_WAVES 4    // minimum waves per SIMD asked of the register allocator: 4 (89 VGPRs) and 6 (80) measure the same
+#endif
 template <bool WANT_IDX>
-__global__ __launch_bounds__(64) void k_raster_fwd_blocks(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TGS_BLK_WAVES, 8))) void k_raster_fwd_blocks(
     CamK cam, int T_total, const float* __restrict__ splats, const int32_t* __restrict__ sorted_gid,
     const int32_t* __restrict__ tile_start, float* __restrict__ out_rgb,
     float* __restrict__ out_depth, float* __restrict__ final_T, int32_t* __restrict__ final_idx,
