@@ -182,8 +182,8 @@ def densify_run(N, W, H, deg, seed, dev, views, steps=600, clustered=False):
                                          max_gaussians=int(1.6 * N)))
     m.enable_speculative_budget()
     n0 = m.params.N
-    W0 = 110   # warm-up: through the first refinement (step 100), whose torch ops pay ~0.45 s of one-off first-use
-    for i in range(W0):   # initialisation per process (tools/refine_cost.py: 448 ms against ~3 ms for every later one)
+    W0 = 110   # warm-up: through the first refinement (step 100), whose torch ops pay ~0.1 s of one-off first-use
+    for i in range(W0):   # initialisation per process (tools/refine_cost.py: 111 ms against ~3 ms for every later one)
         m.train_step(views[i % len(views)], next_view=views[(i + 1) % len(views)])
     m.flush()
     torch.cuda.synchronize()

@@ -318,10 +318,11 @@ class DepthGaussianSplattingModel:
         self._dp = None
 
     def _speculative_track(self, view: View, distributed: bool = False) -> None:
-        host = self._pinned.pop() if self._pinned else torch.empty(4, dtype=torch.int32).pin_memory()
-        host[:2].copy_(self.last["status"], non_blocking=True)
+        # pinned int32[6]: {#intersections, overflow, sufficient capacity, -} of this rank's frame | the verdict
+        host = self._pinned.pop() if self._pinned else torch.empty(6, dtype=torch.int32).pin_memory()
+        host[:4].copy_(self.budget.last_status4, non_blocking=True)
         # data parallel: the verdict is the agreed flag, not this rank's own
-        host[2:].copy_(self._dp_status if distributed else self.last["status"], non_blocking=True)
+        host[4:].copy_(self._dp_status if distributed else self.last["status"], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self._pending.append((view, host, ev))
@@ -336,8 +337,9 @@ class DepthGaussianSplattingModel:
             view, host, ev = self._pending[0]
             ev.synchronize()
             block = False
-            if int(host[3]) == 0:
+            if int(host[5]) == 0:
                 self._pending.popleft()
+                self._seen_need = max(getattr(self, "_seen_need", 0), int(host[2]), int(host[0]))
                 self._pinned.append(host)
                 if only_one:
                     return
@@ -488,10 +490,15 @@ class DepthGaussianSplattingModel:
             n_before = self.params.N
             self.params, self.optimizer, self.last_refine = density.refine(self.params, self.optimizer, self.step, dp)
             self._refined_at = self.step
-            if self.budget.speculative:   # the intersection count follows N; a wrong guess only costs a replay
-                grow = max(1.0, self.params.N / max(n_before, 1)) * 1.15
-                self.budget = ops.IntersectBudget(capacity=int(self.budget.capacity * grow) + 4096, sync=False,
-                                                  speculative=True)
+            if self.budget.speculative:
+                # the intersection count follows N: size the new buffers from the largest capacity any frame since
+                # the last refinement needed (the verdicts just drained carry it), scaled by the growth of N, +25 %;
+                # a wrong guess only costs a replay.  (Never from the old capacity: that would compound.)
+                seen = getattr(self, "_seen_need", 0)
+                ratio = max(1.0, self.params.N / max(n_before, 1))
+                cap = int(seen * ratio * 1.25) + 4096 if seen > 0 else int(self.budget.capacity * ratio) + 4096
+                self._seen_need = 0
+                self.budget = ops.IntersectBudget(capacity=cap, sync=False, speculative=True)
             else:
                 self.budget = ops.IntersectBudget()  # the intersection count changes with N
             self._prefetch_ready = None
