@@ -29,6 +29,15 @@ DEF_KERNEL(fma3, "v_fma_f32 %0, %0, %1, %2", OUT_RW, "v"(b), "v"(c))
 DEF_KERNEL(fma_samesrc, "v_fma_f32 %0, %0, %0, %1", OUT_RW, "v"(c))
 DEF_KERNEL(fmac, "v_fmac_f32_e32 %0, %1, %2", OUT_RW, "v"(b), "v"(c))
 DEF_KERNEL(fma_sgpr, "v_fma_f32 %0, %0, %1, %2", OUT_RW, "s"(seed), "v"(c))
+DEF_KERNEL(fmamk_lit, "v_fmamk_f32 %0, %1, 0x3dcccccd, %0", OUT_RW, "v"(b))
+DEF_KERNEL(fmaak_lit, "v_fmaak_f32 %0, %0, %1, 0x3dcccccd", OUT_RW, "v"(b))
+DEF_KERNEL(fma_inline, "v_fma_f32 %0, %0, 0.5, %1", OUT_RW, "v"(b))
+DEF_KERNEL(mul_sgpr, "v_mul_f32_e32 %0, %1, %0", OUT_RW, "s"(seed))
+DEF_KERNEL(add_sgpr, "v_add_f32_e32 %0, %1, %0", OUT_RW, "s"(seed))
+DEF_KERNEL(mul_lit, "v_mul_f32_e32 %0, 0x3dcccccd, %0", OUT_RW, "v"(b))
+DEF_KERNEL(cmp_sgprsrc, "v_cmp_lt_f32_e64 s[20:21], %1, %0", OUT_RW, "s"(seed) : "s20", "s21")
+DEF_KERNEL(cmp_vcc_lit, "v_cmp_lt_f32_e32 vcc, 0x38d1b717, %0", OUT_RW, "v"(b) : "vcc")
+DEF_KERNEL(fma_sgpr2, "v_fma_f32 %0, %1, %2, %0", OUT_RW, "s"(seed), "v"(c))
 DEF_KERNEL(mul, "v_mul_f32_e32 %0, %0, %1", OUT_RW, "v"(b))
 DEF_KERNEL(add, "v_add_f32_e32 %0, %0, %1", OUT_RW, "v"(b))
 DEF_KERNEL(min, "v_min_f32_e32 %0, %0, %1", OUT_RW, "v"(b))
@@ -86,12 +95,12 @@ int main(int argc, char** argv) {
   float* out; (void)hipMalloc(&out, 1 << 26);
   const int iters = 60000;
 #define T(NAME, N) {#NAME, k_##NAME, N}
-  Test tests[] = {T(fma3, 16), T(fma_samesrc, 16), T(fmac, 16), T(fma_sgpr, 16), T(mul, 16), T(add, 16), T(min, 16), T(mov, 16),
+  Test tests[] = {T(fma3, 16), T(fma_samesrc, 16), T(fmac, 16), T(fma_sgpr, 16), T(fmamk_lit, 16), T(fmaak_lit, 16), T(fma_inline, 16), T(mul_sgpr, 16), T(add_sgpr, 16), T(mul_lit, 16), T(cmp_sgprsrc, 16), T(cmp_vcc_lit, 16), T(fma_sgpr2, 16), T(mul, 16), T(add, 16), T(min, 16), T(mov, 16),
                   T(exp, 16), T(exp_neg, 16), T(rcp, 16), T(log, 16), T(sqrt, 16), T(cmp_vcc, 16), T(cmp_sgpr, 16),
                   T(cnd_sgpr, 16), T(pl16, 16), T(pl32, 16),
                   T(dpp_add, 16), T(fma_exp_mix, 64),};
   // waves per SIMD: blocks of 256 threads = 4 waves = one per SIMD; B blocks per CU resident -> B waves per SIMD
-  for (int wps : {1, 4}) {
+  for (int wps : {4}) {
     printf("--- %d wave(s) per SIMD (256 CUs x %d blocks of 256 threads, one round) ---\n", wps, wps);
     double base = 0;
     for (auto& t : tests) {

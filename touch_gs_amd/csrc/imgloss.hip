@@ -22,6 +22,19 @@ namespace {
 
 constexpr int WIN = 11, HALO = 5;
 struct Win { float g[WIN]; };
+// The window weights as compile-time constants (11-tap Gaussian, sigma 1.5, normalised in double and rounded
+// to fp32 -- the values the host used to pass as a kernel argument).  As kernel arguments they sat in SGPRs,
+// and on gfx950 a VALU instruction with an SGPR source is the most expensive form there is (v_mul / v_add
+// 5.45 cycles, v_fma 4.5 - 5.5, against 2.8 - 3.0 with a literal: tools/ubench/valu_cost.hip) -- every FMA
+// of the two filters is of that kind.  TGS_SSIM_SGPR_WINDOW restores the argument form for A/B runs.
+#ifdef TGS_SSIM_SGPR_WINDOW
+#define WK(k) win.g[k]
+#else
+__device__ constexpr float WGT[WIN] = {0x1.0d956cp-10f, 0x1.f1fe02p-8f, 0x1.26eb18p-5f, 0x1.bff0fep-4f, 0x1.b43c4p-3f,
+                                       0x1.10656p-2f, 0x1.b43c4p-3f, 0x1.bff0fep-4f, 0x1.26eb18p-5f, 0x1.f1fe02p-8f,
+                                       0x1.0d956cp-10f};
+#define WK(k) WGT[k]
+#endif
 
 constexpr int SW = 64;              // strip width (output columns per workgroup)
 constexpr int NTH = 3 * SW;         // threads: (column, channel)
@@ -130,7 +143,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 #pragma unroll
       for (int k = 0; k < WIN; k++) {
         const float a = ra[3 * k], b = rb[3 * k];
-        const float ga = win.g[k] * a, gb = win.g[k] * b;
+        const float ga = WK(k) * a, gb = WK(k) * b;
         m1 += ga; m2 += gb;
         e11 = fmaf(ga, a, e11); e22 = fmaf(gb, b, e22); e12 = fmaf(ga, b, e12);
       }
@@ -142,7 +155,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 #pragma unroll
         for (int k = 0; k < WIN; k++) {
 #pragma unroll
-          for (int q = 0; q < 5; q++) o[q] = fmaf(win.g[k], w[(p + 1 + k) % RB][q], o[q]);
+          for (int q = 0; q < 5; q++) o[q] = fmaf(WK(k), w[(p + 1 + k) % RB][q], o[q]);
         }
         const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
         const float mu1 = o[0], mu2 = o[1];
@@ -206,9 +219,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
       float h0 = 0.f, h1 = 0.f, h2 = 0.f;
 #pragma unroll
       for (int k = 0; k < WIN; k++) {
-        h0 = fmaf(win.g[k], r[9 * k], h0);
-        h1 = fmaf(win.g[k], r[9 * k + 1], h1);
-        h2 = fmaf(win.g[k], r[9 * k + 2], h2);
+        h0 = fmaf(WK(k), r[9 * k], h0);
+        h1 = fmaf(WK(k), r[9 * k + 1], h1);
+        h2 = fmaf(WK(k), r[9 * k + 2], h2);
       }
       w[p][0] = h0; w[p][1] = h1; w[p][2] = h2;
       const int gy = r0 + p - HALO;
@@ -216,9 +229,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         float o0 = 0.f, o1 = 0.f, o2 = 0.f;
 #pragma unroll
         for (int k = 0; k < WIN; k++) {
-          o0 = fmaf(win.g[k], w[(p + 1 + k) % RB][0], o0);
-          o1 = fmaf(win.g[k], w[(p + 1 + k) % RB][1], o1);
-          o2 = fmaf(win.g[k], w[(p + 1 + k) % RB][2], o2);
+          o0 = fmaf(WK(k), w[(p + 1 + k) % RB][0], o0);
+          o1 = fmaf(WK(k), w[(p + 1 + k) % RB][1], o1);
+          o2 = fmaf(WK(k), w[(p + 1 + k) % RB][2], o2);
         }
         if (gx < W) {
           const size_t pidx = (size_t)gy * W * 3 + (size_t)x0 * 3 + tid;
