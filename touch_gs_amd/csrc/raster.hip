@@ -190,15 +190,19 @@ __device__ __forceinline__ size_t slot_ok_index(int batch_pos, int tile) {
 //          exp2(-s) = o e^-sigma <= 0.999 and min(0.999, .) is the identity -- bit-identical, one VALU less.
 //   okb  : (WANT_OK) lane mask of the pixels that passed the alpha >= 1/255 test while live -- the ballot
 //          sits next to the compare so that it IS the compare's scalar result (no extra VALU)
-template <bool MAYCLAMP = true, bool WANT_OK = false>
+//   okb  : WANT_OK = 1: lane mask of `ok`; WANT_OK = 2: lane mask of `go` (both ballots sit next to their
+//          compares, so they ARE the compares' scalar results: no extra VALU)
+template <bool MAYCLAMP = true, int WANT_OK = 0>
 __device__ __forceinline__ float blend_step(float s, float& T, float& smax, float& Tnew, bool& go,
                                             unsigned long long& okb) {
   const float e = __builtin_amdgcn_exp2f(-s);
   const float al = MAYCLAMP ? fminf(ALPHA_MAX, e) : e;
   const bool ok = s <= smax;
-  if constexpr (WANT_OK) okb = __builtin_amdgcn_ballot_w64(ok);
+  if constexpr (WANT_OK == 1) okb = __builtin_amdgcn_ballot_w64(ok);
   Tnew = fmaf(-al, T, T);
-  go = ok & (Tnew > T_STOP);
+  const bool above = Tnew > T_STOP;
+  if constexpr (WANT_OK == 2) okb = __builtin_amdgcn_ballot_w64(ok) & __builtin_amdgcn_ballot_w64(above);
+  go = ok & above;
   smax = (ok != go) ? -3.0e38f : smax;  // stop (ok and not go; go implies ok): T' <= 1e-4, this Gaussian excluded
   return go ? al : 0.f;
 }
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
           const float s = eval_s(qa, qb, pc, k);
           float Tn; bool go;
           unsigned long long okb = 0ull;
-          const float al = blend_step<true, WANT_OK>(s, T[k], smax[k], Tn, go, okb);
+          const float al = blend_step<true, WANT_OK ? 1 : 0>(s, T[k], smax[k], Tn, go, okb);
           const float w = al * T[k];
           Cr[k] = fmaf(w, qb.w, Cr[k]); Cg[k] = fmaf(w, qc.x, Cg[k]);
           Cb[k] = fmaf(w, qc.y, Cb[k]); D[k] = fmaf(w, qb.z, D[k]);
@@ -474,7 +478,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TGS_BLK_WAVE
             const float s = eval_s(qa, qb, pc, k);
             float Tn; bool go;
             unsigned long long okb = 0ull;
-            const float al = blend_step<MAYCLAMP, false>(s, T[k], smax[k], Tn, go, okb);
+            const float al = blend_step<MAYCLAMP, 0>(s, T[k], smax[k], Tn, go, okb);
             const float w = al * T[k];
             Cr[k] = fmaf(w, qb.w, Cr[k]); Cg[k] = fmaf(w, qc.x, Cg[k]);
             Cb[k] = fmaf(w, qc.y, Cb[k]); D[k] = fmaf(w, qb.z, D[k]);
@@ -690,14 +694,17 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
       float acc[RED_ROWS];
 #pragma unroll
       for (int c = 0; c < RED_ROWS; c++) acc[c] = 0.f;
-      bool any = false;
+      // lanes with a contributing pixel, as a SCALAR mask: the ballots inside blend_step are the compares' own
+      // results, so keeping `any` as a mask costs one s_or per quadrant -- as a per-lane bool it cost three scalar
+      // instructions per quadrant and a v_cndmask + v_cmp per Gaussian for the final ballot (K7 396 -> 383 us)
+      unsigned long long any = 0ull;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         if (m & (1u << k)) {  // wave-uniform
           const float s = eval_s(qa, qb, pc, k);
           float Tn; bool go;
           unsigned long long okb;
-          const float al = blend_step<MAYCLAMP>(s, T[k], smax[k], Tn, go, okb);   // 0 unless this Gaussian contributes
+          const float al = blend_step<MAYCLAMP, 2>(s, T[k], smax[k], Tn, go, okb);   // 0 unless this Gaussian contributes
           const float w = al * T[k];
           // alpha / (1 - alpha) = alpha T / T'  (T' = T (1 - alpha) is already there; w = 0 if skipped)
           const float kap = w * __builtin_amdgcn_rcpf(Tn);
@@ -717,10 +724,10 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
           if (k & 1) acc[5] += q;
           if (k >> 1) acc[6] += q;
           acc[7] = fmaf(q, pc.uv[k], acc[7]);
-          any |= go;
+          any |= okb;
         }
       }
-      if (__ballot(any) != 0ull) {
+      if (any != 0ull) {
         // LDS operations of one wave execute in order, so the (single-wave) workgroup needs no
         // barrier between the scatter and the transposed read -- only the compiler must keep them
         // in order, which the possible aliasing already forces
