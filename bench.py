@@ -465,7 +465,8 @@ def main():
         }
         out["valu_roofline"] = valu_utilisation(kern_ms, N, W, H, deg)
         if dp.world > 1:
-            out["dp_exchange"] = {"form": "all-gather colour gradients + all-reduce geometry gradients"
+            out["dp_exchange"] = {"form": ("all-gather colour gradients (pipelined with K8 / SH Adam over %d row chunks) + "
+                                           "all-reduce geometry gradients" % len(model._color_rows))
                                   if model._color_all is not None else "all-reduce flat gradient buffer",
                                   "payload_bytes_per_rank_per_step": int(dp.bytes_per_step),
                                   "dense_all_reduce_bytes": int(model.params.grad.numel() * 4)}

@@ -299,6 +299,22 @@ int tgs_project_bwd_color(const TgsCamera* cam /*[host]*/, int N, const float* m
                           float* v_log_scales, float* v_quats, float* v_opac_logit, float* v_color,
                           float* v_xy, const int32_t* skip_if_overflow /*status[2] of the frame, or NULL*/,
                           void* stream);
+/* Row-range forms (one chunk of a pipelined exchange; results bit-identical to the whole-model calls):
+ *   tgs_project_bwd_color_rows      rows [row_begin, row_end) of the model, row_begin a multiple of TGS_GROUP;
+ *                                   all arrays are the whole model's except v_color_rows = the CHUNK's block
+ *                                   [3 (row_end - row_begin) + 4] (colour gradients | camera position | pad);
+ *   tgs_adam_step_sh_gathered_rows  the SH rows [row_begin, row_end) from the all-gathered chunk blocks
+ *                                   v_color_rows_all[world][3 (row_end - row_begin) + 4]. */
+int tgs_project_bwd_color_rows(const TgsCamera* cam /*[host]*/, int N, int row_begin, int row_end,
+                               const float* means, const float* log_scales, const float* quats,
+                               const float* opac_logit, const float* sh, int sh_stride, int sh_deg,
+                               const float* splats, const int32_t* group_base, const float* partials,
+                               float* v_means, float* v_log_scales, float* v_quats, float* v_opac_logit,
+                               float* v_color_rows, float* v_xy, const int32_t* skip_if_overflow, void* stream);
+int tgs_adam_step_sh_gathered_rows(int world, int N, int row_begin, int row_end, int sh_stride, int sh_deg,
+                                   float* params, const float* v_color_rows_all, float* exp_avg,
+                                   float* exp_avg_sq, const TgsAdamSpec* spec /*[host]*/, float grad_scale,
+                                   const int32_t* skip_if_overflow, void* stream);
 int tgs_dp_agree_overflow(int world, int N, const float* v_color_all, int32_t* status_out,
                           int32_t* sticky_overflow /*may be NULL*/, void* stream);
 int tgs_adam_step_sh_gathered(int world, int N, int sh_stride, int sh_deg, float* params,

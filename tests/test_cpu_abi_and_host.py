@@ -232,6 +232,37 @@ def step_geom(b, e, scale):
     assert torch.allclose(geom, torch.arange(44, dtype=torch.float32) * 3.0)
 dp.gather_color_reduce_geom_and_step(geom, block, allc, step_sh, step_geom, lambda: order.append("begin"))
 assert order == ["begin", "sh", "geom"] and dp.bytes_per_step == 4 * (2 * (3 * Ng + 4) + 44)
+# pipelined factored form: K8 / gather / SH-Adam per row chunk, then the geometry all-reduce
+dp.color_chunks = 3
+rows = dp.color_chunk_rows(1000)
+assert rows == [(0, 512), (512, 1000)] and dp.color_chunk_rows(100) == [(0, 100)]      # boundaries on 256 rows
+dp.color_chunks = 4
+assert dp.color_chunk_rows(1024) == [(0, 256), (256, 512), (512, 768), (768, 1024)]
+rows = [(0, 512), (512, 1000)]
+blocks = [torch.zeros(3 * (e - b) + 4) for b, e in rows]
+blocks_all = [torch.zeros(2, 3 * (e - b) + 4) for b, e in rows]
+geom2 = torch.zeros(44)
+order = []
+def backward_chunk(c):
+    order.append(("k8", c))
+    b, e = rows[c]
+    blocks[c][:3 * (e - b)] = torch.arange(3 * b, 3 * e, dtype=torch.float32) + 1000.0 * dp.rank
+    blocks[c][3 * (e - b):] = torch.tensor([10. * dp.rank, 1., 2., 0.])
+    geom2[22 * c:22 * (c + 1)] = float((c + 1) * (dp.rank + 1))
+def step_sh_chunk(c, allc, scale):
+    order.append(("sh", c))
+    b, e = rows[c]
+    assert scale == 0.5 and allc.shape == (2, 3 * (e - b) + 4)
+    for r in range(2):
+        assert torch.equal(allc[r, :3 * (e - b)], torch.arange(3 * b, 3 * e, dtype=torch.float32) + 1000.0 * r)
+        assert allc[r, 3 * (e - b)].item() == 10.0 * r
+def step_geom2(b, e, scale):
+    order.append("geom")
+    assert torch.allclose(geom2, torch.cat([torch.full((22,), 3.0), torch.full((22,), 6.0)]))
+dp.pipelined_color_exchange_and_step(geom2, blocks, blocks_all, backward_chunk, step_sh_chunk, step_geom2,
+                                     lambda: order.append("begin"))
+assert order == ["begin", ("k8", 0), ("k8", 1), ("sh", 0), ("sh", 1), "geom"], order
+assert dp.bytes_per_step == 4 * (2 * (3 * 1000 + 8) + 44)
 dp.barrier()
 if dp.rank == 0: print("GLOO_OK", bytes_dense)
 '''

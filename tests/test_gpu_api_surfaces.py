@@ -196,6 +196,7 @@ def fresh():
     params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
     return DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=0), params)
 dp.n_chunks = 3
+dp.color_chunks = 3          # pipelined factored exchange: K8 / gather / SH Adam in 3 row chunks
 def train(factored):
     m = fresh()
     m.dp_factored_sh = factored
@@ -448,6 +449,55 @@ def test_gathered_sh_adam_equals_dense_adam_single_rank(dev, deg, interval):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("chunks", [4, 3, 16])
+def test_pipelined_color_exchange_is_bit_identical_to_the_unchunked_form(dev, chunks):
+    """Row-chunked K8 (tgs_project_bwd_color_rows) + per-chunk SH Adam (tgs_adam_step_sh_gathered_rows) --
+    the pipelined exchange of the data-parallel step -- against the one-piece calls: parameters, both moment
+    buffers, geometry gradients and v_xy bit for bit (world = 1; N not a multiple of the chunk grain)."""
+    from touch_gs_amd import parallel
+    from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
+    from touch_gs_amd.optim import GaussianParams
+    from touch_gs_amd.scene import make_view, synthetic_gaussians
+    N, W, H, deg = 4100, 160, 96, 3
+    views = [make_view(N, W, H, deg, 7, dev, view=v, n_views=4) for v in range(2)]
+    P, _ = synthetic_gaussians(N, W, H, deg, 99)
+    def fresh():
+        params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
+        return DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=0), params)
+    a, b = fresh(), fresh()
+    dp = parallel.GradSync(0, 1, 0, color_chunks=chunks)
+    rows = dp.color_chunk_rows(N)
+    assert 1 < len(rows) <= min(chunks, N // 256) and rows[0][0] == 0 and rows[-1][1] == N
+    assert all(r[0] % 256 == 0 for r in rows) and all(rows[i][1] == rows[i + 1][0] for i in range(len(rows) - 1))
+    block = torch.zeros(3 * N + 4, device=dev)
+    allc = torch.zeros(1, 3 * N + 4, device=dev)
+    blocks = [torch.zeros(3 * (e - s) + 4, device=dev) for s, e in rows]
+    blocks_all = [torch.zeros(1, 3 * (e - s) + 4, device=dev) for s, e in rows]
+    for step in range(2):
+        view = views[step]
+        a.forward_backward(view, color_block=block, want_v_xy=True)
+        ga = a.params.grad[:a.optimizer.geom_end()].clone()
+        dp.gather_color_reduce_geom_and_step(a.params.grad[:a.optimizer.geom_end()], block, allc,
+                                             lambda c, sc: a.optimizer.step_sh_gathered(1, deg, c, sc),
+                                             a.optimizer.step_range, a.optimizer.begin_step)
+        b.forward_backward(view, color_block=(rows, blocks), want_v_xy=True)
+        dp.pipelined_color_exchange_and_step(
+            b.params.grad[:b.optimizer.geom_end()], blocks, blocks_all, b._backward_chunk,
+            lambda c, allb, sc: b.optimizer.step_sh_gathered(1, deg, allb, sc, rows=rows[c]),
+            b.optimizer.step_range, b.optimizer.begin_step)
+        assert torch.equal(ga, b.params.grad[:b.optimizer.geom_end()])
+        assert torch.equal(a.last["v_xy"], b.last["v_xy"])
+        assert torch.equal(torch.cat([blk[:-4] for blk in blocks]), block[:3 * N])
+        for blk in blocks:
+            assert torch.equal(blk[-4:], block[3 * N:])       # every chunk carries the camera trailer
+        a.step += 1
+        b.step += 1
+    assert torch.equal(a.params.flat, b.params.flat)
+    assert torch.equal(a.optimizer.exp_avg, b.optimizer.exp_avg)
+    assert torch.equal(a.optimizer.exp_avg_sq, b.optimizer.exp_avg_sq)
+
+
+@pytest.mark.gpu
 def test_step_graph_replay_equals_eager_steps(dev):
     """hipGraph replay of the fused train step (one captured graph per view, Adam bias corrections
     read from device memory) is bit-identical to launching the kernels one by one."""
@@ -635,6 +685,7 @@ def fresh():
     params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
     return DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=0), params)
 dp.n_chunks = 3
+dp.color_chunks = 3          # pipelined factored exchange: K8 / gather / SH Adam in 3 row chunks
 def train(factored, sync):
     m = fresh()
     m.dp_factored_sh = factored

@@ -66,6 +66,8 @@ SIGNATURES = {
     "tgs_project_bwd_adam_next": (C.c_int, [C.POINTER(TgsCamera), _I, _I, _I, _P, _P, _P, C.POINTER(TgsAdamSpec), _P, _P, _P,
                                             _P, _P, C.POINTER(TgsCamera), _P, _P, C.c_int32, _P]),
     "tgs_project_bwd_color": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I] + [_P] * 11),
+    "tgs_project_bwd_color_rows": (C.c_int, [C.POINTER(TgsCamera), _I, _I, _I, _P, _P, _P, _P, _P, _I, _I] + [_P] * 11),
+    "tgs_adam_step_sh_gathered_rows": (C.c_int, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, C.POINTER(TgsAdamSpec), C.c_float, _P, _P]),
     "tgs_dp_agree_overflow": (C.c_int, [_I, _I, _P, _P, _P, _P]),
     "tgs_adam_step_sh_gathered": (C.c_int, [_I, _I, _I, _I, _P, _P, _P, _P, C.POINTER(TgsAdamSpec), C.c_float, _P, _P]),
     "tgs_store_small": (C.c_int, [_P, C.POINTER(C.c_float), _I, _P]),

@@ -842,9 +842,10 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
 // is needed.
 template <int DEG>
 __global__ __launch_bounds__(256) void k_adam_sh_gathered(
-    int world, int N, int sh_stride, const float* __restrict__ means,
+    int world, int row0, int N, int sh_stride, const float* __restrict__ means,
     float* __restrict__ sh, const float* __restrict__ v_color_all, AdamK ad_in,
     float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq) {
+  // rows [row0, N) of the model; the gathered blocks hold exactly these rows (N - row0 colour gradients each)
   if (ad_in.guard && ad_in.guard[1]) return;   // a rank's frame overflowed (tgs_dp_agree_overflow): no update
   const AdamK ad = adam_resolve(ad_in);
   constexpr int K = (DEG + 1) * (DEG + 1);
@@ -852,7 +853,7 @@ __global__ __launch_bounds__(256) void k_adam_sh_gathered(
   extern __shared__ float4 lds4[];
   float* lds = reinterpret_cast<float*>(lds4);
   const int tid = threadIdx.x;
-  const int g0 = blockIdx.x * 256;
+  const int g0 = row0 + blockIdx.x * 256;
   const int g = g0 + tid;
   const int nrows = min(256, N - g0);
   const size_t blk = (size_t)g0 * ROW;
@@ -861,10 +862,11 @@ __global__ __launch_bounds__(256) void k_adam_sh_gathered(
     float acc[3 * K];
 #pragma unroll
     for (int i = 0; i < 3 * K; i++) acc[i] = 0.f;
-    const size_t blk_r = 3 * (size_t)N + 4;   // one rank's block: v_color[N,3] | campos[3] | pad
+    const size_t nb = (size_t)(N - row0);
+    const size_t blk_r = 3 * nb + 4;   // one rank's block: v_color[rows,3] | campos[3] | pad
     for (int r = 0; r < world; r++) {
-      const float* vc = v_color_all + r * blk_r + 3 * (size_t)g;
-      const float* cp = v_color_all + r * blk_r + 3 * (size_t)N;
+      const float* vc = v_color_all + r * blk_r + 3 * (size_t)(g - row0);
+      const float* cp = v_color_all + r * blk_r + 3 * nb;
       const float v0 = vc[0], v1 = vc[1], v2 = vc[2];
       const float dx = m0 - cp[0], dy = m1 - cp[1], dz = m2 - cp[2];
       const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
@@ -1292,6 +1294,31 @@ extern "C" int tgs_project_bwd_color(const TgsCamera* cam, int N, const float* m
   return TGS_OK;
 }
 
+// The same for the model rows [row_begin, row_end) only (one chunk of a pipelined exchange): all per-Gaussian
+// arrays are the whole model's, v_color_rows is the CHUNK's block [3 (row_end - row_begin) + 4] with its own
+// trailer.  A workgroup owns 256 consecutive rows and a binning group is TGS_GROUP rows, so a chunk that starts
+// on a multiple of TGS_GROUP is the whole-model launch restricted to some of its workgroups -- same arithmetic.
+extern "C" int tgs_project_bwd_color_rows(const TgsCamera* cam, int N, int row_begin, int row_end,
+                                          const float* means, const float* log_scales, const float* quats,
+                                          const float* opac_logit, const float* sh, int sh_stride,
+                                          int sh_deg, const float* splats, const int32_t* group_base,
+                                          const float* partials, float* v_means, float* v_log_scales,
+                                          float* v_quats, float* v_opac_logit, float* v_color_rows,
+                                          float* v_xy, const int32_t* skip_if_overflow, void* stream) {
+  TGS_CHECK_ARG(row_begin >= 0 && row_begin <= row_end && row_end <= N, "bad row range");
+  TGS_CHECK_ARG(row_begin % TGS_GROUP == 0, "row_begin must be a multiple of TGS_GROUP");
+  if (row_end == row_begin) return TGS_OK;
+  TGS_CHECK_ARG(means && log_scales && quats && opac_logit && sh && splats && group_base && partials,
+                "null pointer");
+  TGS_CHECK_ARG(v_means && v_log_scales && v_quats && v_opac_logit && v_color_rows, "null output pointer");
+  const size_t r = (size_t)row_begin;
+  return tgs_project_bwd_color(cam, row_end - row_begin, means + 3 * r, log_scales + 3 * r, quats + 4 * r,
+                               opac_logit + r, sh + r * (size_t)sh_stride * 3, sh_stride, sh_deg,
+                               splats + r * TGS_SPLAT_FLOATS, group_base + r / TGS_GROUP, partials,
+                               v_means + 3 * r, v_log_scales + 3 * r, v_quats + 4 * r, v_opac_logit + r,
+                               v_color_rows, v_xy ? v_xy + 2 * r : nullptr, skip_if_overflow, stream);
+}
+
 // Sync-free intersection budget under data parallelism: every rank's colour-gradient block carries
 // its frame's overflow flag in the pad slot; after the all-gather each rank derives the SAME verdict.
 static __global__ void k_dp_agree_overflow(int world, size_t blk, const float* __restrict__ v_color_all,
@@ -1316,23 +1343,24 @@ extern "C" int tgs_dp_agree_overflow(int world, int N, const float* v_color_all,
   return TGS_OK;
 }
 
-extern "C" int tgs_adam_step_sh_gathered(int world, int N, int sh_stride, int sh_deg, float* params,
-                                         const float* v_color_all, float* exp_avg,
-                                         float* exp_avg_sq, const TgsAdamSpec* spec,
-                                         float grad_scale, const int32_t* skip_if_overflow, void* stream) {
+extern "C" int tgs_adam_step_sh_gathered_rows(int world, int N, int row_begin, int row_end, int sh_stride,
+                                              int sh_deg, float* params, const float* v_color_rows_all,
+                                              float* exp_avg, float* exp_avg_sq, const TgsAdamSpec* spec,
+                                              float grad_scale, const int32_t* skip_if_overflow, void* stream) {
   TGS_CHECK_ARG(world >= 1 && N >= 0, "bad size");
-  if (N == 0) return TGS_OK;
-  TGS_CHECK_ARG(params && v_color_all && exp_avg && exp_avg_sq && spec, "null pointer");
+  TGS_CHECK_ARG(row_begin >= 0 && row_begin <= row_end && row_end <= N, "bad row range");
+  if (row_end == row_begin) return TGS_OK;
+  TGS_CHECK_ARG(params && v_color_rows_all && exp_avg && exp_avg_sq && spec, "null pointer");
   TGS_CHECK_ARG(sh_deg >= 0 && sh_deg <= 3 && sh_stride >= (sh_deg + 1) * (sh_deg + 1), "bad SH degree / stride");
   TGS_CHECK_ARG((3 * sh_stride) % 4 == 0, "SH row (3*sh_stride floats) must be a multiple of 16 bytes");
-  AdamK a = make_adamk(N, sh_stride, spec, grad_scale);
+  AdamK a = make_adamk(N, sh_stride, spec, grad_scale);   // segment offsets of the WHOLE model
   a.guard = skip_if_overflow;
-  const dim3 grid((N + 255) / 256), block(256);
+  const dim3 grid((row_end - row_begin + 255) / 256), block(256);
   const size_t lds_bytes = 256 * (size_t)(3 * sh_stride + 4) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_G(D)                                                                              \
-  hipLaunchKernelGGL((k_adam_sh_gathered<D>), grid, block, lds_bytes, s, world, N, sh_stride,    \
-                     params, params + a.e_opac, v_color_all, a, exp_avg, exp_avg_sq)
+  hipLaunchKernelGGL((k_adam_sh_gathered<D>), grid, block, lds_bytes, s, world, row_begin, row_end, sh_stride, \
+                     params, params + a.e_opac, v_color_rows_all, a, exp_avg, exp_avg_sq)
   switch (sh_deg) {
     case 0: LAUNCH_G(0); break;
     case 1: LAUNCH_G(1); break;
@@ -1342,4 +1370,13 @@ extern "C" int tgs_adam_step_sh_gathered(int world, int N, int sh_stride, int sh
 #undef LAUNCH_G
   TGS_CHECK_LAUNCH();
   return TGS_OK;
+}
+
+extern "C" int tgs_adam_step_sh_gathered(int world, int N, int sh_stride, int sh_deg, float* params,
+                                         const float* v_color_all, float* exp_avg,
+                                         float* exp_avg_sq, const TgsAdamSpec* spec,
+                                         float grad_scale, const int32_t* skip_if_overflow, void* stream) {
+  TGS_CHECK_ARG(world >= 1 && N >= 0, "bad size");
+  return tgs_adam_step_sh_gathered_rows(world, N, 0, N, sh_stride, sh_deg, params, v_color_all, exp_avg,
+                                        exp_avg_sq, spec, grad_scale, skip_if_overflow, stream);
 }

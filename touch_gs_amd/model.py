@@ -118,7 +118,7 @@ class DepthGaussianSplattingModel:
         self._sync_budget = ops.IntersectBudget()   # render / eval path when `budget` is sync-free
         self.fuse_adam = True   # single-process steps use the fused K8+K9 kernel when it applies
         self.dp_factored_sh = True   # data-parallel steps exchange colour gradients, not SH rows
-        self._color_block = self._color_all = None
+        self._color_block = self._color_all = self._color_rows = None
         self.last = {}
 
     @property
@@ -249,9 +249,22 @@ class DepthGaussianSplattingModel:
         if fuse_adam:
             v_xy = self.optimizer.backward_and_step(cam, deg, splats, group_base, partials, want_v_xy,
                                                     begin=begin_step, guard=guard, prefetch=prefetch)
-        elif color_block is not None:   # data-parallel: geometry gradients + colour-gradient block
-            v_xy = ops.project_bwd_color(cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, splats,
-                                         group_base, partials, p.grad_views()[:4], color_block, want_v_xy, guard=guard)
+        elif color_block is not None:   # data-parallel: geometry gradients + colour-gradient block(s)
+            if isinstance(color_block, (list, tuple)):
+                # pipelined exchange: K8 is launched chunk by chunk by the caller (train_step), between the gathers
+                rows, blocks = color_block
+                v_xy = torch.empty(p.N, 2, dtype=torch.float32, device=p.flat.device) if want_v_xy else None
+                out4 = p.grad_views()[:4]
+
+                def backward_chunk(c, cam=cam, deg=deg, splats=splats, group_base=group_base, partials=partials,
+                                   guard=guard, v_xy=v_xy):
+                    ops.project_bwd_color(cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, splats,
+                                          group_base, partials, out4, blocks[c], guard=guard, rows=rows[c], v_xy=v_xy)
+                self._backward_chunk = backward_chunk
+            else:
+                v_xy = ops.project_bwd_color(cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, splats,
+                                             group_base, partials, p.grad_views()[:4], color_block, want_v_xy,
+                                             guard=guard)
         else:
             v_xy = ops.project_bwd(cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, splats,
                                    group_base, partials, out=p.grad_views(), want_v_xy=want_v_xy, guard=guard)[5]
@@ -435,12 +448,22 @@ class DepthGaussianSplattingModel:
         self._dp = dp if distributed else None
         block = None
         if factored:
-            n = 3 * self.params.N + 4
-            if self._color_block is None or self._color_block.numel() != n or self._color_all.numel() != n * dp.world:
+            # the rank's colour-gradient blocks, one per row chunk of the pipelined exchange: [3 rows + 4] each
+            # (colour gradients | camera position | overflow flag), and their all-gathered images [world, 3 rows + 4]
+            rows = dp.color_chunk_rows(self.params.N)
+            n = 3 * self.params.N + 4 * len(rows)
+            if (self._color_block is None or self._color_block.numel() != n or self._color_all.numel() != n * dp.world
+                    or self._color_rows != rows):
                 dev = self.params.flat.device
                 self._color_block = torch.zeros(n, dtype=torch.float32, device=dev)
-                self._color_all = torch.zeros(dp.world, n, dtype=torch.float32, device=dev)
-            block = self._color_block
+                self._color_all = torch.zeros(dp.world * n, dtype=torch.float32, device=dev)
+                self._color_rows, self._color_blocks, self._color_blocks_all, off = rows, [], [], 0
+                for b, e in rows:
+                    m = 3 * (e - b) + 4
+                    self._color_blocks.append(self._color_block[off:off + m])
+                    self._color_blocks_all.append(self._color_all[dp.world * off:dp.world * (off + m)].view(dp.world, m))
+                    off += m
+            block = (rows, self._color_blocks)
         colors = pre if (pre is not None and fuse and pre.matches(view.cam, self.params.N, deg)) else None
         arm = None
         if fuse and next_view is not None and self.active_sh_degree(self.step + 1) == deg:
@@ -453,7 +476,7 @@ class DepthGaussianSplattingModel:
         self.forward_backward(view, want_v_xy=density is not None, fuse_adam=fuse, color_block=block,
                               colors=colors, prefetch=arm)
         self._prefetch_ready = arm
-        if density is not None:
+        if density is not None and not factored:
             # a frame that overflowed its intersection buffer (sync-free budget) rendered nothing and will be
             # replayed: it must not count as a view (guard = its status word, evaluated on the device)
             density.accumulate(self.last["v_xy"], self.last["radii"], view.cam.W, view.cam.H, guard=self.last["guard"])
@@ -464,14 +487,20 @@ class DepthGaussianSplattingModel:
                     self._dp_status = torch.zeros(2, dtype=torch.int32, device=self.params.flat.device)
                 dguard = self._dp_status
 
-            def step_sh(allc, scale):
-                if dguard is not None:
-                    ops.dp_agree_overflow(dp.world, self.params.N, allc, dguard, self.budget.sticky)
-                opt.step_sh_gathered(dp.world, deg, allc, scale, guard=dguard)
+            rows = self._color_rows
 
-            dp.gather_color_reduce_geom_and_step(
-                self.params.grad[:opt.geom_end()], block, self._color_all, step_sh,
-                lambda b, e, scale: opt.step_range(b, e, scale, guard=dguard), opt.begin_step)
+            def step_sh_chunk(c, allc, scale):
+                if c == 0 and dguard is not None:   # every chunk block of a rank carries the frame's flag
+                    ops.dp_agree_overflow(dp.world, rows[0][1] - rows[0][0], allc, dguard, self.budget.sticky)
+                opt.step_sh_gathered(dp.world, deg, allc, scale, guard=dguard, rows=rows[c])
+
+            dp.pipelined_color_exchange_and_step(
+                self.params.grad[:opt.geom_end()], self._color_blocks, self._color_blocks_all, self._backward_chunk,
+                step_sh_chunk, lambda b, e, scale: opt.step_range(b, e, scale, guard=dguard), opt.begin_step)
+            self._backward_chunk = None
+            if density is not None:   # v_xy exists once the K8 chunks are enqueued
+                density.accumulate(self.last["v_xy"], self.last["radii"], view.cam.W, view.cam.H,
+                                   guard=self.last["guard"])
         elif distributed:
             dp.reduce_and_step(self.params.grad, self.optimizer.step_range, self.optimizer.begin_step)
         elif not fuse:

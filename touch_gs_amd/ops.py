@@ -409,21 +409,27 @@ def project_bwd(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_deg, s
 
 
 def project_bwd_color(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_deg, splats, group_base,
-                      partials, out, v_color, want_v_xy=False, guard=None):
+                      partials, out, v_color, want_v_xy=False, guard=None, rows=None, v_xy=None):
     """K8 of the data-parallel step (tgs_project_bwd_color): geometry gradients into ``out`` =
     (v_means, v_log_scales, v_quats, v_opac_logit) and, instead of the SH gradient, the block
-    ``v_color`` [3N+4] = clamp-gated colour gradients | camera position | pad.  -> v_xy or None."""
+    ``v_color`` [3N+4] = clamp-gated colour gradients | camera position | pad.  -> v_xy or None.
+    ``rows`` = (begin, end): only these model rows (begin a multiple of 256); ``v_color`` is then the
+    chunk's own block [3 (end - begin) + 4] and ``v_xy`` [N,2] (if wanted) must be passed in."""
     lib = _lib.load()
     N = means.shape[0]
-    if v_color.numel() != 3 * N + 4 or v_color.dtype != torch.float32:
-        raise ValueError("v_color must be a float32 tensor of 3N+4 elements")
+    b, e = (0, N) if rows is None else rows
+    if v_color.numel() != 3 * (e - b) + 4 or v_color.dtype != torch.float32:
+        raise ValueError("v_color must be a float32 tensor of 3*rows+4 elements")
     v_means, v_ls, v_q, v_ol = out
-    v_xy = torch.empty(N, 2, dtype=torch.float32, device=means.device) if want_v_xy else None
+    if v_xy is None and want_v_xy:
+        if rows is not None:
+            raise ValueError("a row-range call writes into the caller's v_xy [N,2]")
+        v_xy = torch.empty(N, 2, dtype=torch.float32, device=means.device)
     cs = cam.c_struct()
-    check(lib.tgs_project_bwd_color(C.byref(cs), N, ptr(means), ptr(log_scales), ptr(quats), ptr(opac_logit),
-                                    ptr(sh), sh.shape[1], sh_deg, ptr(splats), ptr(group_base), ptr(partials),
-                                    ptr(v_means), ptr(v_ls), ptr(v_q), ptr(v_ol), ptr(v_color), ptr(v_xy),
-                                    ptr(guard), _stream()), "tgs_project_bwd_color")
+    check(lib.tgs_project_bwd_color_rows(C.byref(cs), N, b, e, ptr(means), ptr(log_scales), ptr(quats), ptr(opac_logit),
+                                         ptr(sh), sh.shape[1], sh_deg, ptr(splats), ptr(group_base), ptr(partials),
+                                         ptr(v_means), ptr(v_ls), ptr(v_q), ptr(v_ol), ptr(v_color), ptr(v_xy),
+                                         ptr(guard), _stream()), "tgs_project_bwd_color_rows")
     return v_xy
 
 

@@ -196,18 +196,22 @@ class FusedAdam:
         """First flat element of the SH segment (= number of geometry elements incl. padding)."""
         return layout(self.p.N, self.p.K)["sh"][0]
 
-    def step_sh_gathered(self, world: int, sh_deg: int, v_color_all: torch.Tensor, grad_scale: float, guard=None):
+    def step_sh_gathered(self, world: int, sh_deg: int, v_color_all: torch.Tensor, grad_scale: float, guard=None,
+                         rows=None):
         """Adam on the SH segment from the all-gathered colour-gradient blocks [world, 3N+4] of the
         current step (call before the geometry segments are stepped: it reads the means).
-        ``guard``: the status word written by ops.dp_agree_overflow (no-op if any rank overflowed)."""
+        ``guard``: the status word written by ops.dp_agree_overflow (no-op if any rank overflowed).
+        ``rows`` = (begin, end): only these model rows, ``v_color_all`` = [world, 3 (end - begin) + 4]."""
         lib = _lib.load()
-        if v_color_all.numel() != world * (3 * self.p.N + 4):
-            raise ValueError("v_color_all must hold world blocks of 3N+4 floats")
+        b, e = (0, self.p.N) if rows is None else rows
+        if v_color_all.numel() != world * (3 * (e - b) + 4):
+            raise ValueError("v_color_all must hold world blocks of 3*rows+4 floats")
         s = self._spec()
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        check(lib.tgs_adam_step_sh_gathered(world, self.p.N, self.p.K, sh_deg, ptr(self.p.flat), ptr(v_color_all),
-                                            ptr(self.exp_avg), ptr(self.exp_avg_sq), C.byref(s),
-                                            C.c_float(grad_scale), ptr(guard), stream), "tgs_adam_step_sh_gathered")
+        check(lib.tgs_adam_step_sh_gathered_rows(world, self.p.N, b, e, self.p.K, sh_deg, ptr(self.p.flat),
+                                                 ptr(v_color_all), ptr(self.exp_avg), ptr(self.exp_avg_sq), C.byref(s),
+                                                 C.c_float(grad_scale), ptr(guard), stream),
+              "tgs_adam_step_sh_gathered_rows")
 
     def state_dict(self):
         return dict(t=self.t, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lrs=self.lrs)

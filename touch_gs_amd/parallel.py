@@ -51,13 +51,21 @@ class GradSync:
     stream and the fused Adam of range c is enqueued on the compute stream behind an event that
     fires when range c has been reduced -- so the optimizer (~0.3 ms at 1 M Gaussians) runs under
     the shadow of the collective (estimated >1 ms for 236 MB on xGMI) instead of after it.
-    ``gather_color_reduce_geom_and_step`` is the default of the trainer (see its docstring).
+    ``gather_color_reduce_geom_and_step`` is the factored exchange in one piece;
+    ``pipelined_color_exchange_and_step`` -- the default of the trainer -- is the same exchange cut into row
+    chunks, K8 included (see its docstring).
     """
 
     def __init__(self, rank: int = 0, world: int = 1, local_rank: int = 0, n_chunks: int = 8,
-                 force_collectives: bool = False):
+                 force_collectives: bool = False, color_chunks: Optional[int] = None):
         self.rank, self.world, self.local_rank = rank, world, local_rank
         self.n_chunks = n_chunks
+        # row chunks of the pipelined factored exchange (1 = one K8, one gather).  Every chunk costs ~16 us of
+        # launches and workgroup-round tails (measured with one rank, where nothing is hidden: 1.145 / 1.209 /
+        # 1.307 ms per step with 1 / 4 / 8 chunks); what it buys is link time hidden behind K8 and the SH Adam, which
+        # grows with the number of ranks -- so: 4 chunks from 4 ranks on, one piece below.  TGS_DP_COLOR_CHUNKS overrides.
+        env = os.environ.get("TGS_DP_COLOR_CHUNKS")
+        self.color_chunks = color_chunks if color_chunks is not None else int(env) if env else (4 if world >= 4 else 1)
         # collectives are issued when there is more than one rank -- or when forced (1-rank RCCL test)
         self.active = world > 1 or (force_collectives and dist.is_initialized())
         self.bytes_per_step = 0
@@ -164,6 +172,89 @@ class GradSync:
             self._comm_events = (begun, gathered, reduced, v_color.numel() * 4, geom_grad.numel() * 4)
         comp.wait_event(gathered)
         step_sh(v_color_all, scale)
+        comp.wait_event(reduced)
+        step_geom(0, geom_grad.numel(), scale)
+
+    def color_chunk_rows(self, N: int, align: int = 256):
+        """Row ranges [begin, end) of the pipelined exchange: at most ``color_chunks`` ranges covering [0, N),
+        every boundary a multiple of ``align`` (K8's workgroup / the binning group: 256 rows)."""
+        n = max(1, min(self.color_chunks, N // align))
+        per = -(-N // n)
+        per = -(-per // align) * align
+        out, b = [], 0
+        while b < N:
+            out.append((b, min(b + per, N)))
+            b += per
+        return out
+
+    def pipelined_color_exchange_and_step(self, geom_grad: torch.Tensor, blocks: Sequence[torch.Tensor],
+                                          blocks_all: Sequence[torch.Tensor], backward_chunk, step_sh_chunk,
+                                          step_geom, begin_step=None) -> None:
+        """The factored exchange of ``gather_color_reduce_geom_and_step`` pipelined over row chunks, K8 included:
+
+        compute stream:  K8(0) K8(1) ... K8(C-1)   SH-Adam(0) ... SH-Adam(C-1)              geometry Adam
+        side stream:           gather(0) gather(1) ... gather(C-1)  all-reduce(geometry gradients)
+
+        ``backward_chunk(c)`` launches K8 in colour mode for chunk c (geometry gradients of its rows into
+        ``geom_grad``, its colour block into ``blocks[c]``); chunk c's block is all-gathered into
+        ``blocks_all[c]`` [world, len(blocks[c])] as soon as its K8 has run -- while the later chunks' K8 still
+        runs -- and ``step_sh_chunk(c, blocks_all[c], 1/world)`` (Adam on the SH rows of the chunk) starts when
+        its gather has landed, under the later gathers and the geometry all-reduce.  Exposed link time: the
+        gathers minus the tail of K8, the all-reduce minus the last chunk's SH Adam.  Same arithmetic per row
+        as the unchunked form, so the results are bit-identical to it."""
+        scale = 1.0 / self.world
+        C_ = len(blocks)
+        if begin_step is not None:
+            begin_step()
+        nccl = self.active and dist.get_backend() == "nccl"
+
+        def gather(c):
+            if not self.active:
+                blocks_all[c].copy_(blocks[c].view(1, -1))
+            elif nccl:
+                dist.all_gather_into_tensor(blocks_all[c].view(-1), blocks[c])
+            else:
+                dist.all_gather(list(blocks_all[c].view(self.world, -1).unbind(0)), blocks[c])
+
+        self.bytes_per_step = 4 * (sum(b.numel() for b in blocks) * self.world + geom_grad.numel())
+        if not self.active or not geom_grad.is_cuda:
+            for c in range(C_):
+                backward_chunk(c)
+                gather(c)
+            for c in range(C_):
+                step_sh_chunk(c, blocks_all[c], scale)
+            if self.active:
+                dist.all_reduce(geom_grad, op=dist.ReduceOp.SUM)
+            step_geom(0, geom_grad.numel(), scale)
+            return
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=geom_grad.device)
+        comp, comm = torch.cuda.current_stream(geom_grad.device), self._comm_stream
+        t = self.timing
+        gathered = []
+        begun = None
+        for c in range(C_):
+            backward_chunk(c)
+            done = torch.cuda.Event()
+            done.record(comp)                  # chunk c's block (and geometry gradients) complete
+            comm.wait_event(done)
+            with torch.cuda.stream(comm):
+                if c == 0:
+                    begun = torch.cuda.Event(enable_timing=t)
+                    begun.record(comm)
+                gather(c)
+                ev = torch.cuda.Event(enable_timing=t and c == C_ - 1)
+                ev.record(comm)
+                gathered.append(ev)
+        with torch.cuda.stream(comm):          # behind the last chunk's K8: every geometry gradient is there
+            dist.all_reduce(geom_grad, op=dist.ReduceOp.SUM)
+            reduced = torch.cuda.Event(enable_timing=t)
+            reduced.record(comm)
+        if t:
+            self._comm_events = (begun, gathered[-1], reduced, sum(b.numel() for b in blocks) * 4, geom_grad.numel() * 4)
+        for c in range(C_):
+            comp.wait_event(gathered[c])
+            step_sh_chunk(c, blocks_all[c], scale)
         comp.wait_event(reduced)
         step_geom(0, geom_grad.numel(), scale)
 
