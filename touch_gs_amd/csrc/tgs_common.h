@@ -28,7 +28,9 @@ static inline __host__ __device__ int tgs_xcd_slots(int T) {
 // row-major tile range [8 c chunk, 8 (c+1) chunk), an "image band" that tgs_rasterize_bwd_band can
 // launch on its own.  TGS_BANDS = minimum number of chunks: 1 -- finer chunks (4 per XCD at 1080p)
 // cost K6 / K7 6 % (longest-first only inside 256 slots).
+#ifndef TGS_BANDS
 #define TGS_BANDS 1
+#endif
 static inline __host__ __device__ int tgs_band_slots(int T) {
   const int per = tgs_xcd_slots(T);
   int n = (per + 1023) / 1024;
