@@ -10,7 +10,10 @@ SRCS="api project binning raster optim imgloss"
 # raster.hip: the SLP vectoriser pairs the per-pixel FMAs into v_pk_fma_f32, which on gfx950 costs
 # 1.84x a plain v_fma_f32 and needs register-pair shuffles (v_mov) around it: K7 127 -> 100 VGPRs and
 # -7 % time, K6 -3 % without it (measured, same box)
-declare -A EXTRA=([raster]="-fno-slp-vectorize")
+# imgloss.hip: the same for the SSIM filters (k_ssim_fwd 2105 static VALU with 341 v_pk_* and 326 v_mov at 110
+# VGPRs -> 2232 VALU, 143 v_mov, 92 VGPRs: 58.4 -> 51.8 us at 1080p, k_ssim_bwd unchanged; same box, same checksum).
+# The other translation units hold HBM-bound kernels: no difference either way (1.0129 / 1.0122 ms per step).
+declare -A EXTRA=([raster]="-fno-slp-vectorize" [imgloss]="-fno-slp-vectorize")
 pids=()
 for s in $SRCS; do
   [ -f "$HERE/$s.hip" ] || continue
