@@ -275,6 +275,34 @@ int tgs_project_bwd_adam_next(const TgsCamera* cam /*[host]*/, int N, int sh_str
                               const TgsCamera* next_cam /*[host]*/, float* colors_next,
                               int32_t* color_tag, int32_t tag_value, void* stream);
 
+/* Front prefetch (single-process training loop): tgs_project_bwd_adam_next + the NEXT view's K1.  The fused
+ *     optimizer kernel holds every updated parameter of its 256 Gaussians in registers and its workgroup IS the
+ *     binning group, so it also projects them for next_cam, writes their records (splats_next[N,12], radii_next
+ *     [N] or NULL), allocates the group's pair range (group_base_next) and counts its tile intersections
+ *     (tile_cursor_next, ranks inside scratch_next) -- K1 of the next frame, with the arithmetic of the
+ *     stand-alone kernel on the same values, hence bit-identical.  The call clears tile_cursor_next / status_next
+ *     first (sticky_overflow as in tgs_bin_sort).  capacity_next / scratch_next as for tgs_bin_sort.
+ *     tgs_project_bin_sort_front completes that frame (scan, fill, sort) on the SAME buffers: if *tag_word ==
+ *     tag_expect the records and counts are there; otherwise (the optimizer kernel was voided by its overflow
+ *     guard, which leaves the counters cleared and the tag unchanged) K1 runs now, from the SH rows. */
+int tgs_project_bwd_adam_next_front(const TgsCamera* cam /*[host]*/, int N, int sh_stride, int sh_deg,
+                                    float* params, float* exp_avg, float* exp_avg_sq,
+                                    const TgsAdamSpec* spec /*[host]*/, const float* splats,
+                                    const int32_t* group_base, const float* partials, float* v_xy,
+                                    const int32_t* skip_if_overflow /*status[2] of the frame, or NULL*/,
+                                    const TgsCamera* next_cam /*[host]*/, float* colors_next,
+                                    int32_t* tag_word, int32_t tag_value, float* splats_next,
+                                    int32_t* radii_next, int32_t* group_base_next, int32_t* tile_cursor_next,
+                                    int64_t capacity_next, void* scratch_next, int32_t* status_next,
+                                    int32_t* sticky_overflow, void* stream);
+int tgs_project_bin_sort_front(const TgsCamera* cam /*[host]*/, int N, const float* means,
+                               const float* log_scales, const float* quats, const float* opac_logit,
+                               const float* sh, int sh_stride, int sh_deg, float* splats, int32_t* radii,
+                               int32_t* group_base, int32_t* tile_start, int32_t* tile_cursor,
+                               int32_t* sorted_gid, int32_t* tile_order, int64_t capacity, void* scratch,
+                               int32_t* status, int32_t* sticky_overflow, const int32_t* tag_word,
+                               int32_t tag_expect, void* stream);
+
 /* Data-parallel step (one view per rank, SURVEY section 8 row e).  The SH gradient of a rank is the
  *     outer product Y_k(dir(g)) x v_color[g,:], so the ranks exchange v_color (all-gather, 3 floats
  *     per Gaussian and rank) instead of all-reducing 3*sh_stride floats per Gaussian:

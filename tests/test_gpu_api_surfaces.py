@@ -1261,6 +1261,79 @@ def test_color_prefetch_is_bit_identical(dev, deg, interval):
     assert torch.equal(m.last["rgb"], ref.last["rgb"]) and torch.equal(m.params.flat, ref.params.flat)
 
 
+@pytest.mark.parametrize("densify,speculative", [(False, False), (True, False), (False, True)])
+def test_front_prefetch_is_bit_identical(dev, densify, speculative):
+    """Front prefetch (tgs_project_bwd_adam_next_front -> tgs_project_bin_sort_front): the fused optimizer kernel of
+    step t also runs K1 of step t+1's view -- records, radii, pair ranges, tile counts -- on the parameters it has
+    just updated; step t+1 only scans, fills and sorts.  Records, images, parameters and moments bit for bit equal to
+    the same sequence with the prefetch switched off, with the synchronous and the sync-free budget, with radii
+    requested (densification statistics), when the announced view is not the one that comes, and across an
+    overflowing frame (the voided optimizer kernel leaves the tag word alone: K1 runs in the next step)."""
+    from touch_gs_amd import ops
+    from touch_gs_amd.densify import DensifyConfig
+    from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
+    from touch_gs_amd.optim import GaussianParams
+    from touch_gs_amd.scene import make_view, synthetic_gaussians
+    N, W, H, deg = 4100, 160, 96, 3
+    views = [make_view(N, W, H, deg, 7, dev, view=v, n_views=4) for v in range(4)]
+    P, _ = synthetic_gaussians(N, W, H, deg, 99)
+
+    def fresh(front):
+        params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
+        m = DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=0), params)
+        m.front_prefetch = front
+        if densify:
+            m.enable_densification(DensifyConfig(warmup_length=1000, refine_every=1000))   # statistics only
+        if speculative:
+            m.enable_speculative_budget(capacity=200_000)
+        return m
+
+    order = [0, 1, 2, 3, 1, 1, 0, 2]
+    on, off = fresh(True), fresh(False)
+    taken = 0
+    for i, v in enumerate(order):
+        nxt = views[order[i + 1]] if i + 1 < len(order) else None
+        if i == 3:
+            nxt = views[3]                                   # wrong announcement: the front buffers are dropped
+        ready = getattr(on, "_prefetch_ready", None)
+        use = ready is not None and ready.front_issued and ready.matches(views[v].cam, N, deg)
+        taken += int(use)
+        on.train_step(views[v], next_view=nxt)
+        off.train_step(views[v], next_view=nxt)
+        assert not use or ready.front is None                # consumed by this step's front half
+        assert torch.equal(on.last["splats"], off.last["splats"]), i
+        assert torch.equal(on.last["rgb"], off.last["rgb"]), i
+        assert torch.equal(on.last["status"], off.last["status"]), i
+        if densify:
+            assert torch.equal(on.last["radii"], off.last["radii"]), i
+    assert taken >= 5, taken
+    assert getattr(off, "_prefetch_ready", None) is None or off._prefetch_ready.front is None
+    if speculative:
+        on.flush(); off.flush()
+    for x, y in ((on.params.flat, off.params.flat), (on.optimizer.exp_avg, off.optimizer.exp_avg),
+                 (on.optimizer.exp_avg_sq, off.optimizer.exp_avg_sq)):
+        assert torch.equal(x, y)
+    if densify:
+        assert torch.equal(on.density.grad_norm_sum, off.density.grad_norm_sum)
+        assert torch.equal(on.density.max_radius, off.density.max_radius)
+
+    if not densify and not speculative:
+        # an overflowing frame between two announced steps, SAME budget object (sync-free, fixed capacity): the fused
+        # kernel of the overflowing step is voided, the sticky word voids the next frame too -- whose K1 therefore runs
+        # in k_project_fwd_unless_done (tag mismatch) on counters the voided call had cleared; nothing is updated
+        m = fresh(True)
+        m.budget = ops.IntersectBudget(capacity=16, sync=False)
+        flat = m.params.flat.clone()
+        m.train_step(views[0], next_view=views[1])           # overflows: no update, front of view 1 announced
+        ready = m._prefetch_ready
+        assert ready is not None and ready.front_issued and int(ready.tag_word) != ready.tag
+        m.train_step(views[1], next_view=views[2])           # front path taken on the host, K1 falls back on the device
+        assert ready.front is None and int(m.last["status"][1]) == 1
+        assert torch.equal(m.params.flat, flat)
+        with pytest.raises(RuntimeError):
+            m.budget.check()
+
+
 def test_spatial_sort_is_a_pure_relayout(dev):
     """model.spatial_sort(): Morton order of parameters + Adam moments.  The render is unchanged and a
     few train steps give the same model up to the permutation (only the order of exactly equal depths

@@ -9,7 +9,7 @@ SRC=$ROOT/touch_gs_amd/csrc
 OUT=$ROOT/build_ab/obj_$NAME
 mkdir -p $OUT
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wall -Wno-unused-function -I$SRC"
-declare -A EXTRA=([raster]="-fno-slp-vectorize" [imgloss]="${TGS_IMGLOSS_FLAGS--fno-slp-vectorize}")
+declare -A EXTRA=([raster]="-fno-slp-vectorize" [imgloss]="${TGS_IMGLOSS_FLAGS--fno-slp-vectorize}" [project]="-ffp-contract=on")
 declare -A ALT
 ARGS=()
 for a in "$@"; do

@@ -13,7 +13,10 @@ SRCS="api project binning raster optim imgloss"
 # imgloss.hip: the same for the SSIM filters (k_ssim_fwd 2105 static VALU with 341 v_pk_* and 326 v_mov at 110
 # VGPRs -> 2232 VALU, 143 v_mov, 92 VGPRs: 58.4 -> 51.8 us at 1080p, k_ssim_bwd unchanged; same box, same checksum).
 # The other translation units hold HBM-bound kernels: no difference either way (1.0129 / 1.0122 ms per step).
-declare -A EXTRA=([raster]="-fno-slp-vectorize" [imgloss]="-fno-slp-vectorize")
+# project.hip: -ffp-contract=on (fusion per source expression, decided by the front end) instead of =fast (decided by
+# the backend after inlining): geom_eval / project_fwd_core are inlined into the stand-alone K1 AND into the fused
+# optimizer kernel (front prefetch), and the two must produce the same bits.
+declare -A EXTRA=([raster]="-fno-slp-vectorize" [imgloss]="-fno-slp-vectorize" [project]="-ffp-contract=on")
 pids=()
 for s in $SRCS; do
   [ -f "$HERE/$s.hip" ] || continue

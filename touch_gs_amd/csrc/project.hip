@@ -101,11 +101,27 @@ __device__ __forceinline__ void sh_color(const float* m, const float* campos, Ro
 
 // Colour prefetch request of the fused K8+Adam kernel: the NEXT view's camera position, the [N,3]
 // colour buffer and the tag word that marks it valid (colors == NULL: off).
+// Front prefetch: the fused K8 + Adam kernel also runs the NEXT view's K1 (projection, record, tile counting of its
+// 256-Gaussian group) on the parameters it has just updated -- they are in registers, the workgroup is the binning
+// group, and the kernel is HBM-bound with the VALU idle.  splats == nullptr: not requested.
+struct NextFront {
+  CamK cam;
+  float* splats;
+  int32_t* radii;
+  int32_t* group_base;
+  int32_t* tile_count;
+  int32_t* rank;
+  int32_t* status;
+  long long capacity;
+  int32_t* sticky;
+};
+
 struct NextView {
   float campos[3];
   float* colors;
   int32_t* tag;
   int32_t tag_value;
+  NextFront fr;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -174,6 +190,10 @@ struct Geom {  // everything the forward and backward share for one Gaussian
 
 __device__ __forceinline__ void geom_eval(const CamK& cam, const float* m, const float* ls,
                                           const float* q, Geom& G) {
+  // This code is inlined into several kernels -- the stand-alone K1 and the fused optimizer kernel that runs the NEXT
+  // view's K1 (front prefetch).  Under -ffp-contract=fast the backend chose different products to fuse in the two
+  // (1-ulp differences in ~9 % of the conics), so project.hip is compiled with -ffp-contract=on (build.sh): fusion is
+  // then decided per source expression by the front end, identically in every instantiation.
   const float* R = cam.R;
   G.tx = R[0] * m[0] + R[1] * m[1] + R[2] * m[2] + cam.t[0];
   G.ty = R[3] * m[0] + R[4] * m[1] + R[5] * m[2] + cam.t[1];
@@ -234,31 +254,19 @@ __device__ __forceinline__ void geom_eval(const CamK& cam, const float* m, const
 // group's pair range and counts its (tile, Gaussian) intersections (K3a), so the records are not
 // re-read and the pair offset is stored with the record instead of patched into it afterwards.
 // PRE: the colours come from colors_in although DEG >= 0 (colour prefetch, k_project_fwd_colors)
-template <int DEG, bool FUSED, bool PRE>  // DEG = -1: no SH (colours from colors_in or zero)
-__device__ __forceinline__ void project_fwd_body(
-    const CamK& cam, int N, const float* __restrict__ means, const float* __restrict__ log_scales,
-    const float* __restrict__ quats, const float* __restrict__ opac_logit,
-    const float* __restrict__ sh, int sh_stride, const float* __restrict__ colors_in,
+// project_fwd_core: everything after the parameters and the colour are in registers (m, ls, q, opac_logit value,
+// rgb; ignored for g >= N) -- shared by the stand-alone K1 below and by the fused K8 + Adam kernel, which runs
+// the NEXT view's K1 on the parameters it has just updated (front prefetch).
+template <bool FUSED>
+__device__ __forceinline__ void project_fwd_core(
+    const CamK& cam, int N, int g, const float* m, const float* ls, const float* q, float ol, const float* rgb,
     float* __restrict__ splats, int32_t* __restrict__ radii, int32_t* __restrict__ group_base,
     int32_t* __restrict__ tile_count, int32_t* __restrict__ rank, int32_t* __restrict__ status,
     long long capacity, int32_t* __restrict__ sticky, GroupScan* Sp) {
-  const int g = tgs_group_id() * 256 + threadIdx.x;
-  if constexpr (!FUSED) { if (g >= N) return; }
   unsigned rect = 0u;
   float tz = 0.f, c1 = 0.f, c2 = 0.f;
   if (g < N) {
-  const float m[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
-  const float ls[3] = {log_scales[3 * g], log_scales[3 * g + 1], log_scales[3 * g + 2]};
-  const float4 q4 = ld4(quats + 4 * (size_t)g);
-  const float q[4] = {q4.x, q4.y, q4.z, q4.w};
-  const float opac = 1.0f / (1.0f + expf(-opac_logit[g]));
-
-  float rgb[3] = {0.f, 0.f, 0.f};
-  if constexpr (DEG >= 0 && !PRE) {
-    sh_color<DEG>(m, cam.campos, sh + (size_t)g * sh_stride * 3, rgb);
-  } else if (colors_in) {
-    rgb[0] = colors_in[3 * g]; rgb[1] = colors_in[3 * g + 1]; rgb[2] = colors_in[3 * g + 2];
-  }
+  const float opac = 1.0f / (1.0f + expf(-ol));
 
   Geom G;
   geom_eval(cam, m, ls, q, G);
@@ -320,6 +328,34 @@ __device__ __forceinline__ void project_fwd_body(
   }
 }
 
+template <int DEG, bool FUSED, bool PRE>  // DEG = -1: no SH (colours from colors_in or zero)
+__device__ __forceinline__ void project_fwd_body(
+    const CamK& cam, int N, const float* __restrict__ means, const float* __restrict__ log_scales,
+    const float* __restrict__ quats, const float* __restrict__ opac_logit,
+    const float* __restrict__ sh, int sh_stride, const float* __restrict__ colors_in,
+    float* __restrict__ splats, int32_t* __restrict__ radii, int32_t* __restrict__ group_base,
+    int32_t* __restrict__ tile_count, int32_t* __restrict__ rank, int32_t* __restrict__ status,
+    long long capacity, int32_t* __restrict__ sticky, GroupScan* Sp) {
+  const int g = tgs_group_id() * 256 + threadIdx.x;
+  if constexpr (!FUSED) { if (g >= N) return; }
+  float m[3] = {0.f, 0.f, 0.f}, ls[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, rgb[3] = {0.f, 0.f, 0.f};
+  float ol = 0.f;
+  if (g < N) {
+    m[0] = means[3 * g]; m[1] = means[3 * g + 1]; m[2] = means[3 * g + 2];
+    ls[0] = log_scales[3 * g]; ls[1] = log_scales[3 * g + 1]; ls[2] = log_scales[3 * g + 2];
+    const float4 q4 = ld4(quats + 4 * (size_t)g);
+    q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+    ol = opac_logit[g];
+    if constexpr (DEG >= 0 && !PRE) {
+      sh_color<DEG>(m, cam.campos, sh + (size_t)g * sh_stride * 3, rgb);
+    } else if (colors_in) {
+      rgb[0] = colors_in[3 * g]; rgb[1] = colors_in[3 * g + 1]; rgb[2] = colors_in[3 * g + 2];
+    }
+  }
+  project_fwd_core<FUSED>(cam, N, g, m, ls, q, ol, rgb, splats, radii, group_base, tile_count, rank, status,
+                          capacity, sticky, Sp);
+}
+
 template <int DEG, bool FUSED>
 __global__ __launch_bounds__(256) void k_project_fwd(
     CamK cam, int N, const float* __restrict__ means, const float* __restrict__ log_scales,
@@ -355,6 +391,24 @@ __global__ __launch_bounds__(256) void k_project_fwd_colors(
   else
     project_fwd_body<DEG, true, false>(cam, N, means, log_scales, quats, opac_logit, sh, sh_stride, colors_in,
                                        splats, radii, group_base, tile_count, rank, status, capacity, sticky, &S);
+}
+
+// K1 of a frame whose records and tile counts the previous step's fused optimizer kernel may already have
+// produced (front prefetch): nothing to do if its tag word says so, else the full K1 from the SH rows (the counters
+// are clear in that case: the fused kernel returned at its overflow guard before touching them).
+template <int DEG>
+__global__ __launch_bounds__(256) void k_project_fwd_unless_done(
+    CamK cam, int N, const float* __restrict__ means, const float* __restrict__ log_scales,
+    const float* __restrict__ quats, const float* __restrict__ opac_logit,
+    const float* __restrict__ sh, int sh_stride,
+    float* __restrict__ splats, int32_t* __restrict__ radii, int32_t* __restrict__ group_base,
+    int32_t* __restrict__ tile_count, int32_t* __restrict__ rank, int32_t* __restrict__ status,
+    long long capacity, int32_t* __restrict__ sticky, const int32_t* __restrict__ front_tag,
+    int32_t tag_expect) {
+  __shared__ GroupScan S;
+  if (*front_tag == tag_expect) return;
+  project_fwd_body<DEG, true, false>(cam, N, means, log_scales, quats, opac_logit, sh, sh_stride, nullptr,
+                                     splats, radii, group_base, tile_count, rank, status, capacity, sticky, &S);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -630,6 +684,7 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
   const AdamK ad = FUSE_ADAM ? adam_resolve(ad_in) : ad_in;
   constexpr int K = (DEG + 1) * (DEG + 1);   // active bases; sh_stride == KS here
   static_assert(KS >= K && (3 * KS) % 4 == 0, "storage must hold the active degree in whole float4s");
+  static_assert(256 * (3 * KS + 4) * sizeof(float) >= sizeof(GroupScan), "the group scan of the front prefetch reuses the SH image");
   constexpr int ROW = 3 * KS, RS = ROW + 4, F4 = ROW / 4;
   extern __shared__ float4 lds4[];
   float* lds = reinterpret_cast<float*>(lds4);
@@ -755,6 +810,7 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
         float pl = ls[j], M = ea[e], V = es[e];
         adam1(ad, ad.lr_scales, pl, vls[j], M, V);
         log_scales[3 * g + j] = pl; ea[e] = M; es[e] = V;
+        ls[j] = pl;
       }
       {
         const long long e = ad.e_scales + 4ll * g;
@@ -763,12 +819,14 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
         adam1(ad, ad.lr_quats, Q.x, vq[0], M.x, V.x); adam1(ad, ad.lr_quats, Q.y, vq[1], M.y, V.y);
         adam1(ad, ad.lr_quats, Q.z, vq[2], M.z, V.z); adam1(ad, ad.lr_quats, Q.w, vq[3], M.w, V.w);
         st4_nt(quats + 4 * (size_t)g, Q); st4_nt(ea + e, M); st4_nt(es + e, V);
+        q[0] = Q.x; q[1] = Q.y; q[2] = Q.z; q[3] = Q.w;
       }
       {
         const long long e = ad.e_quats + g;
         float po = ol, M = ea[e], V = es[e];
         adam1(ad, ad.lr_opac, po, vol, M, V);
         opac_logit[g] = po; ea[e] = M; es[e] = V;
+        ol = po;
       }
     }
   }
@@ -818,10 +876,19 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
     // 12 B instead of 12K B per Gaussian (tgs_project_bin_sort_colors).
     if (nx.colors) {
       __syncthreads();
+      float rgb[3] = {0.f, 0.f, 0.f};
       if (g < N) {
-        float rgb[3];
         sh_color<DEG>(m, nx.campos, lds + tid * RS, rgb);
         nx.colors[3 * g] = rgb[0]; nx.colors[3 * g + 1] = rgb[1]; nx.colors[3 * g + 2] = rgb[2];
+      }
+      if (nx.fr.splats) {
+        // the next view's K1 for this group: same code and the same inputs (the stepped parameters, the colour just
+        // evaluated) as the stand-alone kernel would read back from memory -> bit-identical records and counts.
+        // The group scan takes over the (consumed) SH image.
+        __syncthreads();
+        project_fwd_core<true>(nx.fr.cam, N, g, m, ls, q, ol, rgb, nx.fr.splats, nx.fr.radii, nx.fr.group_base,
+                               nx.fr.tile_count, nx.fr.rank, nx.fr.status, nx.fr.capacity, nx.fr.sticky,
+                               reinterpret_cast<GroupScan*>(lds4));
       }
       if (g == 0) *nx.tag = nx.tag_value;
     }
@@ -1121,6 +1188,76 @@ extern "C" int tgs_project_bwd_adam_next(const TgsCamera* cam, int N, int sh_str
   nx.colors = colors_next; nx.tag = color_tag; nx.tag_value = tag_value;
   return project_bwd_adam_impl(cam, N, sh_stride, sh_deg, params, exp_avg, exp_avg_sq, spec, splats,
                                group_base, partials, v_xy, skip_if_overflow, nx, stream);
+}
+
+// Fused K8 + Adam + the next view's colours AND its K1 (front prefetch).  The next frame's counters are cleared
+// here, before the kernel that counts into them; tgs_project_bin_sort_front finishes that frame.
+extern "C" int tgs_project_bwd_adam_next_front(const TgsCamera* cam, int N, int sh_stride, int sh_deg,
+                                               float* params, float* exp_avg, float* exp_avg_sq,
+                                               const TgsAdamSpec* spec, const float* splats,
+                                               const int32_t* group_base, const float* partials,
+                                               float* v_xy, const int32_t* skip_if_overflow,
+                                               const TgsCamera* next_cam, float* colors_next,
+                                               int32_t* tag_word, int32_t tag_value,
+                                               float* splats_next, int32_t* radii_next,
+                                               int32_t* group_base_next, int32_t* tile_cursor_next,
+                                               int64_t capacity_next, void* scratch_next,
+                                               int32_t* status_next, int32_t* sticky_overflow, void* stream) {
+  TGS_CHECK_ARG(camera_ok(next_cam), "bad next camera");
+  TGS_CHECK_ARG(next_cam->W <= 4080 && next_cam->H <= 4080, "image side > 4080 px (255 tiles)");
+  TGS_CHECK_ARG(colors_next && tag_word, "null colour prefetch buffer");
+  TGS_CHECK_ARG(splats_next && group_base_next && tile_cursor_next && scratch_next && status_next, "null front buffer");
+  TGS_CHECK_ARG(capacity_next >= 0 && capacity_next < (1ll << 31), "bad capacity");
+  if (N <= 0) return TGS_OK;
+  const CamK kn = make_camk(next_cam);
+  const int T = kn.TW * kn.TH;
+  const BinScratch sc = carve_scratch(scratch_next, capacity_next);
+  hipLaunchKernelGGL(k_clear_counters, dim3((max(TGS_XCC * T, 2) + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     tile_cursor_next, T, status_next, sticky_overflow);
+  TGS_CHECK_LAUNCH();
+  NextView nx;
+  nx.campos[0] = kn.campos[0]; nx.campos[1] = kn.campos[1]; nx.campos[2] = kn.campos[2];
+  nx.colors = colors_next; nx.tag = tag_word; nx.tag_value = tag_value;
+  nx.fr.cam = kn; nx.fr.splats = splats_next; nx.fr.radii = radii_next; nx.fr.group_base = group_base_next;
+  nx.fr.tile_count = tile_cursor_next; nx.fr.rank = sc.rank; nx.fr.status = status_next;
+  nx.fr.capacity = (long long)capacity_next; nx.fr.sticky = sticky_overflow;
+  return project_bwd_adam_impl(cam, N, sh_stride, sh_deg, params, exp_avg, exp_avg_sq, spec, splats,
+                               group_base, partials, v_xy, skip_if_overflow, nx, stream);
+}
+
+// The rest of a frame whose K1 tgs_project_bwd_adam_next_front (tag_word == tag_expect) has run: scan / fill /
+// sort.  If the tag does not match (the fused kernel was voided by its overflow guard) K1 runs here, from the SH rows.
+extern "C" int tgs_project_bin_sort_front(const TgsCamera* cam, int N, const float* means,
+                                          const float* log_scales, const float* quats,
+                                          const float* opac_logit, const float* sh, int sh_stride,
+                                          int sh_deg, float* splats, int32_t* radii, int32_t* group_base,
+                                          int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
+                                          int32_t* tile_order, int64_t capacity, void* scratch,
+                                          int32_t* status, int32_t* sticky_overflow,
+                                          const int32_t* tag_word, int32_t tag_expect, void* stream) {
+  TGS_CHECK_ARG(camera_ok(cam), "bad camera");
+  TGS_CHECK_ARG(N > 0 && capacity >= 0 && capacity < (1ll << 31), "bad size");
+  TGS_CHECK_ARG(group_base && tile_start && tile_cursor && sorted_gid && scratch && status && tag_word, "null pointer");
+  TGS_CHECK_ARG(means && log_scales && quats && opac_logit && sh && splats, "null pointer (the SH rows stay the fallback)");
+  TGS_CHECK_ARG(sh_deg >= 0 && sh_deg <= 3 && sh_stride >= (sh_deg + 1) * (sh_deg + 1), "bad SH degree / stride");
+  const CamK k = make_camk(cam);
+  hipStream_t s = (hipStream_t)stream;
+  const BinScratch sc = carve_scratch(scratch, capacity);
+  const dim3 grid((N + 255) / 256), block(256);
+#define LAUNCH_U(D)                                                                                   \
+  hipLaunchKernelGGL((k_project_fwd_unless_done<D>), grid, block, 0, s, k, N, means, log_scales, quats, \
+                     opac_logit, sh, sh_stride, splats, radii, group_base, tile_cursor, sc.rank, status, \
+                     (long long)capacity, sticky_overflow, tag_word, tag_expect)
+  switch (sh_deg) {
+    case 0: LAUNCH_U(0); break;
+    case 1: LAUNCH_U(1); break;
+    case 2: LAUNCH_U(2); break;
+    default: LAUNCH_U(3); break;
+  }
+#undef LAUNCH_U
+  TGS_CHECK_LAUNCH();
+  return tgs_bin_finish(k, N, splats, group_base, tile_start, tile_cursor, sorted_gid, tile_order,
+                        capacity, scratch, status, s);
 }
 
 // K1 + K3a fused, then scan / fill / sort: the whole front half of a frame in one call.

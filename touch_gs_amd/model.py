@@ -17,6 +17,7 @@ Two execution paths over the same kernels:
 from __future__ import annotations
 
 import collections
+import os
 import dataclasses
 import math
 from typing import Dict, Optional
@@ -118,6 +119,8 @@ class DepthGaussianSplattingModel:
         self._sync_budget = ops.IntersectBudget()   # render / eval path when `budget` is sync-free
         self.fuse_adam = True   # single-process steps use the fused K8+K9 kernel when it applies
         self.dp_factored_sh = True   # data-parallel steps exchange colour gradients, not SH rows
+        # single-process steps that know the next view: its K1 runs inside this step's optimizer kernel
+        self.front_prefetch = os.environ.get("TGS_FRONT_PREFETCH", "1") != "0"
         self._color_block = self._color_all = self._color_rows = None
         self.last = {}
 
@@ -472,7 +475,11 @@ class DepthGaussianSplattingModel:
             if bufs is None or bufs[0].N != N or bufs[0].colors.device != dev:
                 bufs = self._prefetch_bufs = [ops.ColorPrefetch(N, dev), ops.ColorPrefetch(N, dev)]
             # two buffers alternate: the one this step's K1 reads is not the one this step's K9 writes
-            arm = (bufs[1] if colors is bufs[0] else bufs[0]).arm(next_view.cam, deg)
+            # front prefetch: the optimizer kernel also runs the next view's K1 into that frame's buffers
+            front = None
+            if self.front_prefetch and not torch.cuda.is_current_stream_capturing():
+                front = ops.FrontBuffers(next_view.cam, N, self.budget.initial(N), density is not None, dev)
+            arm = (bufs[1] if colors is bufs[0] else bufs[0]).arm(next_view.cam, deg, front, self.budget)
         self.forward_backward(view, want_v_xy=density is not None, fuse_adam=fuse, color_block=block,
                               colors=colors, prefetch=arm)
         self._prefetch_ready = arm

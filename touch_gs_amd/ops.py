@@ -180,14 +180,44 @@ class ColorPrefetch:
         self.tag = 0
         self.cam = None
         self.N, self.sh_deg = N, -1
+        self.front = None           # FrontBuffers of that view's frame, if its K1 is prefetched too
+        self.front_budget = None    # the IntersectBudget that frame is binned with (capacity, sticky word)
+        self.front_issued = False   # the fused optimizer call that fills `front` has been enqueued
 
-    def arm(self, cam: Camera, sh_deg: int) -> "ColorPrefetch":
+    def arm(self, cam: Camera, sh_deg: int, front: Optional["FrontBuffers"] = None,
+            budget: Optional["IntersectBudget"] = None) -> "ColorPrefetch":
         self.tag += 1
         self.cam, self.sh_deg = cam, sh_deg
+        self.front, self.front_budget, self.front_issued = front, budget, False
         return self
 
     def matches(self, cam: Camera, N: int, sh_deg: int) -> bool:
         return self.cam is cam and self.N == N and self.sh_deg == sh_deg and self.tag > 0
+
+
+class FrontBuffers:
+    """Everything the front half of ONE frame writes (what project_bin_sort allocates per call).  Allocated one
+    step ahead when the previous step's fused optimizer kernel also runs this frame's K1 (front prefetch,
+    tgs_project_bwd_adam_next_front): records, group bases, per-tile counters and ranks are then filled by that
+    kernel, and project_bin_sort only scans, fills and sorts (tgs_project_bin_sort_front)."""
+
+    def __init__(self, cam: Camera, N: int, cap: int, want_radii: bool, dev):
+        lib = _lib.load()
+        T = cam.num_tiles
+        self.N, self.cap, self.cam = N, cap, cam
+        self.splats = torch.empty(max(N, 1), SPLAT_FLOATS, dtype=torch.float32, device=dev)[:N]  # non-null even for N = 0
+        self.radii = torch.empty(N, dtype=torch.int32, device=dev) if want_radii else None
+        self.group_base = torch.empty(max(lib.tgs_num_groups(N), 1), dtype=torch.int32, device=dev)
+        self.tile_start = torch.empty(T + 1, dtype=torch.int32, device=dev)
+        nc = lib.tgs_tile_counter_len(cam.W, cam.H)
+        counters = torch.empty(nc + 4, dtype=torch.int32, device=dev)   # per-XCD tile counters + sub-list starts | status[4]
+        self.tile_cursor, self.status, self.status4 = counters[:nc], counters[nc:nc + 2], counters[nc:]
+        # block -> tile schedule of K6 / K7 (tiles dealt to the XCDs in granules of 8, longest list first inside each XCD); it rides on the
+        # tile_start tensor object so that the (tile_start, sorted_gid) pair keeps its meaning for callers
+        self.tile_start.tile_order = torch.empty(lib.tgs_tile_order_len(cam.W, cam.H), dtype=torch.int32, device=dev)
+        self.tile_start.slot_ok = None     # quadrant bitmaps K6 leaves for K7 (rasterize_fwd allocates and fills them)
+        self.sorted_gid = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+        self.scratch = torch.empty(lib.tgs_sort_scratch_bytes(cap), dtype=torch.uint8, device=dev)
 
 
 def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_deg: int,
@@ -200,27 +230,33 @@ def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_d
     budget = budget or _default_budget
     N = means.shape[0]
     dev = means.device
-    T = cam.num_tiles
-    G = lib.tgs_num_groups(N)
     cs = cam.c_struct()
-    splats = torch.empty(max(N, 1), SPLAT_FLOATS, dtype=torch.float32, device=dev)[:N]  # non-null even for N = 0
-    radii = torch.empty(N, dtype=torch.int32, device=dev) if want_radii else None
-    group_base = torch.empty(max(G, 1), dtype=torch.int32, device=dev)
-    tile_start = torch.empty(T + 1, dtype=torch.int32, device=dev)
-    nc = lib.tgs_tile_counter_len(cam.W, cam.H)
-    counters = torch.empty(nc + 4, dtype=torch.int32, device=dev)   # per-XCD tile counters + sub-list starts | status[4]
-    tile_cursor, status, status4 = counters[:nc], counters[nc:nc + 2], counters[nc:]
-    # block -> tile schedule of K6 / K7 (tiles dealt to the XCDs in granules of 8, longest list first inside each XCD); it rides on the
-    # tile_start tensor object so that the (tile_start, sorted_gid) pair keeps its meaning for callers
-    tile_order = torch.empty(lib.tgs_tile_order_len(cam.W, cam.H), dtype=torch.int32, device=dev)
-    tile_start.tile_order = tile_order
-    tile_start.slot_ok = None          # quadrant bitmaps K6 leaves for K7 (rasterize_fwd allocates and fills them)
     sh_stride = sh.shape[1] if sh is not None else 0
     cap = budget.initial(N)
+    # front prefetch: this frame's K1 already ran inside the previous step's optimizer kernel, into buffers
+    # allocated then (same sizes as here) -- usable if nothing changed in between
+    fb = colors.front if (colors is not None and sh is not None and N > 0 and colors.front_issued) else None
+    if fb is not None:
+        colors.front, colors.front_issued = None, False      # single use: the finish below consumes the counters
+        if (fb.N != N or fb.cap != cap or fb.cam is not cam or colors.front_budget is not budget
+                or (want_radii and fb.radii is None)):
+            fb = None
+    from_front = fb is not None
+    if fb is None:
+        fb = FrontBuffers(cam, N, cap, want_radii, dev)
+    splats, radii, group_base, tile_start = fb.splats, fb.radii, fb.group_base, fb.tile_start
+    tile_cursor, status, status4, tile_order = fb.tile_cursor, fb.status, fb.status4, fb.tile_start.tile_order
+    sorted_gid, scratch = fb.sorted_gid, fb.scratch
     while True:
-        sorted_gid = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
-        scratch = torch.empty(lib.tgs_sort_scratch_bytes(cap), dtype=torch.uint8, device=dev)
-        if colors is None or sh is None:
+        if from_front:
+            check(lib.tgs_project_bin_sort_front(C.byref(cs), N, ptr(means), ptr(log_scales), ptr(quats), ptr(opac_logit),
+                                                 ptr(sh), sh_stride, sh_deg, ptr(splats), ptr(radii), ptr(group_base),
+                                                 ptr(tile_start), ptr(tile_cursor), ptr(sorted_gid), ptr(tile_order),
+                                                 cap, ptr(scratch), ptr(status), ptr(budget.sticky_word(dev)),
+                                                 ptr(colors.tag_word), colors.tag, _stream()),
+                  "tgs_project_bin_sort_front")
+            from_front = False          # a regrown capacity (synchronous budget) goes through the regular K1
+        elif colors is None or sh is None:
             check(lib.tgs_project_bin_sort(C.byref(cs), N, ptr(means), ptr(log_scales), ptr(quats), ptr(opac_logit),
                                            ptr(sh), sh_stride, sh_deg if sh is not None else -1, ptr(splats),
                                            ptr(radii), ptr(group_base), ptr(tile_start), ptr(tile_cursor),
@@ -245,6 +281,8 @@ def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_d
             break
         cap = int(n * budget.growth) + 1024
         budget.capacity = cap
+        sorted_gid = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+        scratch = torch.empty(lib.tgs_sort_scratch_bytes(cap), dtype=torch.uint8, device=dev)
     return splats, radii, group_base, tile_start, sorted_gid, status
 
 

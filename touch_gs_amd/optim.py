@@ -179,6 +179,16 @@ class FusedAdam:
             check(lib.tgs_project_bwd_adam(C.byref(cs), self.p.N, self.p.K, sh_deg, ptr(self.p.flat), ptr(self.exp_avg),
                                            ptr(self.exp_avg_sq), C.byref(s), ptr(splats), ptr(group_base),
                                            ptr(partials), ptr(v_xy), ptr(guard), stream), "tgs_project_bwd_adam")
+        elif prefetch.front is not None:
+            # ... and the next view's K1 (records, pair ranges, tile counts) into that frame's buffers
+            ncs, fb, budget = prefetch.cam.c_struct(), prefetch.front, prefetch.front_budget
+            check(lib.tgs_project_bwd_adam_next_front(
+                C.byref(cs), self.p.N, self.p.K, sh_deg, ptr(self.p.flat), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                C.byref(s), ptr(splats), ptr(group_base), ptr(partials), ptr(v_xy), ptr(guard), C.byref(ncs),
+                ptr(prefetch.colors), ptr(prefetch.tag_word), prefetch.tag, ptr(fb.splats), ptr(fb.radii),
+                ptr(fb.group_base), ptr(fb.tile_cursor), fb.cap, ptr(fb.scratch), ptr(fb.status),
+                ptr(budget.sticky_word(self.p.flat.device)), stream), "tgs_project_bwd_adam_next_front")
+            prefetch.front_issued = True
         else:
             ncs = prefetch.cam.c_struct()
             check(lib.tgs_project_bwd_adam_next(C.byref(cs), self.p.N, self.p.K, sh_deg, ptr(self.p.flat),
