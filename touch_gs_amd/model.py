@@ -367,6 +367,7 @@ class DepthGaussianSplattingModel:
             need = max(int(h[0]) for _, h, _ in redo)      # this rank's own largest frame
             self.budget.capacity = max(self.budget.capacity, int(need * self.budget.growth) + 1024)
             self.budget.sticky.zero_()
+            self._prefetch_ready = None     # announced by a voided step: its front buffers were cleared under the sticky word
             self.optimizer.t -= len(redo)
             self.step -= len(redo)
             self.speculative_replays = getattr(self, "speculative_replays", 0) + len(redo)
