@@ -635,8 +635,9 @@ def test_trainer_on_disk_dataset_in_reference_format(dev, tmp_path):
     assert len(os.listdir(tmp_path / "disk_exp_renders" / "rgb")) == 1
 
 
+@pytest.mark.parametrize("announce", [False, True])
 @pytest.mark.parametrize("capacity", [0, 3000])
-def test_speculative_budget_equals_synchronous_budget(dev, capacity):
+def test_speculative_budget_equals_synchronous_budget(dev, capacity, announce):
     """Sync-free training: status words are read late; capacity=3000 is far too small, so frames
     overflow, the sticky device word turns the following steps into no-ops, and the host replays them
     with grown buffers -- parameters, moments and step counters end bit-identical to the synchronous
@@ -654,7 +655,9 @@ def test_speculative_budget_equals_synchronous_budget(dev, capacity):
     spec.enable_speculative_budget(capacity=capacity, max_in_flight=3)
     for step in range(11):
         ref.train_step(views[step % 4])
-        spec.train_step(views[step % 4])
+        # the next view is announced: colour + front prefetch run ahead of the verdicts (the overflowing steps void
+        # the optimizer kernel that would have produced them; the replay drops what a voided step announced)
+        spec.train_step(views[step % 4], next_view=views[(step + 1) % 4] if announce else None)
     spec.flush()
     torch.cuda.synchronize()
     assert spec.step == ref.step == 11 and spec.optimizer.t == ref.optimizer.t == 11
