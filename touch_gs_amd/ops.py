@@ -225,7 +225,9 @@ def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_d
                      colors: Optional[ColorPrefetch] = None):
     """K1 fused with the tile counting, then scan / fill / sort: the front half of a frame in ONE C
     call -> (splats, radii or None, group_base, tile_start, sorted_gid, status).  (tgs_project_bin_sort;
-    with ``colors`` -- a ColorPrefetch armed for THIS camera -- tgs_project_bin_sort_colors)"""
+    with ``colors`` -- a ColorPrefetch armed for THIS camera -- tgs_project_bin_sort_colors, or, if the previous
+    step's optimizer kernel also ran this frame's K1 into ``colors.front``, tgs_project_bin_sort_front: scan, fill
+    and sort only)"""
     lib = _lib.load()
     budget = budget or _default_budget
     N = means.shape[0]
