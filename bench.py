@@ -307,7 +307,8 @@ def main():
     def step(i):
         # single process: the view of the following step is known, so the optimizer kernel of this step
         # also evaluates the colours the updated Gaussians show to it (colour prefetch; same results)
-        nxt = None if (dp.active or args.no_color_prefetch) else views[dp.views_for_step(i + 1, len(views))]
+        # (data parallel: this rank's next view -- the geometry Adam of the step then runs its K1, front prefetch)
+        nxt = None if args.no_color_prefetch else views[dp.views_for_step(i + 1, len(views))]
         model.train_step(views[dp.views_for_step(i, len(views))], dp if dp.active else None, next_view=nxt)
 
     done = [0]

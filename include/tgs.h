@@ -295,6 +295,18 @@ int tgs_project_bwd_adam_next_front(const TgsCamera* cam /*[host]*/, int N, int 
                                     int32_t* radii_next, int32_t* group_base_next, int32_t* tile_cursor_next,
                                     int64_t capacity_next, void* scratch_next, int32_t* status_next,
                                     int32_t* sticky_overflow, void* stream);
+/* Data-parallel counterpart (the optimizer is not fused with K8 there): Adam on the 11 geometry parameters of every
+ *     Gaussian from the all-reduced flat gradient `grads` (layout of `params`, scaled by grad_scale) -- what
+ *     tgs_adam_step does on [0, start of the SH segment) -- and, on the result, the next view's K1 with the colours
+ *     from the (already stepped) SH rows, into the next frame's buffers; then *tag_word = tag_value.
+ *     tgs_project_bin_sort_front completes that frame.  No-op (tag unchanged) if skip_if_overflow[1] != 0. */
+int tgs_adam_geom_project_next(const TgsCamera* next_cam /*[host]*/, int N, int sh_stride, int sh_deg,
+                               float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                               const TgsAdamSpec* spec /*[host]*/, float grad_scale,
+                               const int32_t* skip_if_overflow, int32_t* tag_word, int32_t tag_value,
+                               float* splats_next, int32_t* radii_next, int32_t* group_base_next,
+                               int32_t* tile_cursor_next, int64_t capacity_next, void* scratch_next,
+                               int32_t* status_next, int32_t* sticky_overflow, void* stream);
 int tgs_project_bin_sort_front(const TgsCamera* cam /*[host]*/, int N, const float* means,
                                const float* log_scales, const float* quats, const float* opac_logit,
                                const float* sh, int sh_stride, int sh_deg, float* splats, int32_t* radii,

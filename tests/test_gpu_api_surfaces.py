@@ -272,6 +272,32 @@ assert ds.params.N == dm.params.N and torch.equal(ds.params.flat, dm.params.flat
 assert torch.equal(ds.optimizer.exp_avg_sq, dm.optimizer.exp_avg_sq)
 dp.assert_replicas_identical(ds.params.flat)
 dp.barrier()
+# front prefetch of the data-parallel form: with the rank's next view announced, the geometry Adam (last kernel of
+# the step) also runs that view's K1 (tgs_adam_geom_project_next) and the next step only scans, fills and sorts --
+# bit-identical to the unannounced sequence, also with densification statistics (radii) and the sync-free budget
+# across a forced overflow
+def run_announced(announce, speculative):
+    m = fresh()
+    m.enable_densification(DensifyConfig(warmup_length=1000, refine_every=1000))
+    if speculative:
+        m.enable_speculative_budget(capacity=3000, max_in_flight=2)
+    taken = 0
+    for step in range(7):
+        nxt = views[dp.views_for_step(step + 1, 4)] if announce else None
+        pre = getattr(m, "_prefetch_ready", None)
+        taken += int(pre is not None and pre.front_issued)
+        m.train_step(views[dp.views_for_step(step, 4)], dp, next_view=nxt)
+    m.flush()
+    torch.cuda.synchronize()
+    return m, taken
+for speculative in (False, True):
+    (fa, taken), (fb, none) = run_announced(True, speculative), run_announced(False, speculative)
+    assert taken >= 3 and none == 0, (taken, none)
+    assert torch.equal(fa.params.flat, fb.params.flat), (fa.params.flat - fb.params.flat).abs().max().item()
+    assert torch.equal(fa.optimizer.exp_avg, fb.optimizer.exp_avg) and torch.equal(fa.optimizer.exp_avg_sq, fb.optimizer.exp_avg_sq)
+    assert torch.equal(fa.density.grad_norm_sum, fb.density.grad_norm_sum) and torch.equal(fa.density.max_radius, fb.density.max_radius)
+    dp.assert_replicas_identical(fa.params.flat)
+dp.barrier()
 if dp.rank == 0: print("DP_OK", d)
 '''
 

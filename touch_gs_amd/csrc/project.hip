@@ -411,6 +411,64 @@ __global__ __launch_bounds__(256) void k_project_fwd_unless_done(
                                      splats, radii, group_base, tile_count, rank, status, capacity, sticky, &S);
 }
 
+// Data-parallel step: Adam on the 11 geometry parameters of every Gaussian from the all-reduced gradients AND the
+// next view's K1 on the result (front prefetch of the data-parallel form: there the optimizer is not fused with K8,
+// and the SH rows were stepped just before by the gathered-SH kernel, so the colour comes from the SH rows as in the
+// stand-alone K1).  Replaces k_adam on the geometry segments + the next step's k_project_fwd; same adam1, same
+// project_fwd_core on the same values: bit-identical to the two-kernel sequence.
+template <int DEG>
+__global__ __launch_bounds__(256) void k_adam_geom_project_next(
+    CamK cam, int N, int sh_stride, float* __restrict__ means, float* __restrict__ log_scales,
+    float* __restrict__ quats, float* __restrict__ opac_logit, const float* __restrict__ sh,
+    const float* __restrict__ grads, AdamK ad_in, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
+    float* __restrict__ splats, int32_t* __restrict__ radii, int32_t* __restrict__ group_base,
+    int32_t* __restrict__ tile_count, int32_t* __restrict__ rank, int32_t* __restrict__ status,
+    long long capacity, int32_t* __restrict__ sticky, int32_t* __restrict__ tag, int32_t tag_value) {
+  __shared__ GroupScan S;
+  if (ad_in.guard && ad_in.guard[1]) return;   // a rank's frame overflowed: no update, the tag keeps its old value
+  const AdamK ad = adam_resolve(ad_in);
+  const int g = tgs_group_id() * 256 + threadIdx.x;
+  float m[3] = {0.f, 0.f, 0.f}, ls[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, rgb[3] = {0.f, 0.f, 0.f};
+  float ol = 0.f;
+  if (g < N) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const long long e = 3ll * g + j;
+      float P = means[3 * g + j], M = exp_avg[e], V = exp_avg_sq[e];
+      adam1(ad, ad.lr_means, P, grads[e], M, V);
+      means[3 * g + j] = P; exp_avg[e] = M; exp_avg_sq[e] = V;
+      m[j] = P;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const long long e = ad.e_means + 3ll * g + j;
+      float P = log_scales[3 * g + j], M = exp_avg[e], V = exp_avg_sq[e];
+      adam1(ad, ad.lr_scales, P, grads[e], M, V);
+      log_scales[3 * g + j] = P; exp_avg[e] = M; exp_avg_sq[e] = V;
+      ls[j] = P;
+    }
+    {
+      const long long e = ad.e_scales + 4ll * g;
+      float4 Q = ld4(quats + 4 * (size_t)g), G = ld4_nt(grads + e), M = ld4_nt(exp_avg + e), V = ld4_nt(exp_avg_sq + e);
+      adam1(ad, ad.lr_quats, Q.x, G.x, M.x, V.x); adam1(ad, ad.lr_quats, Q.y, G.y, M.y, V.y);
+      adam1(ad, ad.lr_quats, Q.z, G.z, M.z, V.z); adam1(ad, ad.lr_quats, Q.w, G.w, M.w, V.w);
+      st4(quats + 4 * (size_t)g, Q); st4_nt(exp_avg + e, M); st4_nt(exp_avg_sq + e, V);
+      q[0] = Q.x; q[1] = Q.y; q[2] = Q.z; q[3] = Q.w;
+    }
+    {
+      const long long e = ad.e_quats + g;
+      float P = opac_logit[g], M = exp_avg[e], V = exp_avg_sq[e];
+      adam1(ad, ad.lr_opac, P, grads[e], M, V);
+      opac_logit[g] = P; exp_avg[e] = M; exp_avg_sq[e] = V;
+      ol = P;
+    }
+    sh_color<DEG>(m, cam.campos, sh + (size_t)g * sh_stride * 3, rgb);
+  }
+  project_fwd_core<true>(cam, N, g, m, ls, q, ol, rgb, splats, radii, group_base, tile_count, rank, status,
+                         capacity, sticky, &S);
+  if (g == 0) *tag = tag_value;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K8a: partials -> one gradient record per Gaussian
 // ---------------------------------------------------------------------------------------------
@@ -1223,6 +1281,51 @@ extern "C" int tgs_project_bwd_adam_next_front(const TgsCamera* cam, int N, int 
   nx.fr.capacity = (long long)capacity_next; nx.fr.sticky = sticky_overflow;
   return project_bwd_adam_impl(cam, N, sh_stride, sh_deg, params, exp_avg, exp_avg_sq, spec, splats,
                                group_base, partials, v_xy, skip_if_overflow, nx, stream);
+}
+
+// Data-parallel counterpart: geometry Adam from the all-reduced gradients + the next view's K1 (see the kernel).
+extern "C" int tgs_adam_geom_project_next(const TgsCamera* next_cam, int N, int sh_stride, int sh_deg,
+                                          float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                          const TgsAdamSpec* spec, float grad_scale,
+                                          const int32_t* skip_if_overflow, int32_t* tag_word, int32_t tag_value,
+                                          float* splats_next, int32_t* radii_next, int32_t* group_base_next,
+                                          int32_t* tile_cursor_next, int64_t capacity_next, void* scratch_next,
+                                          int32_t* status_next, int32_t* sticky_overflow, void* stream) {
+  TGS_CHECK_ARG(camera_ok(next_cam), "bad next camera");
+  TGS_CHECK_ARG(next_cam->W <= 4080 && next_cam->H <= 4080, "image side > 4080 px (255 tiles)");
+  TGS_CHECK_ARG(N >= 0 && capacity_next >= 0 && capacity_next < (1ll << 31), "bad size");
+  if (N == 0) return TGS_OK;
+  TGS_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && spec && tag_word, "null pointer");
+  TGS_CHECK_ARG(splats_next && group_base_next && tile_cursor_next && scratch_next && status_next, "null front buffer");
+  TGS_CHECK_ARG(sh_deg >= 0 && sh_deg <= 3 && sh_stride >= (sh_deg + 1) * (sh_deg + 1), "bad SH degree / stride");
+  const CamK kn = make_camk(next_cam);
+  const int T = kn.TW * kn.TH;
+  hipStream_t s = (hipStream_t)stream;
+  const BinScratch sc = carve_scratch(scratch_next, capacity_next);
+  hipLaunchKernelGGL(k_clear_counters, dim3((max(TGS_XCC * T, 2) + 255) / 256), dim3(256), 0, s, tile_cursor_next, T,
+                     status_next, sticky_overflow);
+  TGS_CHECK_LAUNCH();
+  AdamK a = make_adamk(N, sh_stride, spec, grad_scale);
+  a.guard = skip_if_overflow;
+  float* means = params;
+  float* log_scales = params + a.e_means;
+  float* quats = params + a.e_scales;
+  float* opac = params + a.e_quats;
+  const float* sh = params + a.e_opac;
+  const dim3 grid((N + 255) / 256), block(256);
+#define LAUNCH_G(D)                                                                                          \
+  hipLaunchKernelGGL((k_adam_geom_project_next<D>), grid, block, 0, s, kn, N, sh_stride, means, log_scales,    \
+                     quats, opac, sh, grads, a, exp_avg, exp_avg_sq, splats_next, radii_next, group_base_next, \
+                     tile_cursor_next, sc.rank, status_next, (long long)capacity_next, sticky_overflow, tag_word, tag_value)
+  switch (sh_deg) {
+    case 0: LAUNCH_G(0); break;
+    case 1: LAUNCH_G(1); break;
+    case 2: LAUNCH_G(2); break;
+    default: LAUNCH_G(3); break;
+  }
+#undef LAUNCH_G
+  TGS_CHECK_LAUNCH();
+  return TGS_OK;
 }
 
 // The rest of a frame whose K1 tgs_project_bwd_adam_next_front (tag_word == tag_expect) has run: scan / fill /

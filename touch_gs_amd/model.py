@@ -468,7 +468,10 @@ class DepthGaussianSplattingModel:
                     self._color_blocks_all.append(self._color_all[dp.world * off:dp.world * (off + m)].view(dp.world, m))
                     off += m
             block = (rows, self._color_blocks)
-        colors = pre if (pre is not None and fuse and pre.matches(view.cam, self.params.N, deg)) else None
+        # prefetched by the previous step: colours (+ front) from the fused optimizer kernel, or the front alone from
+        # the geometry Adam of a data-parallel step
+        colors = pre if (pre is not None and (fuse or (factored and pre.front_issued and not pre.colors_valid))
+                         and pre.matches(view.cam, self.params.N, deg)) else None
         arm = None
         if fuse and next_view is not None and self.active_sh_degree(self.step + 1) == deg:
             bufs = getattr(self, "_prefetch_bufs", None)
@@ -481,8 +484,18 @@ class DepthGaussianSplattingModel:
             if self.front_prefetch and not torch.cuda.is_current_stream_capturing():
                 front = ops.FrontBuffers(next_view.cam, N, self.budget.initial(N), density is not None, dev)
             arm = (bufs[1] if colors is bufs[0] else bufs[0]).arm(next_view.cam, deg, front, self.budget)
+        if (factored and next_view is not None and self.front_prefetch
+                and self.active_sh_degree(self.step + 1) == deg):
+            # data-parallel form of the front prefetch: the geometry Adam (last kernel of the step) also runs this
+            # rank's next K1; no colours (the SH rows are stepped by another kernel)
+            N, dev = self.params.N, self.params.flat.device
+            bufs = getattr(self, "_prefetch_bufs", None)
+            if bufs is None or bufs[0].N != N or bufs[0].colors.device != dev:
+                bufs = self._prefetch_bufs = [ops.ColorPrefetch(N, dev), ops.ColorPrefetch(N, dev)]
+            front = ops.FrontBuffers(next_view.cam, N, self.budget.initial(N), density is not None, dev)
+            arm = (bufs[1] if pre is bufs[0] else bufs[0]).arm(next_view.cam, deg, front, self.budget, colors_valid=False)
         self.forward_backward(view, want_v_xy=density is not None, fuse_adam=fuse, color_block=block,
-                              colors=colors, prefetch=arm)
+                              colors=colors, prefetch=arm if fuse else None)
         self._prefetch_ready = arm
         if density is not None and not factored:
             # a frame that overflowed its intersection buffer (sync-free budget) rendered nothing and will be
@@ -502,9 +515,13 @@ class DepthGaussianSplattingModel:
                     ops.dp_agree_overflow(dp.world, rows[0][1] - rows[0][0], allc, dguard, self.budget.sticky)
                 opt.step_sh_gathered(dp.world, deg, allc, scale, guard=dguard, rows=rows[c])
 
+            if arm is not None and not fuse:
+                step_geom = lambda b, e, scale: opt.step_geom_and_project_next(deg, scale, dguard, arm)
+            else:
+                step_geom = lambda b, e, scale: opt.step_range(b, e, scale, guard=dguard)
             dp.pipelined_color_exchange_and_step(
                 self.params.grad[:opt.geom_end()], self._color_blocks, self._color_blocks_all, self._backward_chunk,
-                step_sh_chunk, lambda b, e, scale: opt.step_range(b, e, scale, guard=dguard), opt.begin_step)
+                step_sh_chunk, step_geom, opt.begin_step)
             self._backward_chunk = None
             if density is not None:   # v_xy exists once the K8 chunks are enqueued
                 density.accumulate(self.last["v_xy"], self.last["radii"], view.cam.W, view.cam.H,

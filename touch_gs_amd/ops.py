@@ -183,12 +183,14 @@ class ColorPrefetch:
         self.front = None           # FrontBuffers of that view's frame, if its K1 is prefetched too
         self.front_budget = None    # the IntersectBudget that frame is binned with (capacity, sticky word)
         self.front_issued = False   # the fused optimizer call that fills `front` has been enqueued
+        self.colors_valid = True    # False: only `front` is produced (data-parallel form), `colors` stays unwritten
 
     def arm(self, cam: Camera, sh_deg: int, front: Optional["FrontBuffers"] = None,
-            budget: Optional["IntersectBudget"] = None) -> "ColorPrefetch":
+            budget: Optional["IntersectBudget"] = None, colors_valid: bool = True) -> "ColorPrefetch":
         self.tag += 1
         self.cam, self.sh_deg = cam, sh_deg
         self.front, self.front_budget, self.front_issued = front, budget, False
+        self.colors_valid = colors_valid
         return self
 
     def matches(self, cam: Camera, N: int, sh_deg: int) -> bool:
@@ -244,6 +246,9 @@ def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_d
                 or (want_radii and fb.radii is None)):
             fb = None
     from_front = fb is not None
+    tag_holder = colors
+    if colors is not None and not colors.colors_valid:
+        colors = None                    # nothing but the front was prefetched: any other path evaluates the SH rows
     if fb is None:
         fb = FrontBuffers(cam, N, cap, want_radii, dev)
     splats, radii, group_base, tile_start = fb.splats, fb.radii, fb.group_base, fb.tile_start
@@ -255,7 +260,7 @@ def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_d
                                                  ptr(sh), sh_stride, sh_deg, ptr(splats), ptr(radii), ptr(group_base),
                                                  ptr(tile_start), ptr(tile_cursor), ptr(sorted_gid), ptr(tile_order),
                                                  cap, ptr(scratch), ptr(status), ptr(budget.sticky_word(dev)),
-                                                 ptr(colors.tag_word), colors.tag, _stream()),
+                                                 ptr(tag_holder.tag_word), tag_holder.tag, _stream()),
                   "tgs_project_bin_sort_front")
             from_front = False          # a regrown capacity (synchronous budget) goes through the regular K1
         elif colors is None or sh is None:

@@ -154,6 +154,20 @@ class FusedAdam:
                                 ptr(self.exp_avg_sq), C.byref(s), C.c_float(grad_scale), elem_begin, elem_end,
                                 ptr(guard), stream), "tgs_adam_step")
 
+    def step_geom_and_project_next(self, sh_deg: int, grad_scale: float, guard, prefetch):
+        """Data-parallel step: Adam on the geometry segments from ``params.grad`` (all-reduced) fused with the NEXT
+        view's K1 into ``prefetch.front`` (tgs_adam_geom_project_next); call after the SH rows have been stepped."""
+        lib = _lib.load()
+        s = self._spec()
+        ncs, fb, budget = prefetch.cam.c_struct(), prefetch.front, prefetch.front_budget
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.tgs_adam_geom_project_next(
+            C.byref(ncs), self.p.N, self.p.K, sh_deg, ptr(self.p.flat), ptr(self.p.grad), ptr(self.exp_avg),
+            ptr(self.exp_avg_sq), C.byref(s), C.c_float(grad_scale), ptr(guard), ptr(prefetch.tag_word), prefetch.tag,
+            ptr(fb.splats), ptr(fb.radii), ptr(fb.group_base), ptr(fb.tile_cursor), fb.cap, ptr(fb.scratch),
+            ptr(fb.status), ptr(budget.sticky_word(self.p.flat.device)), stream), "tgs_adam_geom_project_next")
+        prefetch.front_issued = True
+
     def step(self, grad_scale: float = 1.0, guard=None):
         self.begin_step()
         self.step_range(0, -1, grad_scale, guard)

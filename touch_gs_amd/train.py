@@ -165,7 +165,7 @@ def main(argv=None):
     for step in range(model.step, args.max_num_iterations):
         view = train_views[dp.views_for_step(step, len(train_views))]
         # single process: tell the step which view follows (colour prefetch, model.train_step)
-        nxt = None if dp.active else train_views[dp.views_for_step(step + 1, len(train_views))]
+        nxt = train_views[dp.views_for_step(step + 1, len(train_views))]   # this rank's next view (prefetches)
         model.train_step(view, dp if dp.active else None, next_view=nxt)
         if getattr(model, "_refined_at", None) == model.step and seen_refine != model.step:
             seen_refine, n_refines = model.step, n_refines + 1
