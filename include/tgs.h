@@ -294,7 +294,8 @@ int tgs_project_bwd_adam_next_front(const TgsCamera* cam /*[host]*/, int N, int 
                                     int32_t* tag_word, int32_t tag_value, float* splats_next,
                                     int32_t* radii_next, int32_t* group_base_next, int32_t* tile_cursor_next,
                                     int64_t capacity_next, void* scratch_next, int32_t* status_next,
-                                    int32_t* sticky_overflow, void* stream);
+                                    int32_t* sticky_overflow,
+                                    int counters_cleared /*1: tgs_project_bin_sort_front cleared them*/, void* stream);
 /* Data-parallel counterpart (the optimizer is not fused with K8 there): Adam on the 11 geometry parameters of every
  *     Gaussian from the all-reduced flat gradient `grads` (layout of `params`, scaled by grad_scale) -- what
  *     tgs_adam_step does on [0, start of the SH segment) -- and, on the result, the next view's K1 with the colours
@@ -306,14 +307,20 @@ int tgs_adam_geom_project_next(const TgsCamera* next_cam /*[host]*/, int N, int 
                                const int32_t* skip_if_overflow, int32_t* tag_word, int32_t tag_value,
                                float* splats_next, int32_t* radii_next, int32_t* group_base_next,
                                int32_t* tile_cursor_next, int64_t capacity_next, void* scratch_next,
-                               int32_t* status_next, int32_t* sticky_overflow, void* stream);
+                               int32_t* status_next, int32_t* sticky_overflow, int counters_cleared, void* stream);
 int tgs_project_bin_sort_front(const TgsCamera* cam /*[host]*/, int N, const float* means,
                                const float* log_scales, const float* quats, const float* opac_logit,
                                const float* sh, int sh_stride, int sh_deg, float* splats, int32_t* radii,
                                int32_t* group_base, int32_t* tile_start, int32_t* tile_cursor,
                                int32_t* sorted_gid, int32_t* tile_order, int64_t capacity, void* scratch,
                                int32_t* status, int32_t* sticky_overflow, const int32_t* tag_word,
-                               int32_t tag_expect, void* stream);
+                               int32_t tag_expect,
+                               const TgsCamera* next_cam /*[host] or NULL*/, int32_t* next_tile_cursor /*or NULL*/,
+                               int32_t* next_status /*or NULL*/, void* stream);
+/* next_tile_cursor != NULL: the (otherwise idle) threads of this call's K1-check launch also clear the counters and
+ * the status word of the frame AFTER this one (next_cam's size; sticky_overflow as usual) -- pass counters_cleared = 1
+ * to the optimizer call that fills them.  Needs ceil(N/256)*256 >= 8 * #tiles of that frame: */
+int tgs_front_can_clear_next(int N, int W, int H);
 
 /* Data-parallel step (one view per rank, SURVEY section 8 row e).  The SH gradient of a rank is the
  *     outer product Y_k(dir(g)) x v_color[g,:], so the ranks exchange v_color (all-gather, 3 floats

@@ -67,11 +67,12 @@ SIGNATURES = {
                                             _P, _P, C.POINTER(TgsCamera), _P, _P, C.c_int32, _P]),
     "tgs_project_bwd_adam_next_front": (C.c_int, [C.POINTER(TgsCamera), _I, _I, _I, _P, _P, _P, C.POINTER(TgsAdamSpec), _P, _P, _P,
                                                   _P, _P, C.POINTER(TgsCamera), _P, _P, C.c_int32, _P, _P, _P, _P, C.c_int64,
-                                                  _P, _P, _P, _P]),
+                                                  _P, _P, _P, _I, _P]),
     "tgs_adam_geom_project_next": (C.c_int, [C.POINTER(TgsCamera), _I, _I, _I, _P, _P, _P, _P, C.POINTER(TgsAdamSpec), C.c_float,
-                                             _P, _P, C.c_int32, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _P]),
+                                             _P, _P, C.c_int32, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _I, _P]),
     "tgs_project_bin_sort_front": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P,
-                                             _P, _P, C.c_int64, _P, _P, _P, _P, C.c_int32, _P]),
+                                             _P, _P, C.c_int64, _P, _P, _P, _P, C.c_int32, C.POINTER(TgsCamera), _P, _P, _P]),
+    "tgs_front_can_clear_next": (C.c_int, [_I, _I, _I]),
     "tgs_project_bwd_color": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I] + [_P] * 11),
     "tgs_project_bwd_color_rows": (C.c_int, [C.POINTER(TgsCamera), _I, _I, _I, _P, _P, _P, _P, _P, _I, _I] + [_P] * 11),
     "tgs_adam_step_sh_gathered_rows": (C.c_int, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, C.POINTER(TgsAdamSpec), C.c_float, _P, _P]),

@@ -404,8 +404,11 @@ __global__ __launch_bounds__(256) void k_project_fwd_unless_done(
     float* __restrict__ splats, int32_t* __restrict__ radii, int32_t* __restrict__ group_base,
     int32_t* __restrict__ tile_count, int32_t* __restrict__ rank, int32_t* __restrict__ status,
     long long capacity, int32_t* __restrict__ sticky, const int32_t* __restrict__ front_tag,
-    int32_t tag_expect) {
+    int32_t tag_expect, int32_t* __restrict__ next_cursor, int next_T, int32_t* __restrict__ next_status) {
   __shared__ GroupScan S;
+  // this launch has N otherwise idle threads: they clear the counters of the frame AFTER this one (whose K1 this
+  // step's optimizer kernel will run), which saves that call its own clearing launch
+  if (next_cursor) clear_counters_elem(blockIdx.x * 256 + threadIdx.x, next_cursor, next_T, next_status, sticky);
   if (*front_tag == tag_expect) return;
   project_fwd_body<DEG, true, false>(cam, N, means, log_scales, quats, opac_logit, sh, sh_stride, nullptr,
                                      splats, radii, group_base, tile_count, rank, status, capacity, sticky, &S);
@@ -1260,7 +1263,8 @@ extern "C" int tgs_project_bwd_adam_next_front(const TgsCamera* cam, int N, int 
                                                float* splats_next, int32_t* radii_next,
                                                int32_t* group_base_next, int32_t* tile_cursor_next,
                                                int64_t capacity_next, void* scratch_next,
-                                               int32_t* status_next, int32_t* sticky_overflow, void* stream) {
+                                               int32_t* status_next, int32_t* sticky_overflow,
+                                               int counters_cleared, void* stream) {
   TGS_CHECK_ARG(camera_ok(next_cam), "bad next camera");
   TGS_CHECK_ARG(next_cam->W <= 4080 && next_cam->H <= 4080, "image side > 4080 px (255 tiles)");
   TGS_CHECK_ARG(colors_next && tag_word, "null colour prefetch buffer");
@@ -1270,9 +1274,11 @@ extern "C" int tgs_project_bwd_adam_next_front(const TgsCamera* cam, int N, int 
   const CamK kn = make_camk(next_cam);
   const int T = kn.TW * kn.TH;
   const BinScratch sc = carve_scratch(scratch_next, capacity_next);
-  hipLaunchKernelGGL(k_clear_counters, dim3((max(TGS_XCC * T, 2) + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                     tile_cursor_next, T, status_next, sticky_overflow);
-  TGS_CHECK_LAUNCH();
+  if (!counters_cleared) {
+    hipLaunchKernelGGL(k_clear_counters, dim3((max(TGS_XCC * T, 2) + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       tile_cursor_next, T, status_next, sticky_overflow);
+    TGS_CHECK_LAUNCH();
+  }
   NextView nx;
   nx.campos[0] = kn.campos[0]; nx.campos[1] = kn.campos[1]; nx.campos[2] = kn.campos[2];
   nx.colors = colors_next; nx.tag = tag_word; nx.tag_value = tag_value;
@@ -1290,7 +1296,8 @@ extern "C" int tgs_adam_geom_project_next(const TgsCamera* next_cam, int N, int 
                                           const int32_t* skip_if_overflow, int32_t* tag_word, int32_t tag_value,
                                           float* splats_next, int32_t* radii_next, int32_t* group_base_next,
                                           int32_t* tile_cursor_next, int64_t capacity_next, void* scratch_next,
-                                          int32_t* status_next, int32_t* sticky_overflow, void* stream) {
+                                          int32_t* status_next, int32_t* sticky_overflow, int counters_cleared,
+                                          void* stream) {
   TGS_CHECK_ARG(camera_ok(next_cam), "bad next camera");
   TGS_CHECK_ARG(next_cam->W <= 4080 && next_cam->H <= 4080, "image side > 4080 px (255 tiles)");
   TGS_CHECK_ARG(N >= 0 && capacity_next >= 0 && capacity_next < (1ll << 31), "bad size");
@@ -1302,9 +1309,11 @@ extern "C" int tgs_adam_geom_project_next(const TgsCamera* next_cam, int N, int 
   const int T = kn.TW * kn.TH;
   hipStream_t s = (hipStream_t)stream;
   const BinScratch sc = carve_scratch(scratch_next, capacity_next);
-  hipLaunchKernelGGL(k_clear_counters, dim3((max(TGS_XCC * T, 2) + 255) / 256), dim3(256), 0, s, tile_cursor_next, T,
-                     status_next, sticky_overflow);
-  TGS_CHECK_LAUNCH();
+  if (!counters_cleared) {
+    hipLaunchKernelGGL(k_clear_counters, dim3((max(TGS_XCC * T, 2) + 255) / 256), dim3(256), 0, s, tile_cursor_next, T,
+                       status_next, sticky_overflow);
+    TGS_CHECK_LAUNCH();
+  }
   AdamK a = make_adamk(N, sh_stride, spec, grad_scale);
   a.guard = skip_if_overflow;
   float* means = params;
@@ -1328,6 +1337,12 @@ extern "C" int tgs_adam_geom_project_next(const TgsCamera* next_cam, int N, int 
   return TGS_OK;
 }
 
+// Can tgs_project_bin_sort_front (N Gaussians) clear the counters of a W x H frame on the side?
+extern "C" int tgs_front_can_clear_next(int N, int W, int H) {
+  const int T = ((W + TGS_BLOCK - 1) / TGS_BLOCK) * ((H + TGS_BLOCK - 1) / TGS_BLOCK);
+  return N > 0 && (long long)((N + 255) / 256) * 256 >= max(TGS_XCC * T, 2);
+}
+
 // The rest of a frame whose K1 tgs_project_bwd_adam_next_front (tag_word == tag_expect) has run: scan / fill /
 // sort.  If the tag does not match (the fused kernel was voided by its overflow guard) K1 runs here, from the SH rows.
 extern "C" int tgs_project_bin_sort_front(const TgsCamera* cam, int N, const float* means,
@@ -1337,9 +1352,19 @@ extern "C" int tgs_project_bin_sort_front(const TgsCamera* cam, int N, const flo
                                           int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
                                           int32_t* tile_order, int64_t capacity, void* scratch,
                                           int32_t* status, int32_t* sticky_overflow,
-                                          const int32_t* tag_word, int32_t tag_expect, void* stream) {
+                                          const int32_t* tag_word, int32_t tag_expect,
+                                          const TgsCamera* next_cam, int32_t* next_tile_cursor,
+                                          int32_t* next_status, void* stream) {
   TGS_CHECK_ARG(camera_ok(cam), "bad camera");
   TGS_CHECK_ARG(N > 0 && capacity >= 0 && capacity < (1ll << 31), "bad size");
+  int next_T = 0;
+  if (next_tile_cursor) {
+    TGS_CHECK_ARG(camera_ok(next_cam) && next_status, "next frame's counters without its camera / status word");
+    const CamK kn = make_camk(next_cam);
+    next_T = kn.TW * kn.TH;
+    TGS_CHECK_ARG((long long)((N + 255) / 256) * 256 >= max(TGS_XCC * next_T, 2),
+                  "too few Gaussians to clear the next frame's counters (tgs_front_can_clear_next)");
+  }
   TGS_CHECK_ARG(group_base && tile_start && tile_cursor && sorted_gid && scratch && status && tag_word, "null pointer");
   TGS_CHECK_ARG(means && log_scales && quats && opac_logit && sh && splats, "null pointer (the SH rows stay the fallback)");
   TGS_CHECK_ARG(sh_deg >= 0 && sh_deg <= 3 && sh_stride >= (sh_deg + 1) * (sh_deg + 1), "bad SH degree / stride");
@@ -1350,7 +1375,7 @@ extern "C" int tgs_project_bin_sort_front(const TgsCamera* cam, int N, const flo
 #define LAUNCH_U(D)                                                                                   \
   hipLaunchKernelGGL((k_project_fwd_unless_done<D>), grid, block, 0, s, k, N, means, log_scales, quats, \
                      opac_logit, sh, sh_stride, splats, radii, group_base, tile_cursor, sc.rank, status, \
-                     (long long)capacity, sticky_overflow, tag_word, tag_expect)
+                     (long long)capacity, sticky_overflow, tag_word, tag_expect, next_tile_cursor, next_T, next_status)
   switch (sh_deg) {
     case 0: LAUNCH_U(0); break;
     case 1: LAUNCH_U(1); break;

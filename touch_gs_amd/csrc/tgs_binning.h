@@ -131,15 +131,19 @@ __device__ __forceinline__ void group_pair_xy(const GroupScan& S, int i, int& j,
 // `sticky` (may be NULL): a persistent overflow word.  Once an overflowing frame has set it, every
 // later frame starts with status[1] = 1 -- empty lists, and the guarded optimizer kernels do nothing
 // -- until the host, which reads the status words late and without blocking, clears it and replays.
-static __global__ __launch_bounds__(256) void k_clear_counters(int32_t* __restrict__ tile_cursor, int T,
-                                                        int32_t* __restrict__ status,
-                                                        const int32_t* __restrict__ sticky) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+// element i of the clearing job (i = 0 .. max(TGS_XCC * T, 2) - 1); also run by other kernels' idle threads
+__device__ __forceinline__ void clear_counters_elem(int i, int32_t* __restrict__ tile_cursor, int T,
+                                                    int32_t* __restrict__ status, const int32_t* __restrict__ sticky) {
   if (i < TGS_XCC * T) tile_cursor[i] = 0;
   if (i < TGS_SCAN_WGS + 4) tile_cursor[2 * TGS_XCC * T + i] = 0;   // look-back flags of k_scan_tiles, longest list
   if (i < 4 * TGS_XCC) tile_cursor[TGS_ALLOC_OFF(T) + (i >> 2) * TGS_ALLOC_STRIDE + (i & 3)] = 0;   // pair allocator lines
   if (i == 0) status[0] = 0;
   if (i == 1) status[1] = sticky ? (*sticky != 0) : 0;
+}
+static __global__ __launch_bounds__(256) void k_clear_counters(int32_t* __restrict__ tile_cursor, int T,
+                                                        int32_t* __restrict__ status,
+                                                        const int32_t* __restrict__ sticky) {
+  clear_counters_elem(blockIdx.x * 256 + threadIdx.x, tile_cursor, T, status, sticky);
 }
 
 // pair i of the group -> (local Gaussian j, tile id)

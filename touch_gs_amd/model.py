@@ -223,7 +223,7 @@ class DepthGaussianSplattingModel:
 
     def forward_backward(self, view: View, want_v_xy: bool = False, fuse_adam: bool = False,
                          color_block: Optional[torch.Tensor] = None, begin_step: bool = True,
-                         colors=None, prefetch=None):
+                         colors=None, prefetch=None, next_front=None):
         """Forward + loss + backward of one view into ``params.grad`` (overwritten) -- or, with
         ``fuse_adam``, straight through the optimizer update (K8+K9 fused, ``params.grad`` untouched).
         No host sync unless ``budget.sync``.  Returns device tensors (l1+depth tile losses, ssim sum)."""
@@ -232,7 +232,7 @@ class DepthGaussianSplattingModel:
         H, W = cam.H, cam.W
         splats, radii, group_base, tile_start, sorted_gid, status = ops.project_bin_sort(
             cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, self.budget, want_radii=want_v_xy,
-            colors=colors)
+            colors=colors, next_front=next_front)
         guard = None if self.budget.sync else status   # overflowed frame => optimizer kernels are no-ops
         rgb, depth_acc, fT, fidx = ops.rasterize_fwd(cam, splats, sorted_gid, tile_start)
         v_img, ssim_sum = None, None
@@ -495,7 +495,8 @@ class DepthGaussianSplattingModel:
             front = ops.FrontBuffers(next_view.cam, N, self.budget.initial(N), density is not None, dev)
             arm = (bufs[1] if pre is bufs[0] else bufs[0]).arm(next_view.cam, deg, front, self.budget, colors_valid=False)
         self.forward_backward(view, want_v_xy=density is not None, fuse_adam=fuse, color_block=block,
-                              colors=colors, prefetch=arm if fuse else None)
+                              colors=colors, prefetch=arm if fuse else None,
+                              next_front=arm.front if arm is not None else None)
         self._prefetch_ready = arm
         if density is not None and not factored:
             # a frame that overflowed its intersection buffer (sync-free budget) rendered nothing and will be

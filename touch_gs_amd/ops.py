@@ -197,6 +197,9 @@ class ColorPrefetch:
         return self.cam is cam and self.N == N and self.sh_deg == sh_deg and self.tag > 0
 
 
+_SIDE_CLEAR = _os.environ.get("TGS_FRONT_SIDE_CLEAR", "1") != "0"   # A/B switch: next frame's counters cleared by the K1-check launch
+
+
 class FrontBuffers:
     """Everything the front half of ONE frame writes (what project_bin_sort allocates per call).  Allocated one
     step ahead when the previous step's fused optimizer kernel also runs this frame's K1 (front prefetch,
@@ -220,16 +223,18 @@ class FrontBuffers:
         self.tile_start.slot_ok = None     # quadrant bitmaps K6 leaves for K7 (rasterize_fwd allocates and fills them)
         self.sorted_gid = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
         self.scratch = torch.empty(lib.tgs_sort_scratch_bytes(cap), dtype=torch.uint8, device=dev)
+        self.cleared = False     # counters + status word already cleared (by the previous frame's K1-check launch)
 
 
 def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_deg: int,
                      budget: Optional[IntersectBudget] = None, want_radii: bool = False,
-                     colors: Optional[ColorPrefetch] = None):
+                     colors: Optional[ColorPrefetch] = None, next_front: Optional["FrontBuffers"] = None):
     """K1 fused with the tile counting, then scan / fill / sort: the front half of a frame in ONE C
     call -> (splats, radii or None, group_base, tile_start, sorted_gid, status).  (tgs_project_bin_sort;
     with ``colors`` -- a ColorPrefetch armed for THIS camera -- tgs_project_bin_sort_colors, or, if the previous
     step's optimizer kernel also ran this frame's K1 into ``colors.front``, tgs_project_bin_sort_front: scan, fill
-    and sort only)"""
+    and sort only.  ``next_front``: the FrontBuffers of the frame AFTER this one, if this step's optimizer kernel is
+    going to fill them -- the front path clears their counters on the side)"""
     lib = _lib.load()
     budget = budget or _default_budget
     N = means.shape[0]
@@ -256,12 +261,20 @@ def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_d
     sorted_gid, scratch = fb.sorted_gid, fb.scratch
     while True:
         if from_front:
+            nf = next_front if (_SIDE_CLEAR and next_front is not None and not next_front.cleared and next_front is not fb and
+                                lib.tgs_front_can_clear_next(N, next_front.cam.W, next_front.cam.H)) else None
+            ncs = nf.cam.c_struct() if nf is not None else None
             check(lib.tgs_project_bin_sort_front(C.byref(cs), N, ptr(means), ptr(log_scales), ptr(quats), ptr(opac_logit),
                                                  ptr(sh), sh_stride, sh_deg, ptr(splats), ptr(radii), ptr(group_base),
                                                  ptr(tile_start), ptr(tile_cursor), ptr(sorted_gid), ptr(tile_order),
                                                  cap, ptr(scratch), ptr(status), ptr(budget.sticky_word(dev)),
-                                                 ptr(tag_holder.tag_word), tag_holder.tag, _stream()),
+                                                 ptr(tag_holder.tag_word), tag_holder.tag,
+                                                 C.byref(ncs) if nf is not None else None,
+                                                 ptr(nf.tile_cursor) if nf is not None else None,
+                                                 ptr(nf.status) if nf is not None else None, _stream()),
                   "tgs_project_bin_sort_front")
+            if nf is not None:
+                nf.cleared = True
             from_front = False          # a regrown capacity (synchronous budget) goes through the regular K1
         elif colors is None or sh is None:
             check(lib.tgs_project_bin_sort(C.byref(cs), N, ptr(means), ptr(log_scales), ptr(quats), ptr(opac_logit),

@@ -165,7 +165,8 @@ class FusedAdam:
             C.byref(ncs), self.p.N, self.p.K, sh_deg, ptr(self.p.flat), ptr(self.p.grad), ptr(self.exp_avg),
             ptr(self.exp_avg_sq), C.byref(s), C.c_float(grad_scale), ptr(guard), ptr(prefetch.tag_word), prefetch.tag,
             ptr(fb.splats), ptr(fb.radii), ptr(fb.group_base), ptr(fb.tile_cursor), fb.cap, ptr(fb.scratch),
-            ptr(fb.status), ptr(budget.sticky_word(self.p.flat.device)), stream), "tgs_adam_geom_project_next")
+            ptr(fb.status), ptr(budget.sticky_word(self.p.flat.device)), int(fb.cleared), stream),
+              "tgs_adam_geom_project_next")
         prefetch.front_issued = True
 
     def step(self, grad_scale: float = 1.0, guard=None):
@@ -201,7 +202,7 @@ class FusedAdam:
                 C.byref(s), ptr(splats), ptr(group_base), ptr(partials), ptr(v_xy), ptr(guard), C.byref(ncs),
                 ptr(prefetch.colors), ptr(prefetch.tag_word), prefetch.tag, ptr(fb.splats), ptr(fb.radii),
                 ptr(fb.group_base), ptr(fb.tile_cursor), fb.cap, ptr(fb.scratch), ptr(fb.status),
-                ptr(budget.sticky_word(self.p.flat.device)), stream), "tgs_project_bwd_adam_next_front")
+                ptr(budget.sticky_word(self.p.flat.device)), int(fb.cleared), stream), "tgs_project_bwd_adam_next_front")
             prefetch.front_issued = True
         else:
             ncs = prefetch.cam.c_struct()
