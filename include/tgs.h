@@ -25,7 +25,9 @@
 extern "C" {
 #endif
 
-#define TGS_VERSION 100         /* 0.1.0 */
+#define TGS_VERSION 200         /* 0.2.0 -- ABI break against 100: tgs_rasterize_fwd / tgs_rasterize_bwd[_band]
+                                   gained stop_pos; earlier (round 3, then unversioned): status is int32[4], the
+                                   rasterize calls carry slot_ok, splat slots 0/1 are rect-relative */
 #define TGS_BLOCK 16            /* tile edge in pixels */
 #define TGS_SPLAT_FLOATS 12     /* floats per projected-splat record */
 #define TGS_PARTIAL_FLOATS 12   /* floats per (tile,Gaussian) partial-gradient record */
@@ -193,16 +195,27 @@ int tgs_project_bin_sort_colors(const TgsCamera* cam /*[host]*/, int N, const fl
 int tgs_rasterize_fwd(const TgsCamera* cam /*[host]*/, const float* splats,
                       const int32_t* sorted_gid, const int32_t* tile_start,
                       const int32_t* tile_order, float* out_rgb, float* out_depth, float* final_T,
-                      int32_t* final_idx, uint64_t* slot_ok /*may be NULL*/, void* stream);
+                      int32_t* final_idx /*may be NULL*/, int32_t* stop_pos /*may be NULL*/,
+                      uint64_t* slot_ok /*may be NULL*/, void* stream);
+/* stop_pos[H,W] (optional; REQUIRED by tgs_rasterize_bwd*): per pixel the list position (relative to the
+ * tile's first entry) of the Gaussian whose T' <= 1e-4 stopped the pixel (App. B.6) -- every earlier position
+ * with alpha >= 1/255 contributed, nothing else did -- or 0x7fffffff if the pixel never stopped.  The
+ * backward walks the lists back to front from there (since TGS_VERSION 200). */
 /* slot_ok[4 * tgs_slot_ok_len(W, H, capacity)] (optional): per batch of 64 list positions of a tile, four
  * 64-bit maps (one per 8x8 quadrant) of the Gaussians that changed the quadrant's state in the forward.
  * Handed to tgs_rasterize_bwd* (same splats and lists) the backward skips the other (Gaussian, quadrant)
  * evaluations; the results are bit-identical with and without it. */
 size_t tgs_slot_ok_len(int W, int H, int64_t capacity);
 
+/* Developer switch (A/B runs, tests): k6_blocks_on 1 / 0 = K6 in 4x4-block / quadrant form,
+ * k7_front_to_back 1 / 0 = K7 in the front-to-back form of TGS_VERSION 100 / back to front; -1 leaves a
+ * setting as it is.  Defaults: environment TGS_K6_BLOCKS (1), TGS_K7_F2B (0), read once at first use.
+ * Returns the settings in force: bit 0 = block-form K6, bit 1 = front-to-back K7. */
+int tgs_set_raster_variant(int k6_blocks_on, int k7_front_to_back);
+
 /* K7  compositing backward with the tactile depth/uncertainty loss fused in  (stands behind
  *     gsplat `rasterize_gaussians` bwd; spec App. B.7).
- * in : out_rgb, out_depth, final_T of the forward (required);
+ * in : out_rgb, out_depth, final_T, stop_pos of the forward (required);
  *      v_rgb[H,W,3] v_depth[H,W] v_alpha[H,W] upstream grads (each may be NULL);
  *      loss (may be NULL) adds dL/d(out) of the fused loss computed from out_rgb/out_depth/final_T;
  * out: partials[#intersections,12] one record per (tile,Gaussian) pair, addressed by the pair's
@@ -213,7 +226,7 @@ int tgs_rasterize_bwd(const TgsCamera* cam /*[host]*/, const float* splats,
                       const int32_t* group_base, const int32_t* sorted_gid,
                       const int32_t* tile_start, const int32_t* tile_order /*may be NULL*/,
                       const float* out_rgb, const float* out_depth, const float* final_T,
-                      const float* v_rgb, const float* v_depth, const float* v_alpha,
+                      const int32_t* stop_pos, const float* v_rgb, const float* v_depth, const float* v_alpha,
                       const TgsLossSpec* loss /*[host]*/, float* partials, float* tile_loss,
                       const uint64_t* slot_ok /*may be NULL*/, void* stream);
 
@@ -226,7 +239,7 @@ int tgs_rasterize_bwd_band(const TgsCamera* cam /*[host]*/, const float* splats,
                       const int32_t* group_base, const int32_t* sorted_gid,
                       const int32_t* tile_start, const int32_t* tile_order /*may be NULL*/,
                       const float* out_rgb, const float* out_depth, const float* final_T,
-                      const float* v_rgb, const float* v_depth, const float* v_alpha,
+                      const int32_t* stop_pos, const float* v_rgb, const float* v_depth, const float* v_alpha,
                       const TgsLossSpec* loss /*[host]*/, float* partials, float* tile_loss,
                       int band, const uint64_t* slot_ok /*may be NULL*/, void* stream);
 

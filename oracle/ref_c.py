@@ -107,6 +107,19 @@ class RefC:
                                              C.c_int(W), C.c_int(H), self._p(out), self._p(cnt))
         return out, int(cnt[0])
 
+    def gaussian_min_margin(self, xy, conic, opac, rect, tiles_hit, cam, W, H, pix_margin, near=0.5):
+        """-> (min of pix_margin over the pixels each Gaussian (nearly) contributes to [N] float64, their number [N])."""
+        xy, conic, opac = map(self._r, (xy, conic, opac))
+        rect = np.ascontiguousarray(rect, np.int32)
+        tiles_hit = np.ascontiguousarray(tiles_hit, np.int32)
+        pm = np.ascontiguousarray(pix_margin, np.float64)
+        out = np.zeros(xy.shape[0], np.float64)
+        npix = np.zeros(xy.shape[0], np.int64)
+        self.lib.ref_gaussian_min_margin(C.c_int(xy.shape[0]), self._p(xy), self._p(conic), self._p(opac),
+                                         self._p(rect), self._p(tiles_hit), self._p(cam), C.c_int(W), C.c_int(H),
+                                         self._p(pm), C.c_double(near), self._p(out), self._p(npix))
+        return out, npix
+
     def blend_bwd(self, xy, conic, opac, rgb, depth, gid, ts, cam, W, H, final_T, final_idx,
                   v_rgb_img, v_depth_img, v_alpha_img, tile_range=None):
         xy, conic, opac, rgb, depth, final_T, v_rgb_img, v_depth_img, v_alpha_img = map(

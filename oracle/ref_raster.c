@@ -320,6 +320,35 @@ void ref_dropped_pairs_max_alpha(int N, const real *xy, const real *conic, const
     *o_count = count;
 }
 
+/* Test aid for gradient parity at full size: classifies GAUSSIANS by the decision margins of the pixels
+ * they (nearly) contribute to.  pix_margin [H,W] is the per-pixel map of ref_blend_margin_range (the caller
+ * zeroes it in tiles whose fp32 depth order differs from the fp64 order).  For every Gaussian the minimum of
+ * pix_margin over the pixel centres of its NORMATIVE B.4 rect where o*exp(-sigma) >= near * 1/255 (near < 1:
+ * contributing, or close enough to the threshold to contribute under fp32 rounding) -- 1e30 if there is no
+ * such pixel.  A flipped alpha_min / T_stop decision at a pixel changes the transmittance every later
+ * Gaussian of that pixel sees, so a Gaussian's gradient is only comparable at 1e-4 if ALL the pixels it
+ * reaches are decision-clear; occlusion (T_stop) is ignored, which can only classify too many as unclear. */
+void ref_gaussian_min_margin(int N, const real *xy, const real *conic, const real *opac,
+                   const int32_t *rect, const int32_t *tiles_hit, const cam_t *cam, int W, int H,
+                   const double *pix_margin, double near, double *o_min, int64_t *o_npix) {
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int i = 0; i < N; i++) {
+        double best = 1e30; int64_t np_ = 0;
+        if (tiles_hit[i])
+            for (int py = rect[4 * i + 1] * BLK; py < rect[4 * i + 3] * BLK && py < H; py++)
+                for (int px = rect[4 * i] * BLK; px < rect[4 * i + 2] * BLK && px < W; px++) {
+                    real dx = xy[2 * i] - (px + cam->pc), dy = xy[2 * i + 1] - (py + cam->pc);
+                    real sig = (real)0.5 * (conic[3 * i] * dx * dx + conic[3 * i + 2] * dy * dy) + conic[3 * i + 1] * dx * dy;
+                    if (sig < 0) continue;
+                    if ((double)(opac[i] * exp(-sig)) < near * (double)ALPHA_MIN) continue;
+                    double m = pix_margin[(size_t)py * W + px];
+                    if (m < best) best = m;
+                    np_++;
+                }
+        o_min[i] = best; o_npix[i] = np_;
+    }
+}
+
 /* B.7 backward blend.  v_rgb_img [H,W,3], v_depth_img [H,W] (w.r.t. depth_acc), v_alpha_img [H,W].
  * Accumulates (+=) into v_xy [N,2], v_conic [N,3], v_opac [N], v_rgb [N,3], v_depth [N] (caller zeroes). */
 void ref_blend_bwd_range(const real *xy, const real *conic, const real *opac, const real *rgb, const real *depth,

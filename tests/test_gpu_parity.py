@@ -267,14 +267,19 @@ def test_slot_ok_bitmaps_do_not_change_the_backward(dev, monkeypatch):
     v = [torch.randn(208, 320, 3, generator=g).to(dev), torch.randn(208, 320, generator=g).to(dev),
          torch.randn(208, 320, generator=g).to(dev)]
     res = []
-    for on in (False, True):
-        monkeypatch.setattr(ops, "SLOT_OK", on)
-        sp, _, gb, ts, sg, st = ops.project_bin_sort(acam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], 3)
-        rgb, depth, fT, _ = ops.rasterize_fwd(acam, sp, sg, ts)
-        assert (ts.slot_ok is not None) == on
-        partials, _ = ops.rasterize_bwd(acam, sp, gb, sg, ts, rgb, depth, fT, *v)
-        grads = ops.project_bwd(acam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], 3, sp, gb, partials)
-        res.append([rgb, depth, fT] + list(grads[:5]))
+    was = ops.set_raster_variant()
+    ops.set_raster_variant(k7_front_to_back=True)     # the bitmaps belong to the front-to-back form of K7
+    try:
+        for on in (False, True):
+            monkeypatch.setattr(ops, "SLOT_OK", on)
+            sp, _, gb, ts, sg, st = ops.project_bin_sort(acam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], 3)
+            rgb, depth, fT, _ = ops.rasterize_fwd(acam, sp, sg, ts)
+            assert (ts.slot_ok is not None) == on
+            partials, _ = ops.rasterize_bwd(acam, sp, gb, sg, ts, rgb, depth, fT, *v)
+            grads = ops.project_bwd(acam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], 3, sp, gb, partials)
+            res.append([rgb, depth, fT] + list(grads[:5]))
+    finally:
+        ops.set_raster_variant(k7_front_to_back=bool(was & 2))
     for a, b in zip(*res):
         assert torch.equal(a, b)
     if res:   # some quadrant evaluations were really skipped
@@ -293,11 +298,20 @@ def test_k6_block_form_is_bit_identical(dev, monkeypatch, N, W, H, seed, clamp):
     D = to_dev(P, dev)
     sp, _, gb, ts, sg, st = ops.project_bin_sort(acam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], 3)
     res = []
-    for on in ("0", "1"):
-        monkeypatch.setenv("TGS_K6_BLOCKS", on)
-        res.append(ops.rasterize_fwd(acam, sp, sg, ts, want_idx=True))
+    was = ops.set_raster_variant()
+    try:
+        for on in (False, True):
+            assert ops.set_raster_variant(k6_blocks=on) & 1 == int(on)
+            out = ops.rasterize_fwd(acam, sp, sg, ts, want_idx=True)
+            res.append(list(out) + [out[2].stop_pos])      # + the per-pixel stop positions the backward starts from
+    finally:
+        ops.set_raster_variant(k6_blocks=bool(was & 1))
     for a, b in zip(*res):
         assert torch.equal(a, b), (a.float() - b.float()).abs().max().item()
+    # stop position and last contributor are consistent: a pixel that stopped did so behind its last contributor
+    fidx, stop = res[0][3], res[0][4]
+    stopped = stop != 0x7fffffff
+    assert bool((stop[stopped] > fidx[stopped]).all()) and bool(stopped.any())
 
 
 def test_deterministic_bitwise(dev):

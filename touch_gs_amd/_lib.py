@@ -56,10 +56,11 @@ SIGNATURES = {
                                        _P, C.c_int64, _P, _P, _P, _P]),
     "tgs_project_bin_sort_colors": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P,
                                               _P, _P, C.c_int64, _P, _P, _P, _P, _P, C.c_int32, _P]),
-    "tgs_rasterize_fwd": (C.c_int, [C.POINTER(TgsCamera), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "tgs_rasterize_fwd": (C.c_int, [C.POINTER(TgsCamera), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "tgs_set_raster_variant": (C.c_int, [_I, _I]),
     "tgs_slot_ok_len": (C.c_size_t, [_I, _I, C.c_int64]),
-    "tgs_rasterize_bwd": (C.c_int, [C.POINTER(TgsCamera)] + [_P] * 11 + [C.POINTER(TgsLossSpec), _P, _P, _P, _P]),
-    "tgs_rasterize_bwd_band": (C.c_int, [C.POINTER(TgsCamera)] + [_P] * 11 + [C.POINTER(TgsLossSpec), _P, _P, _I, _P, _P]),
+    "tgs_rasterize_bwd": (C.c_int, [C.POINTER(TgsCamera)] + [_P] * 12 + [C.POINTER(TgsLossSpec), _P, _P, _P, _P]),
+    "tgs_rasterize_bwd_band": (C.c_int, [C.POINTER(TgsCamera)] + [_P] * 12 + [C.POINTER(TgsLossSpec), _P, _P, _I, _P, _P]),
     "tgs_reduce_partials": (C.c_int, [_I, _P, _P, C.POINTER(TgsCamera), _P, _P, _P]),
     "tgs_project_bwd": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I] + [_P] * 12),
     "tgs_project_bwd_adam": (C.c_int, [C.POINTER(TgsCamera), _I, _I, _I, _P, _P, _P, C.POINTER(TgsAdamSpec), _P, _P, _P, _P, _P, _P]),

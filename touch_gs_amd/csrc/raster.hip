@@ -177,6 +177,15 @@ __device__ __forceinline__ size_t slot_ok_index(int batch_pos, int tile) {
   return (size_t)(batch_pos >> 6) + (size_t)tile;
 }
 
+// smax of a stopped pixel: 0xC0000000 | list position (relative to the tile's first entry, < 2^30).  As a
+// float that is <= -2 or NaN -- dead either way (`s <= smax` and `smax > 0` are false).  A pixel that never
+// stopped keeps smax = log2(255) > 0 and reports TGS_NO_STOP.
+#define TGS_NO_STOP 0x7fffffff
+__device__ __forceinline__ float stop_code(int pos) { return __uint_as_float(0xC0000000u | (unsigned)pos); }
+__device__ __forceinline__ int stop_of(float smax) {
+  return smax > 0.f ? TGS_NO_STOP : (int)(__float_as_uint(smax) & 0x3fffffffu);
+}
+
 // ---------------------------------------------------------------------------------------------
 // K6 forward
 // ---------------------------------------------------------------------------------------------
@@ -192,9 +201,13 @@ __device__ __forceinline__ size_t slot_ok_index(int batch_pos, int tile) {
 //          sits next to the compare so that it IS the compare's scalar result (no extra VALU)
 //   okb  : WANT_OK = 1: lane mask of `ok`; WANT_OK = 2: lane mask of `go` (both ballots sit next to their
 //          compares, so they ARE the compares' scalar results: no extra VALU)
+//   stopv: what smax becomes when THIS Gaussian stops the pixel -- stop_code(list position): a negative
+//          float (so the pixel is dead for every later `s <= smax`, s >= 0 up to rounding) whose low 30
+//          bits are the list position; the forward stores it per pixel (stop_pos) and the backward, which
+//          walks the list back to front, starts each pixel there.  One v_cndmask, as with a literal.
 template <bool MAYCLAMP = true, int WANT_OK = 0>
 __device__ __forceinline__ float blend_step(float s, float& T, float& smax, float& Tnew, bool& go,
-                                            unsigned long long& okb) {
+                                            unsigned long long& okb, float stopv = -3.0e38f) {
   const float e = __builtin_amdgcn_exp2f(-s);
   const float al = MAYCLAMP ? fminf(ALPHA_MAX, e) : e;
   const bool ok = s <= smax;
@@ -203,7 +216,7 @@ __device__ __forceinline__ float blend_step(float s, float& T, float& smax, floa
   const bool above = Tnew > T_STOP;
   if constexpr (WANT_OK == 2) okb = __builtin_amdgcn_ballot_w64(ok) & __builtin_amdgcn_ballot_w64(above);
   go = ok & above;
-  smax = (ok != go) ? -3.0e38f : smax;  // stop (ok and not go; go implies ok): T' <= 1e-4, this Gaussian excluded
+  smax = (ok != go) ? stopv : smax;  // stop (ok and not go; go implies ok): T' <= 1e-4, this Gaussian excluded
   return go ? al : 0.f;
 }
 
@@ -212,7 +225,8 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
     CamK cam, int T_total, const float* __restrict__ splats, const int32_t* __restrict__ sorted_gid,
     const int32_t* __restrict__ tile_start, float* __restrict__ out_rgb,
     float* __restrict__ out_depth, float* __restrict__ final_T, int32_t* __restrict__ final_idx,
-    const int32_t* __restrict__ tile_order, unsigned long long* __restrict__ slot_ok) {
+    const int32_t* __restrict__ tile_order, unsigned long long* __restrict__ slot_ok,
+    int32_t* __restrict__ stop_pos) {
   const int tile = tile_order ? tile_order[blockIdx.x] : xcd_tile(blockIdx.x, T_total);
   if (tile >= T_total) return;
   const int lane = threadIdx.x;
@@ -249,7 +263,8 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
       const float4 q0 = ld4(r), q1 = ld4(r + 4), q2 = ld4(r + 8);
       float gx, gy;
       centre_rel(q0, q2, tx, ty, cam.pix_center, gx, gy);
-      const TileRec t = make_tile_rec(q0, q1, q2, gx, gy);
+      TileRec t = make_tile_rec(q0, q1, q2, gx, gy);
+      t.c.z = stop_code(base - start + lane);
       recs[lane * 3] = t.a; recs[lane * 3 + 1] = t.b; recs[lane * 3 + 2] = t.c;
       my_mask = __float_as_uint(t.c.w);
     }
@@ -280,7 +295,7 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
           const float s = eval_s(qa, qb, pc, k);
           float Tn; bool go;
           unsigned long long okb = 0ull;
-          const float al = blend_step<true, WANT_OK ? 1 : 0>(s, T[k], smax[k], Tn, go, okb);
+          const float al = blend_step<true, WANT_OK ? 1 : 0>(s, T[k], smax[k], Tn, go, okb, qc.z);
           const float w = al * T[k];
           Cr[k] = fmaf(w, qb.w, Cr[k]); Cg[k] = fmaf(w, qc.x, Cg[k]);
           Cb[k] = fmaf(w, qc.y, Cb[k]); D[k] = fmaf(w, qb.z, D[k]);
@@ -305,6 +320,7 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
       out_depth[p] = D[k];
       final_T[p] = T[k];
       if (WANT_IDX) final_idx[p] = last[k];
+      if (stop_pos) stop_pos[p] = stop_of(smax[k]);
     }
   }
 }
@@ -379,7 +395,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TGS_BLK_WAVE
     CamK cam, int T_total, const float* __restrict__ splats, const int32_t* __restrict__ sorted_gid,
     const int32_t* __restrict__ tile_start, float* __restrict__ out_rgb,
     float* __restrict__ out_depth, float* __restrict__ final_T, int32_t* __restrict__ final_idx,
-    const int32_t* __restrict__ tile_order) {
+    const int32_t* __restrict__ tile_order, int32_t* __restrict__ stop_pos) {
   const int tile = tile_order ? tile_order[blockIdx.x] : xcd_tile(blockIdx.x, T_total);
   if (tile >= T_total) return;
   const int lane = threadIdx.x;
@@ -445,7 +461,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TGS_BLK_WAVE
       const float4 q0 = ld4(r), q1 = ld4(r + 4), q2 = ld4(r + 8);
       float gx, gy;
       centre_rel(q0, q2, tx, ty, cam.pix_center, gx, gy);
-      const TileRec t = make_tile_rec<false>(q0, q1, q2, gx, gy);
+      TileRec t = make_tile_rec<false>(q0, q1, q2, gx, gy);
+      t.c.z = stop_code(base - start + lane);
       recs[lane * 3] = t.a; recs[lane * 3 + 1] = t.b; recs[lane * 3 + 2] = t.c;
       my_mask = block_mask16(gx, gy, q1.x, q1.y, q1.z, -__log2f(q0.w)) & live16;
       my_opac = q0.w;
@@ -478,7 +495,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TGS_BLK_WAVE
             const float s = eval_s(qa, qb, pc, k);
             float Tn; bool go;
             unsigned long long okb = 0ull;
-            const float al = blend_step<MAYCLAMP, 0>(s, T[k], smax[k], Tn, go, okb);
+            const float al = blend_step<MAYCLAMP, 0>(s, T[k], smax[k], Tn, go, okb, qc.z);
             const float w = al * T[k];
             Cr[k] = fmaf(w, qb.w, Cr[k]); Cg[k] = fmaf(w, qc.x, Cg[k]);
             Cb[k] = fmaf(w, qc.y, Cb[k]); D[k] = fmaf(w, qb.z, D[k]);
@@ -502,6 +519,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TGS_BLK_WAVE
       out_depth[p] = D[k];
       final_T[p] = T[k];
       if (WANT_IDX) final_idx[p] = last[k];
+      if (stop_pos) stop_pos[p] = stop_of(smax[k]);
     }
   }
 }
@@ -517,7 +535,7 @@ __device__ __forceinline__ size_t pair_index(const int32_t* __restrict__ group_b
          (size_t)((ty - y0) * w + (tx - x0));
 }
 
-__global__ __launch_bounds__(64) void k_raster_bwd(
+__global__ __launch_bounds__(64) void k_raster_bwd_f2b(
     CamK cam, int T_total, const float* __restrict__ splats, const int32_t* __restrict__ group_base,
     const int32_t* __restrict__ sorted_gid, const int32_t* __restrict__ tile_start,
     const float* __restrict__ out_rgb, const float* __restrict__ out_depth,
@@ -783,12 +801,285 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// K7 backward, back to front (round 4; the default)
+// ---------------------------------------------------------------------------------------------
+// k_raster_bwd_f2b above walks the list front to back and obtains the colour BEHIND a Gaussian as
+// (final colour - prefix).  That difference carries an ABSOLUTE error of one ulp of the pixel's colour
+// (~1e-7) whatever is left behind, while the quantity it feeds -- dL/dalpha of a Gaussian at transmittance
+// T -- is itself O(T): the relative error of the geometry / opacity gradients of an occluded Gaussian is
+// ~1e-7 / T, 2e-4 in the median at cfg3 (lists of ~400, most Gaussians sit behind T ~ 1e-3) against 1e-5 for
+// the back-to-front order every CUDA rasterizer uses (tools/grad_err_k7.py, profiles/r4_grad_err_*.txt).
+// This kernel walks back to front:
+//   * the forward leaves, per pixel, the list position of the Gaussian that stopped it (stop_pos; free: the
+//     position rides in the bits of the dead pixel's smax) -- positions below it with alpha >= 1/255
+//     contributed, nothing else did.  The alpha test is the forward's own compare on the same bits
+//     (eval_s on the same record), so the decisions are the forward's by construction; the T' <= 1e-4 test
+//     is not re-evaluated at all.
+//   * T before a Gaussian = T after it * rcp(1 - alpha) (relative error ~1 ulp per step); the sum behind it,
+//     SX = sum_{j behind} w_j c_j.v - T_final (v_A - bg.v_C), accumulates small terms first.
+//     dL/dalpha = T c.v - SX / (1 - alpha).
+//   * per slot: 28 VALU against ~30 (no T_stop compare, no smax select; one more v_cmp for the position).
+//   * everything else -- staging, quadrant masks, the weighted transposed LDS reduction, the partial record
+//     -- is k_raster_bwd_f2b's.  Batches behind the last pixel's stop position are never staged; their
+//     partial records are zero-filled up front.
+__global__ __launch_bounds__(64) void k_raster_bwd(
+    CamK cam, int T_total, const float* __restrict__ splats, const int32_t* __restrict__ group_base,
+    const int32_t* __restrict__ sorted_gid, const int32_t* __restrict__ tile_start,
+    const float* __restrict__ out_rgb, const float* __restrict__ out_depth,
+    const float* __restrict__ final_T, const int32_t* __restrict__ stop_pos, const float* __restrict__ v_rgb,
+    const float* __restrict__ v_depth, const float* __restrict__ v_alpha, LossK loss,
+    float* __restrict__ partials, float* __restrict__ tile_loss,
+    const int32_t* __restrict__ tile_order) {
+  const int tile = tile_order ? tile_order[blockIdx.x] : xcd_tile(blockIdx.x, T_total);
+  if (tile >= T_total) return;
+  const int lane = threadIdx.x;
+  const int ty = tile / cam.TW, tx = tile - ty * cam.TW;
+  const PixConst pc = make_pix_const(lane);
+  const int start = tile_start[tile], end = tile_start[tile + 1];
+  const int n = end - start;
+
+  // per-pixel state: T (after the Gaussians walked so far, i.e. behind the current one), SX, and lim = number
+  // of leading list positions that may contribute
+  float T[4] = {1.f, 1.f, 1.f, 1.f};
+  float vCr[4], vCg[4], vCb[4], vD[4], SX[4];
+  int lim[4];
+  float l_l1 = 0.f, l_dep = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int px = tx * TGS_BLOCK + 8 * (k & 1) + (lane & 7);
+    const int py = ty * TGS_BLOCK + 8 * (k >> 1) + (lane >> 3);
+    lim[k] = 0; vCr[k] = vCg[k] = vCb[k] = vD[k] = SX[k] = 0.f;
+    if (px < cam.W && py < cam.H) {
+      const size_t p = (size_t)py * cam.W + px;
+      const float Tf = final_T[p];
+      T[k] = Tf;
+      lim[k] = min(stop_pos[p], n);
+      float vA = v_alpha ? v_alpha[p] : 0.f;
+      if (v_rgb) { vCr[k] = v_rgb[3 * p]; vCg[k] = v_rgb[3 * p + 1]; vCb[k] = v_rgb[3 * p + 2]; }
+      if (v_depth) vD[k] = v_depth[p];
+      if (loss.on) {
+        if (loss.gt_rgb) {
+          const float d0 = out_rgb[3 * p] - loss.gt_rgb[3 * p];
+          const float d1 = out_rgb[3 * p + 1] - loss.gt_rgb[3 * p + 1];
+          const float d2 = out_rgb[3 * p + 2] - loss.gt_rgb[3 * p + 2];
+          vCr[k] += loss.l1w * ((d0 > 0.f) - (d0 < 0.f));
+          vCg[k] += loss.l1w * ((d1 > 0.f) - (d1 < 0.f));
+          vCb[k] += loss.l1w * ((d2 > 0.f) - (d2 < 0.f));
+          l_l1 += loss.l1w * (fabsf(d0) + fabsf(d1) + fabsf(d2));
+        }
+        if (loss.gt_depth) {
+          const float gd = loss.gt_depth[p];
+          if (gd > 0.f) {
+            const float alpha = fmaxf(1.f - Tf, 1e-10f);
+            const float ia = 1.0f / alpha;
+            const float dhat = out_depth[p] * ia;
+            const float r = dhat - gd;
+            float wgt = loss.dw;
+            if (loss.unc) wgt = wgt / (loss.uw * loss.unc[p] + loss.eps);
+            l_dep += wgt * r * r;
+            const float gdh = 2.f * wgt * r;
+            vD[k] += gdh * ia;
+            // alpha is clamped from below: the clamp gates its gradient
+            if (1.f - Tf > 1e-10f) vA += -gdh * dhat * ia;
+          }
+        }
+      }
+      const float bgdot = cam.bg[0] * vCr[k] + cam.bg[1] * vCg[k] + cam.bg[2] * vCb[k];
+      SX[k] = -Tf * (vA - bgdot);
+    }
+  }
+  if (tile_loss) {
+    const float a = wave_sum(l_l1), b = wave_sum(l_dep);
+    if (lane == 0) { tile_loss[2 * tile] = a; tile_loss[2 * tile + 1] = b; }
+  }
+  if (n == 0) return;
+  // per quadrant / per tile: how far into the list any pixel reaches (wave-uniform)
+  int qlim[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) qlim[k] = wave_minmax_i<true>(lim[k]);
+  const int tmax = max(max(qlim[0], qlim[1]), max(qlim[2], qlim[3]));
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // behind the last stop position nothing received a gradient
+  for (int i = start + tmax + lane; i < end; i += 64) {
+    const int gid = sorted_gid[i];
+    const size_t P = pair_index(group_base, gid, ld4(splats + (size_t)gid * TGS_SPLAT_FLOATS + 8), tx, ty);
+    float* o = partials + P * TGS_PARTIAL_FLOATS;
+    st4(o, z4); st4(o + 4, z4); st4(o + 8, z4);
+  }
+  if (tmax == 0) return;
+
+  __shared__ float4 recs[64 * 3];
+  __shared__ float4 sums[64 * 4];  // [Gaussian j][16 slots], slot c < 14 = total of term c (table in k_raster_bwd_f2b)
+  constexpr int RED_RS = 68;
+  constexpr int RED_ROWS = 8;
+  __shared__ float4 red4[RED_ROWS * RED_RS / 4];
+  float* red = reinterpret_cast<float*>(red4);
+  const int red_c = lane & 15;
+  const int red_part = (lane >> 4) ^ ((red_c >= 4 && red_c < 12) ? 1 : 0);
+  float wt[16];
+  const float* red_rd;
+  {
+    const unsigned long long ROWS = 0x0076454645443210ull;
+    red_rd = red + (int)((ROWS >> (4 * red_c)) & 15ull) * RED_RS + red_part * 16;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const float u0 = (float)(i & 7) - 7.5f;
+      const float v0 = (float)(2 * red_part + (i >> 3)) - 7.5f;
+      float w = 1.f;                                   // c 0..4, 13
+      w = (red_c == 5) ? u0 : w;
+      w = (red_c == 7) ? v0 : w;
+      w = (red_c == 6 || red_c == 8) ? 8.f : w;
+      w = (red_c == 9) ? u0 * u0 : w;
+      w = (red_c == 11) ? v0 * v0 : w;
+      w = (red_c == 10) ? 16.f * u0 + 64.f : w;
+      w = (red_c == 12) ? 16.f * v0 + 64.f : w;
+      w = (red_c >= 14) ? 0.f : w;
+      wt[i] = w;
+    }
+  }
+  for (int base = start + ((tmax - 1) & ~63); base >= start; base -= 64) {
+    const int rel = base - start;
+    const int cnt = min(64, tmax - rel);
+    size_t P = 0;
+    float4 a0 = z4, a1 = z4;
+    unsigned my_mask = 0u;
+    __syncthreads();
+    if (lane < cnt) {
+      const int gid = sorted_gid[base + lane];
+      const float* r = splats + (size_t)gid * TGS_SPLAT_FLOATS;
+      a0 = ld4(r); a1 = ld4(r + 4);
+      const float4 a2 = ld4(r + 8);
+      float gx, gy;
+      centre_rel(a0, a2, tx, ty, cam.pix_center, gx, gy);
+      a0.x = gx; a0.y = gy;                       // kept for the conversion of the moments below
+      const TileRec t = make_tile_rec(a0, a1, a2, gx, gy);
+      recs[lane * 3] = t.a; recs[lane * 3 + 1] = t.b; recs[lane * 3 + 2] = t.c;
+      my_mask = __float_as_uint(t.c.w);
+      P = pair_index(group_base, gid, a2, tx, ty);
+    }
+    sums[lane * 4] = z4; sums[lane * 4 + 1] = z4; sums[lane * 4 + 2] = z4; sums[lane * 4 + 3] = z4;
+    __syncthreads();
+
+    // quadrant k only needs the batch entries below its own furthest stop position
+    unsigned long long qm[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int r = qlim[k] - rel;
+      const unsigned long long keep = r >= 64 ? ~0ull : (r <= 0 ? 0ull : ((1ull << r) - 1ull));
+      qm[k] = __ballot((my_mask >> k) & 1u) & keep;
+    }
+    auto walk = [&](auto mayclamp) {
+    constexpr bool MAYCLAMP = decltype(mayclamp)::value;
+    unsigned long long rem = qm[0] | qm[1] | qm[2] | qm[3];
+    while (rem) {
+      const int j = 63 - __builtin_clzll(rem);
+      rem &= ~(1ull << j);
+      const unsigned m = (unsigned)((qm[0] >> j) & 1ull) | ((unsigned)((qm[1] >> j) & 1ull) << 1) |
+                         ((unsigned)((qm[2] >> j) & 1ull) << 2) | ((unsigned)((qm[3] >> j) & 1ull) << 3);
+      const float4 qa = recs[j * 3], qb = recs[j * 3 + 1], qc = recs[j * 3 + 2];
+      const int pos = rel + j;
+      // acc: 0..2 v_rgb, 3 v_depth, 4 S = sum q, 5 Sx, 6 Sy, 7 Quv   (rows of the reduction scratch)
+      float acc[RED_ROWS];
+#pragma unroll
+      for (int c = 0; c < RED_ROWS; c++) acc[c] = 0.f;
+      unsigned long long any = 0ull;   // lanes with a contributing pixel, kept as a scalar mask (see k_raster_bwd_f2b)
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (m & (1u << k)) {  // wave-uniform
+          const float s = eval_s(qa, qb, pc, k);
+          const float e = __builtin_amdgcn_exp2f(-s);
+          const float al0 = MAYCLAMP ? fminf(ALPHA_MAX, e) : e;
+          // the forward's alpha test (same bits) below the pixel's stop position: exactly the contributions
+          const bool ok = s <= LOG2_255, in = pos < lim[k];
+          const bool go = ok & in;
+          // each ballot sits next to its compare, so it IS the compare's scalar result (a ballot of `go` costs
+          // a v_cndmask + v_cmp per slot)
+          const unsigned long long gob = __builtin_amdgcn_ballot_w64(ok) & __builtin_amdgcn_ballot_w64(in);
+          const float al = go ? al0 : 0.f;
+          const float ra = __builtin_amdgcn_rcpf(1.0f - al);    // = 1 exactly when al == 0
+          const float Tp = T[k] * ra;                           // transmittance in front of this Gaussian
+          const float w = al * Tp;
+          acc[0] = fmaf(w, vCr[k], acc[0]); acc[1] = fmaf(w, vCg[k], acc[1]);
+          acc[2] = fmaf(w, vCb[k], acc[2]); acc[3] = fmaf(w, vD[k], acc[3]);
+          float cv = qb.w * vCr[k];
+          cv = fmaf(qc.x, vCg[k], cv); cv = fmaf(qc.y, vCb[k], cv); cv = fmaf(qb.z, vD[k], cv);
+          // q = opacity e^-sigma dL/dalpha = alpha (T c.v - SX / (1 - alpha))   (B.7); = 0 when al == 0.
+          // Under the 0.999 clamp (opacity > 0.999 and sigma ~ 0) q is rescaled by e^-s / 0.999 (pass-through).
+          const float z = w * cv;
+          float q = fmaf(-(al * ra), SX[k], z);
+          if constexpr (MAYCLAMP) q *= fmaxf(e * (1.0f / ALPHA_MAX), 1.0f);
+          SX[k] += z;
+          T[k] = Tp;
+          acc[4] += q;
+          if (k & 1) acc[5] += q;
+          if (k >> 1) acc[6] += q;
+          acc[7] = fmaf(q, pc.uv[k], acc[7]);
+          any |= gob;
+        }
+      }
+      if (any != 0ull) {
+#pragma unroll
+        for (int c = 0; c < RED_ROWS; c++) red[c * RED_RS + lane] = acc[c];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float4 r0 = ld4(red_rd), r1 = ld4(red_rd + 4), r2 = ld4(red_rd + 8), r3 = ld4(red_rd + 12);
+        float o0 = r0.x * wt[0], o1 = r1.x * wt[4], o2 = r2.x * wt[8], o3 = r3.x * wt[12];
+        o0 = fmaf(r0.y, wt[1], o0); o1 = fmaf(r1.y, wt[5], o1); o2 = fmaf(r2.y, wt[9], o2); o3 = fmaf(r3.y, wt[13], o3);
+        o0 = fmaf(r0.z, wt[2], o0); o1 = fmaf(r1.z, wt[6], o1); o2 = fmaf(r2.z, wt[10], o2); o3 = fmaf(r3.z, wt[14], o3);
+        o0 = fmaf(r0.w, wt[3], o0); o1 = fmaf(r1.w, wt[7], o1); o2 = fmaf(r2.w, wt[11], o2); o3 = fmaf(r3.w, wt[15], o3);
+        float O = (o0 + o1) + (o2 + o3);
+        O = fold_xor16(O);
+        O = fold_xor32(O);
+        if (lane < 16) reinterpret_cast<float*>(sums)[j * 16 + lane] = O;
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    };
+    if (__ballot(lane < cnt && a0.w > CLAMP_FREE_OPACITY) != 0ull) walk(std::true_type{});
+    else walk(std::false_type{});
+    __syncthreads();
+    if (lane < cnt) {
+      const float4 s0 = sums[lane * 4], s1 = sums[lane * 4 + 1], s2 = sums[lane * 4 + 2], s3 = sums[lane * 4 + 3];
+      const float gx = a0.x, gy = a0.y;           // centre relative to the tile centre (set while staging)
+      const float A = a1.x, B = a1.y, Cc = a1.z;
+      const float Q0 = s1.x, Qu = s1.y + s1.z, Qv = s1.w + s2.x, Quu = s2.y + s2.z, Qvv = s2.w + s3.x, Quv = s3.y;
+      const float Mx = -(gx * Q0 - Qu), My = -(gy * Q0 - Qv);
+      const float Mxx = -(gx * gx * Q0 - 2.f * gx * Qu + Quu);
+      const float Mxy = -(gx * gy * Q0 - gx * Qv - gy * Qu + Quv);
+      const float Myy = -(gy * gy * Q0 - 2.f * gy * Qv + Qvv);
+      float* o = partials + P * TGS_PARTIAL_FLOATS;
+      st4(o, make_float4(A * Mx + B * My, B * Mx + Cc * My, s0.w, Q0 / a0.w));
+      st4(o + 4, make_float4(0.5f * Mxx, Mxy, 0.5f * Myy, s0.x));
+      st4(o + 8, make_float4(s0.y, s0.z, 0.f, 0.f));
+    }
+  }
+}
+
 }  // namespace
+
+// Run-time switches, read from the environment ONCE (first use) and settable through the C ABI afterwards
+// (tgs_rasterize_fwd used to call getenv on every launch).
+static int g_k6_blocks = -1, g_k7_f2b = -1;
+static int env_flag(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+static int k6_blocks() { if (g_k6_blocks < 0) g_k6_blocks = env_flag("TGS_K6_BLOCKS", 1) != 0; return g_k6_blocks; }
+static int k7_f2b() { if (g_k7_f2b < 0) g_k7_f2b = env_flag("TGS_K7_F2B", 0) != 0; return g_k7_f2b; }
+extern "C" int tgs_set_raster_variant(int k6_blocks_on, int k7_front_to_back) {
+  if (k6_blocks_on >= 0) g_k6_blocks = k6_blocks_on != 0;
+  if (k7_front_to_back >= 0) g_k7_f2b = k7_front_to_back != 0;
+  return (k6_blocks() ? 1 : 0) | (k7_f2b() ? 2 : 0);
+}
 
 extern "C" int tgs_rasterize_fwd(const TgsCamera* cam, const float* splats,
                                  const int32_t* sorted_gid, const int32_t* tile_start,
                                  const int32_t* tile_order, float* out_rgb, float* out_depth,
-                                 float* final_T, int32_t* final_idx, uint64_t* slot_ok, void* stream) {
+                                 float* final_T, int32_t* final_idx, int32_t* stop_pos, uint64_t* slot_ok,
+                                 void* stream) {
   TGS_CHECK_ARG(camera_ok(cam), "bad camera");
   TGS_CHECK_ARG(splats && sorted_gid && tile_start && out_rgb && out_depth && final_T,
                 "null pointer");
@@ -798,18 +1089,16 @@ extern "C" int tgs_rasterize_fwd(const TgsCamera* cam, const float* splats,
 #define TGS_LAUNCH_FWD(IDX, OK)                                                                          \
   hipLaunchKernelGGL((k_raster_fwd<IDX, OK>), dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T, splats, \
                      sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx, tile_order,          \
-                     (unsigned long long*)slot_ok)
+                     (unsigned long long*)slot_ok, stop_pos)
   // default: the 4x4-block form (-14.5 % at cfg3, bit-identical images); TGS_K6_BLOCKS=0 selects the quadrant
-  // form (read per call: tests and same-box A/B runs switch it), which also serves the slot_ok bitmaps
-  const char* e_blocks = getenv("TGS_K6_BLOCKS");
-  const int use_blocks = e_blocks ? atoi(e_blocks) : 1;
-  if (use_blocks && !slot_ok) {   // 4x4-block form (bit-identical images)
+  // form, which also serves the slot_ok bitmaps.  tgs_set_k6_blocks() switches it at run time (tests, A/B).
+  if (k6_blocks() && !slot_ok) {   // 4x4-block form (bit-identical images)
     if (final_idx)
       hipLaunchKernelGGL(k_raster_fwd_blocks<true>, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T, splats,
-                         sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx, tile_order);
+                         sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx, tile_order, stop_pos);
     else
       hipLaunchKernelGGL(k_raster_fwd_blocks<false>, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T, splats,
-                         sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx, tile_order);
+                         sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx, tile_order, stop_pos);
     TGS_CHECK_LAUNCH();
     return TGS_OK;
   }
@@ -824,7 +1113,7 @@ static int rasterize_bwd_impl(const TgsCamera* cam, const float* splats,
                                  const int32_t* group_base, const int32_t* sorted_gid,
                                  const int32_t* tile_start, const int32_t* tile_order,
                                  const float* out_rgb, const float* out_depth,
-                                 const float* final_T, const float* v_rgb,
+                                 const float* final_T, const int32_t* stop_pos, const float* v_rgb,
                                  const float* v_depth, const float* v_alpha,
                                  const TgsLossSpec* loss, float* partials, float* tile_loss,
                                  int band, const uint64_t* slot_ok, void* stream) {
@@ -852,10 +1141,17 @@ static int rasterize_bwd_impl(const TgsCamera* cam, const float* splats,
     tile_order += (size_t)s0 * TGS_XCDS;
     grid = (s1 - s0) * TGS_XCDS;
   }
-  hipLaunchKernelGGL(k_raster_bwd, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T, splats,
-                     group_base, sorted_gid, tile_start, out_rgb, out_depth, final_T,
-                     v_rgb, v_depth, v_alpha, lk, partials, tile_loss, tile_order,
-                     (const unsigned long long*)slot_ok);
+  if (k7_f2b() || slot_ok) {   // the front-to-back form (round 1-3; kept for A/B and for the slot_ok bitmaps)
+    hipLaunchKernelGGL(k_raster_bwd_f2b, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T, splats,
+                       group_base, sorted_gid, tile_start, out_rgb, out_depth, final_T,
+                       v_rgb, v_depth, v_alpha, lk, partials, tile_loss, tile_order,
+                       (const unsigned long long*)slot_ok);
+  } else {
+    TGS_CHECK_ARG(stop_pos, "stop_pos (written by tgs_rasterize_fwd) is required");
+    hipLaunchKernelGGL(k_raster_bwd, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T, splats,
+                       group_base, sorted_gid, tile_start, out_rgb, out_depth, final_T, stop_pos,
+                       v_rgb, v_depth, v_alpha, lk, partials, tile_loss, tile_order);
+  }
   TGS_CHECK_LAUNCH();
   return TGS_OK;
 }
@@ -864,23 +1160,23 @@ extern "C" int tgs_rasterize_bwd(const TgsCamera* cam, const float* splats,
                                  const int32_t* group_base, const int32_t* sorted_gid,
                                  const int32_t* tile_start, const int32_t* tile_order,
                                  const float* out_rgb, const float* out_depth,
-                                 const float* final_T, const float* v_rgb,
+                                 const float* final_T, const int32_t* stop_pos, const float* v_rgb,
                                  const float* v_depth, const float* v_alpha,
                                  const TgsLossSpec* loss, float* partials, float* tile_loss,
                                  const uint64_t* slot_ok, void* stream) {
-  return rasterize_bwd_impl(cam, splats, group_base, sorted_gid, tile_start, tile_order, out_rgb, out_depth, final_T, v_rgb, v_depth, v_alpha, loss, partials, tile_loss, -1, slot_ok, stream);
+  return rasterize_bwd_impl(cam, splats, group_base, sorted_gid, tile_start, tile_order, out_rgb, out_depth, final_T, stop_pos, v_rgb, v_depth, v_alpha, loss, partials, tile_loss, -1, slot_ok, stream);
 }
 
 extern "C" int tgs_rasterize_bwd_band(const TgsCamera* cam, const float* splats,
                                  const int32_t* group_base, const int32_t* sorted_gid,
                                  const int32_t* tile_start, const int32_t* tile_order,
                                  const float* out_rgb, const float* out_depth,
-                                 const float* final_T, const float* v_rgb,
+                                 const float* final_T, const int32_t* stop_pos, const float* v_rgb,
                                  const float* v_depth, const float* v_alpha,
                                  const TgsLossSpec* loss, float* partials, float* tile_loss,
                                  int band, const uint64_t* slot_ok, void* stream) {
   TGS_CHECK_ARG(band >= 0, "band < 0");
-  return rasterize_bwd_impl(cam, splats, group_base, sorted_gid, tile_start, tile_order, out_rgb, out_depth, final_T, v_rgb, v_depth, v_alpha, loss, partials, tile_loss, band, slot_ok, stream);
+  return rasterize_bwd_impl(cam, splats, group_base, sorted_gid, tile_start, tile_order, out_rgb, out_depth, final_T, stop_pos, v_rgb, v_depth, v_alpha, loss, partials, tile_loss, band, slot_ok, stream);
 }
 
 extern "C" size_t tgs_slot_ok_len(int W, int H, int64_t capacity) {

@@ -525,8 +525,11 @@ class DepthGaussianSplattingModel:
                 step_sh_chunk, step_geom, opt.begin_step)
             self._backward_chunk = None
             if density is not None:   # v_xy exists once the K8 chunks are enqueued
+                # guarded by the AGREED verdict (written by chunk 0's dp_agree_overflow, enqueued above), not by this
+                # rank's own status word: if another rank's frame overflowed, the step is voided on every rank and
+                # replayed, and this rank's (valid) frame must not be counted twice
                 density.accumulate(self.last["v_xy"], self.last["radii"], view.cam.W, view.cam.H,
-                                   guard=self.last["guard"])
+                                   guard=dguard if dguard is not None else self.last["guard"])
         elif distributed:
             dp.reduce_and_step(self.params.grad, self.optimizer.step_range, self.optimizer.begin_step)
         elif not fuse:

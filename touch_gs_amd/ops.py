@@ -315,6 +315,10 @@ def rasterize_fwd(cam: Camera, splats, sorted_gid, tile_start, want_idx: bool = 
     depth = torch.empty(H, W, dtype=torch.float32, device=dev)
     fT = torch.empty(H, W, dtype=torch.float32, device=dev)
     fidx = torch.empty(H, W, dtype=torch.int32, device=dev) if want_idx else None
+    # per pixel: list position of the Gaussian that stopped it -- where the backward (back to front) starts.
+    # It travels with final_T (fT.stop_pos), like tile_order / slot_ok travel with tile_start.
+    stop = torch.empty(H, W, dtype=torch.int32, device=dev)
+    fT.stop_pos = stop
     cs = cam.c_struct()
     slot_ok = None
     if SLOT_OK and hasattr(tile_start, "slot_ok"):
@@ -324,16 +328,17 @@ def rasterize_fwd(cam: Camera, splats, sorted_gid, tile_start, want_idx: bool = 
         tile_start.slot_ok = slot_ok
     check(lib.tgs_rasterize_fwd(C.byref(cs), ptr(splats), ptr(sorted_gid), ptr(tile_start),
                                 ptr(getattr(tile_start, "tile_order", None)), ptr(rgb),
-                                ptr(depth), ptr(fT), ptr(fidx), ptr(slot_ok), _stream()), "tgs_rasterize_fwd")
+                                ptr(depth), ptr(fT), ptr(fidx), ptr(stop), ptr(slot_ok), _stream()), "tgs_rasterize_fwd")
     return rgb, depth, fT, fidx
 
 
 def rasterize_bwd(cam: Camera, splats, group_base, sorted_gid, tile_start, rgb, depth, fT,
                   v_rgb=None, v_depth=None, v_alpha=None, loss: Optional[dict] = None,
-                  want_tile_loss: bool = False):
+                  want_tile_loss: bool = False, stop_pos=None):
     """K7 -> (partials [cap,12], tile_loss [T,2] or None).  (tgs_rasterize_bwd)
 
     ``loss`` = dict(gt_rgb, gt_depth, uncertainty, l1_weight, depth_weight, uncertainty_weight, eps).
+    ``stop_pos``: the forward's per-pixel stop positions; default = ``fT.stop_pos`` as ``rasterize_fwd`` left it.
     """
     lib = _lib.load()
     dev = splats.device
@@ -347,11 +352,28 @@ def rasterize_bwd(cam: Camera, splats, group_base, sorted_gid, tile_start, rgb, 
     v_rgb, v_depth, v_alpha = _f32c(v_rgb), _f32c(v_depth), _f32c(v_alpha)
     check(lib.tgs_rasterize_bwd(C.byref(cs), ptr(splats), ptr(group_base), ptr(sorted_gid),
                                 ptr(tile_start), ptr(getattr(tile_start, "tile_order", None)),
-                                ptr(rgb), ptr(depth), ptr(fT),
+                                ptr(rgb), ptr(depth), ptr(fT), ptr(_stop_pos_of(fT, stop_pos)),
                                 ptr(v_rgb), ptr(v_depth), ptr(v_alpha),
                                 C.byref(ls) if ls is not None else None, ptr(partials),
                                 ptr(tile_loss), ptr(getattr(tile_start, "slot_ok", None)), _stream()), "tgs_rasterize_bwd")
     return partials, tile_loss
+
+
+def set_raster_variant(k6_blocks: Optional[bool] = None, k7_front_to_back: Optional[bool] = None) -> int:
+    """Developer switch (tgs_set_raster_variant): K6 in 4x4-block (default) / quadrant form, K7 back to front
+    (default) / front to back (the round 1-3 form; the only one that takes the slot_ok bitmaps).  None leaves a
+    setting alone.  Returns the settings in force (bit 0 = block-form K6, bit 1 = front-to-back K7)."""
+    f = lambda v: -1 if v is None else int(bool(v))
+    return _lib.load().tgs_set_raster_variant(f(k6_blocks), f(k7_front_to_back))
+
+
+def _stop_pos_of(fT, stop_pos=None):
+    """The stop positions that belong to a forward's final_T (K7 needs them; there is no fallback)."""
+    sp = stop_pos if stop_pos is not None else getattr(fT, "stop_pos", None)
+    if sp is None:
+        raise RuntimeError("rasterize_bwd needs the forward's stop positions: pass the final_T tensor that "
+                           "rasterize_fwd returned (it carries .stop_pos) or stop_pos=...")
+    return sp
 
 
 def _loss_spec_struct(loss, keep):
@@ -426,7 +448,7 @@ def rasterize_bwd_ssim_pipelined(cam: Camera, splats, group_base, sorted_gid, ti
     for (b, *_), ev in zip(bands, done):
         main.wait_event(ev)
         check(lib.tgs_rasterize_bwd_band(C.byref(cs), ptr(splats), ptr(group_base), ptr(sorted_gid), ptr(tile_start),
-                                         ptr(order), ptr(rgb), ptr(depth), ptr(fT), ptr(v_img), None, None,
+                                         ptr(order), ptr(rgb), ptr(depth), ptr(fT), ptr(_stop_pos_of(fT)), ptr(v_img), None, None,
                                          C.byref(ls) if ls is not None else None, ptr(partials), ptr(tile_loss),
                                          b, ptr(getattr(tile_start, "slot_ok", None)), _stream()), "tgs_rasterize_bwd_band")
     return partials, tile_loss, bp
@@ -512,7 +534,7 @@ class _Render(torch.autograd.Function):
         ctx.cam, ctx.sh_deg = cam, sh_deg
         ctx.want_xy = means2d is not None
         ctx.save_for_backward(means, log_scales, quats, opac_logit, sh, splats, group_base,
-                              tile_start, sorted_gid, rgb, depth, fT)
+                              tile_start, sorted_gid, rgb, depth, fT, fT.stop_pos)
         alpha = 1.0 - fT
         ctx.mark_non_differentiable(radii)
         return rgb, depth, alpha, radii
@@ -520,10 +542,10 @@ class _Render(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_rgb, v_depth, v_alpha, _v_radii):
         (means, log_scales, quats, opac_logit, sh, splats, group_base, tile_start, sorted_gid,
-         rgb, depth, fT) = ctx.saved_tensors
+         rgb, depth, fT, stop) = ctx.saved_tensors
         cam = ctx.cam
         partials, _ = rasterize_bwd(cam, splats, group_base, sorted_gid, tile_start, rgb, depth, fT,
-                                    v_rgb, v_depth, v_alpha)
+                                    v_rgb, v_depth, v_alpha, stop_pos=stop)
         v_means, v_ls, v_q, v_ol, v_sh, v_xy = project_bwd(
             cam, means, log_scales, quats, opac_logit, sh, ctx.sh_deg, splats, group_base, partials,
             want_v_xy=ctx.want_xy)
@@ -701,15 +723,15 @@ class _RasterizeGaussians(torch.autograd.Function):
         rgb, depth, fT, fidx = rasterize_fwd(cam, splats, sorted_gid, tile_start)
         ctx.cam = cam
         ctx.opacity_shape = opacity.shape
-        ctx.save_for_backward(splats, group_base, tile_start, sorted_gid, rgb, depth, fT)
+        ctx.save_for_backward(splats, group_base, tile_start, sorted_gid, rgb, depth, fT, fT.stop_pos)
         return rgb, 1.0 - fT, depth
 
     @staticmethod
     def backward(ctx, v_rgb, v_alpha, v_depth):
-        splats, group_base, tile_start, sorted_gid, rgb, depth, fT = ctx.saved_tensors
+        splats, group_base, tile_start, sorted_gid, rgb, depth, fT, stop = ctx.saved_tensors
         cam = ctx.cam
         partials, _ = rasterize_bwd(cam, splats, group_base, sorted_gid, tile_start, rgb, depth, fT,
-                                    v_rgb, v_depth, v_alpha)
+                                    v_rgb, v_depth, v_alpha, stop_pos=stop)
         v = reduce_partials(cam, splats, group_base, partials)
         v_xys, v_depths = v[:, 0:2].contiguous(), v[:, 2].contiguous()
         v_op = v[:, 3].contiguous().reshape(ctx.opacity_shape)

@@ -185,7 +185,9 @@ class GradSync:
         while b < N:
             out.append((b, min(b + per, N)))
             b += per
-        return out
+        # never empty: chunk 0 carries the overflow verdict (dp_agree_overflow), so a model without Gaussians still
+        # exchanges one (empty) block
+        return out or [(0, 0)]
 
     def pipelined_color_exchange_and_step(self, geom_grad: torch.Tensor, blocks: Sequence[torch.Tensor],
                                           blocks_all: Sequence[torch.Tensor], backward_chunk, step_sh_chunk,
