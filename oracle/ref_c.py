@@ -121,7 +121,9 @@ class RefC:
         return out, npix
 
     def blend_bwd(self, xy, conic, opac, rgb, depth, gid, ts, cam, W, H, final_T, final_idx,
-                  v_rgb_img, v_depth_img, v_alpha_img, tile_range=None):
+                  v_rgb_img, v_depth_img, v_alpha_img, tile_range=None, mass=False):
+        """B.7 -> per-Gaussian screen-space gradients; ``mass=True``: the un-cancelled magnitude of each of them
+        (ref_blend_bwd_mass_range: every term entered with its absolute value)."""
         xy, conic, opac, rgb, depth, final_T, v_rgb_img, v_depth_img, v_alpha_img = map(
             self._r, (xy, conic, opac, rgb, depth, final_T, v_rgb_img, v_depth_img, v_alpha_img))
         gid = np.ascontiguousarray(gid, np.int32)
@@ -131,7 +133,8 @@ class RefC:
         o = dict(v_xy=np.zeros((N, 2), self.dt), v_conic=np.zeros((N, 3), self.dt), v_opac=np.zeros(N, self.dt),
                  v_rgb=np.zeros((N, 3), self.dt), v_depth=np.zeros(N, self.dt))
         t0, t1 = tile_range if tile_range is not None else (0, ((W + 15) // 16) * ((H + 15) // 16))
-        self.lib.ref_blend_bwd_range(self._p(xy), self._p(conic), self._p(opac), self._p(rgb), self._p(depth),
+        fn = self.lib.ref_blend_bwd_mass_range if mass else self.lib.ref_blend_bwd_range
+        fn(self._p(xy), self._p(conic), self._p(opac), self._p(rgb), self._p(depth),
                                      self._p(gid), self._p(ts), self._p(cam), C.c_int(W), C.c_int(H),
                                      self._p(final_T), self._p(final_idx),
                                      self._p(v_rgb_img), self._p(v_depth_img), self._p(v_alpha_img),

@@ -422,6 +422,74 @@ void ref_blend_bwd(const real *xy, const real *conic, const real *opac, const re
                         v_rgb_img, v_depth_img, v_alpha_img, v_xy, v_conic, v_opac, v_rgb, v_depth, 0, TW * TH);
 }
 
+/* Test aid: the UN-CANCELLED magnitude of every screen-space gradient of ref_blend_bwd_range -- the same
+ * walk with the absolute value of every term that is added anywhere (inside dL/dalpha too): m_* >= |v_*|.
+ * A floating-point evaluation of a sum is accurate relative to the sum of the magnitudes of its terms, not
+ * relative to a result that cancels; with random upstream gradients a Gaussian's ~200 pixel contributions
+ * cancel to 1e-3 of their magnitude for one Gaussian in a thousand, which is all the tail of a plain relative
+ * error shows.  The full-size gradient tests therefore bound |HIP - oracle| by tol * m (the componentwise
+ * forward-error measure of a sum).  Accumulates (+=); the caller zeroes. */
+void ref_blend_bwd_mass_range(const real *xy, const real *conic, const real *opac, const real *rgb, const real *depth,
+                   const int32_t *sorted_gid, const int64_t *tile_start, const cam_t *cam, int W, int H,
+                   const real *f_T, const int32_t *f_idx,
+                   const real *v_rgb_img, const real *v_depth_img, const real *v_alpha_img,
+                   real *m_xy, real *m_conic, real *m_opac, real *m_rgb, real *m_depth, int t0, int t1) {
+    int TW = (W + BLK - 1) / BLK;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int t = t0; t < t1; t++) {
+        int ty = t / TW, tx = t % TW;
+        int64_t s = tile_start[t];
+        for (int py = ty * BLK; py < (ty + 1) * BLK && py < H; py++)
+            for (int px = tx * BLK; px < (tx + 1) * BLK && px < W; px++) {
+                size_t p = (size_t)py * W + px;
+                real fxp = px + cam->pc, fyp = py + cam->pc;
+                real Tfin = f_T[p], T = Tfin;
+                real vC[3] = {fabs(v_rgb_img[3 * p]), fabs(v_rgb_img[3 * p + 1]), fabs(v_rgb_img[3 * p + 2])};
+                real vD = fabs(v_depth_img[p]), vA = fabs(v_alpha_img[p]);
+                real S[3] = {0, 0, 0}, SD = 0;
+                real bgdot = fabs(cam->bg[0]) * vC[0] + fabs(cam->bg[1]) * vC[1] + fabs(cam->bg[2]) * vC[2];
+                for (int k = f_idx[p]; k >= 0; k--) {
+                    int g = sorted_gid[s + k];
+                    real dx = xy[2 * g] - fxp, dy = xy[2 * g + 1] - fyp;
+                    real a = conic[3 * g], b = conic[3 * g + 1], c = conic[3 * g + 2];
+                    real sig = (real)0.5 * (a * dx * dx + c * dy * dy) + b * dx * dy;
+                    if (sig < 0) continue;
+                    real ex = exp(-sig), al = opac[g] * ex; if (al > ALPHA_MAX) al = ALPHA_MAX;
+                    if (al < ALPHA_MIN) continue;
+                    real ra = 1 / (1 - al);
+                    T *= ra;
+                    real w = al * T;
+                    real valpha = 0;
+                    for (int ch = 0; ch < 3; ch++) {
+                        real cg = fabs(rgb[3 * g + ch]);
+#pragma omp atomic
+                        m_rgb[3 * g + ch] += w * vC[ch];
+                        valpha += (cg * T + S[ch] * ra) * vC[ch];
+                        S[ch] += w * cg;
+                    }
+#pragma omp atomic
+                    m_depth[g] += w * vD;
+                    valpha += (fabs(depth[g]) * T + SD * ra) * vD;
+                    SD += w * fabs(depth[g]);
+                    valpha += Tfin * ra * (vA + bgdot);
+                    real vsig = opac[g] * ex * valpha;
+#pragma omp atomic
+                    m_opac[g] += ex * valpha;
+#pragma omp atomic
+                    m_conic[3 * g] += (real)0.5 * vsig * dx * dx;
+#pragma omp atomic
+                    m_conic[3 * g + 1] += vsig * fabs(dx * dy);
+#pragma omp atomic
+                    m_conic[3 * g + 2] += (real)0.5 * vsig * dy * dy;
+#pragma omp atomic
+                    m_xy[2 * g] += vsig * (fabs(a * dx) + fabs(b * dy));
+#pragma omp atomic
+                    m_xy[2 * g + 1] += vsig * (fabs(b * dx) + fabs(c * dy));
+                }
+            }
+    }
+}
+
 /* B.8 projection + SH backward.  Inputs: per-Gaussian v_xy, v_conic, v_opac, v_rgb, v_depth.
  * Outputs (overwritten): v_means [N,3], v_log_scales [N,3], v_quats [N,4], v_opac_logit [N],
  * v_sh [N,K_stride,3]. */

@@ -141,3 +141,42 @@ def test_single_gaussian_closed_form():
     assert alpha[i] <= min(0.999, o) + 1e-6 and alpha[i] > 0.8 * min(0.999, o)
     c = np.maximum(z["one/in/sh"][0, 0] * O.SH_C0 + 0.5, 0)
     assert np.allclose(rgb[i], alpha[i] * c + (1 - alpha[i]) * z["one/bg"], atol=1e-5)
+
+
+def test_gradient_mass_and_gaussian_classification_aids():
+    """The two test aids of the full-size gradient tests (oracle/ref_raster.c): blend_bwd(mass=True) is the same
+    walk with absolute values, so it bounds |gradient| and equals it when nothing cancels (non-negative upstream
+    gradients, colours and depths; v_alpha = 0); gaussian_min_margin returns, per Gaussian, the smallest entry
+    of a pixel map over the pixels it (nearly) contributes to."""
+    import numpy as np
+    from oracle.ref_c import RefC
+    from tests.util import scene
+    N, W, H, deg = 600, 96, 64, 1
+    P, cam = scene(N, W, H, deg, 41)
+    R = RefC("f64")
+    cb = R.cam_block(cam.viewmat.numpy(), cam.fx, cam.fy, cam.cx, cam.cy, bg=(0.0, 0.0, 0.0))
+    Pn = {k: v.double().numpy() for k, v in P.items()}
+    pc = R.project_fwd(Pn["means"], Pn["log_scales"], Pn["quats"], Pn["opac_logit"], Pn["sh"], deg, cb, W, H)
+    g, ts = R.bin_sort(pc["rect"], pc["tiles_hit"], pc["depth"], W, H)
+    bf = R.blend_fwd(pc["xy"], pc["conic"], pc["opac"], pc["rgb"], pc["depth"], g, ts, cb, W, H)
+    rng = np.random.default_rng(0)
+    args = (pc["xy"], pc["conic"], pc["opac"], pc["rgb"], pc["depth"], g, ts, cb, W, H, bf["final_T"], bf["final_idx"])
+    v = (rng.standard_normal((H, W, 3)), rng.standard_normal((H, W)), rng.standard_normal((H, W)))
+    bb, m = R.blend_bwd(*args, *v), R.blend_bwd(*args, *v, mass=True)
+    for k in bb:
+        assert (m[k] >= np.abs(bb[k]) * (1 - 1e-12)).all(), k
+        assert (m[k] > 0).sum() == (bb[k] != 0).sum() or k in ("v_conic", "v_xy"), k
+    # no cancellation in v_rgb / v_depth when the upstream gradients are non-negative: mass == gradient
+    vp = (np.abs(v[0]), np.abs(v[1]), np.zeros((H, W)))
+    bp, mp = R.blend_bwd(*args, *vp), R.blend_bwd(*args, *vp, mass=True)
+    assert np.allclose(mp["v_rgb"], bp["v_rgb"], rtol=1e-12) and np.allclose(mp["v_depth"], bp["v_depth"], rtol=1e-12)
+    # classification: a map that is 1 everywhere except one pixel -> only Gaussians reaching that pixel see 0
+    pm = np.ones((H, W)); py, px = H // 2, W // 2; pm[py, px] = 0.0
+    gmin, npix = R.gaussian_min_margin(pc["xy"], pc["conic"], pc["opac"], pc["rect"], pc["tiles_hit"], cb, W, H, pm, near=0.5)
+    dx, dy = pc["xy"][:, 0] - (px + 0.5), pc["xy"][:, 1] - (py + 0.5)
+    sig = 0.5 * (pc["conic"][:, 0] * dx * dx + pc["conic"][:, 2] * dy * dy) + pc["conic"][:, 1] * dx * dy
+    tx, ty = px // 16, py // 16
+    in_rect = (pc["tiles_hit"] > 0) & (pc["rect"][:, 0] <= tx) & (tx < pc["rect"][:, 2]) & (pc["rect"][:, 1] <= ty) & (ty < pc["rect"][:, 3])
+    hits = in_rect & (sig >= 0) & (pc["opac"] * np.exp(-sig) >= 0.5 / 255)
+    assert hits.sum() > 0 and np.array_equal(gmin == 0.0, hits)
+    assert ((npix > 0) == (gmin < 1e29)).all() and (gmin[(npix > 0) & ~hits] == 1.0).all()

@@ -32,6 +32,9 @@ CONFIGS = {"cfg2_100k_800x800": (100_000, 800, 800, 3, 1235, 1),
            # the per-GPU part of configs[4] (5 M Gaussians, SH degree 3, 4K render; seed 1238, view 3 of 8)
            "cfg5_5M_4K": (5_000_000, 3840, 2160, 3, 1238, 3)}
 TOL = 1e-4
+# fraction of the pixels with every threshold decision further than 1e-3 (relative) from its threshold and an
+# fp32 depth order equal to the fp64 one -- where RGB / depth / T are asserted at 1e-4 (r4 measurements)
+CLEAR_MEASURED = {"cfg2_100k_800x800": 0.987, "cfg3_1M_1080p": 0.960, "cfg5_5M_4K": 0.91}
 
 
 def order_ambiguous_tiles(sg_hip, ts_hip, g_ref, ts_ref, N):
@@ -55,14 +58,23 @@ def order_ambiguous_tiles(sg_hip, ts_hip, g_ref, ts_ref, N):
     rank_o = order_o[pos][found]                   # position of every product pair in the oracle's global list
     th = tile_h[found]
     inv = (th[1:] == th[:-1]) & (rank_o[1:] < rank_o[:-1])
-    return np.unique(th[1:][inv])
+    # ... and tiles whose product list holds a Gaussian the oracle's list does not: the NORMATIVE B.4 rect is an
+    # integer decision (ceil of the 3-sigma radius, truncation of (u -+ r) / 16) that fp32 takes differently from
+    # fp64 for ~0.5 % of the Gaussians, and for opacities near 1 the region alpha >= 1/255 (3.33 sigma) reaches
+    # beyond the 3-sigma rect -- the extra list member then contributes on one side only
+    return np.unique(np.concatenate([th[1:][inv], tile_h[~found]]))
 
 
 @pytest.fixture(scope="module", params=list(CONFIGS))
 def both(request, dev):
+    return build_case(request.param, dev)
+
+
+def build_case(name, dev):
+    """HIP path and fp64 C oracle on one BASELINE config (also used by tools/grad_offenders.py)."""
     from touch_gs_amd import ops
     from touch_gs_amd.scene import make_camera, synthetic_gaussians
-    N, W, H, deg, seed, view = CONFIGS[request.param]
+    N, W, H, deg, seed, view = CONFIGS[name]
     P, intr = synthetic_gaussians(N, W, H, deg, seed)
     cam = make_camera(intr, view, 8, bg=(0.1, 0.2, 0.3))
     D = {k: v.to(dev).contiguous() for k, v in P.items()}
@@ -99,12 +111,27 @@ def both(request, dev):
                      bf["final_T"], bf["final_idx"], n64(v_rgb), n64(v_d), n64(v_a))
     pb = R.project_bwd(Pn["means"], Pn["log_scales"], Pn["quats"], Pn["opac_logit"], Pn["sh"], deg, cb, W, H,
                        pc["radius"], bb["v_xy"], bb["v_conic"], bb["v_opac"], bb["v_rgb"], bb["v_depth"])
+    # un-cancelled magnitudes of the same gradients (the scale a floating-point sum is accurate against)
+    m7 = R.blend_bwd(pc["xy"], pc["conic"], pc["opac"], pc["rgb"], pc["depth"], g2, ts2, cb, W, H,
+                     bf["final_T"], bf["final_idx"], n64(v_rgb), n64(v_d), n64(v_a), mass=True)
+    v_splats = ops.reduce_partials(cam, sp, gb, partials).cpu().double().numpy()
     tile_np = tile.cpu().numpy()
     pos2 = ts2[tile_np] + np.maximum(bf["final_idx"], 0)
     last_gid_ref = np.where(bf["final_idx"] >= 0, g2[np.minimum(pos2, max(len(g2) - 1, 0))], -1)
     order_ok = ~np.isin(tile_np, order_ambiguous_tiles(sg.cpu().numpy()[:n_hip], ts.cpu().numpy(), g2, ts2, N))
-    return dict(name=request.param, N=N, W=W, H=H, deg=deg, seed=seed, view=view, cam=cam, D=D, Pn=Pn, g2=g2, ts2=ts2,
-                order_ok=order_ok,
+    # the converse: pairs of the oracle's list that the product's rect drops although alpha reaches 1/255 (less the
+    # decision margin) at a pixel centre of the tile (the tight rect's fp32 extent falling short, or an fp32
+    # normative rect one tile smaller): every tile of such a Gaussian's normative rect counts as ambiguous (a
+    # handful of Gaussians per million; test_tight_rect_drops_only_invisible_pairs bounds their number)
+    f = splat_fields(sp, radii)
+    tight = f["rect"].numpy().astype(np.int32)
+    tight[(f["hits"] == 0).numpy()] = 0
+    mx, dropped = R.dropped_pairs_max_alpha(pc["xy"], pc["conic"], pc["opac"], pc["rect"], pc["tiles_hit"], tight, cb, W, H)
+    for i in np.where(mx >= (1.0 - 1e-3) / 255.0)[0]:
+        x0, y0, x1, y1 = pc["rect"][i]
+        order_ok[16 * y0:16 * y1, 16 * x0:16 * x1] = False
+    return dict(name=name, N=N, W=W, H=H, deg=deg, seed=seed, view=view, cam=cam, D=D, Pn=Pn, g2=g2, ts2=ts2,
+                order_ok=order_ok, dropped_max_alpha=mx, dropped=dropped, tight=tight, bb=bb, m7=m7, v_splats=v_splats, cache={},
                 R=R, cb=cb, sp=sp, radii=radii, n_hip=n_hip, n_ref=len(g2),
                 rgb=rgb.cpu().numpy(), depth=depth.cpu().numpy(), fT=fT.cpu().numpy(), last_hip=last_gid_hip,
                 grads=[t.cpu().double().numpy() for t in grads[:5]], pc=pc, bf=bf, margin=margin, pb=pb,
@@ -117,7 +144,10 @@ def test_forward_matches_oracle_fullsize(both):
     # order agrees with the fp64 order (order_ambiguous_tiles)
     assert b["order_ok"].mean() > 0.99, b["order_ok"].mean()
     clear = (b["margin"] > 1e-3) & b["order_ok"]
-    assert clear.mean() > 0.9, clear.mean()
+    # the share of the image the 1e-4 bound is asserted on, per config (measured: CLEAR_MEASURED; it cannot drift
+    # by more than a percent without failing here)
+    print(f"{b['name']}: decision-clear pixels (margin > 1e-3, depth order agrees) {clear.mean():.4f}")
+    assert clear.mean() > CLEAR_MEASURED[b["name"]] - 0.01, (b["name"], clear.mean())
     er = relerr(b["rgb"], b["bf"]["rgb"], floor=1e-2)
     ed = relerr(b["depth"], b["bf"]["depth_acc"], floor=1e-2)
     eT = np.abs(b["fT"] - b["bf"]["final_T"])
@@ -144,11 +174,8 @@ def test_tight_rect_drops_only_invisible_pairs(both):
     o*exp(-sigma) < 1/255 at every pixel centre of its tile (fp64 oracle values)."""
     b = both
     f = splat_fields(b["sp"], b["radii"])
-    tight = f["rect"].numpy().astype(np.int32)
-    tight[(f["hits"] == 0).numpy()] = 0
     pc = b["pc"]
-    mx, dropped = b["R"].dropped_pairs_max_alpha(pc["xy"], pc["conic"], pc["opac"], pc["rect"], pc["tiles_hit"], tight,
-                                                 b["cb"], b["W"], b["H"])
+    mx, dropped = b["dropped_max_alpha"], b["dropped"]      # (computed in build_case: R.dropped_pairs_max_alpha)
     # the product may only drop pairs (subset), and it drops a substantial share on these scenes.
     # `same`: Gaussians whose NORMATIVE B.4 rect is the same in fp32 and fp64 (radius = ceil() of a value
     # within rounding of an integer, or (u -+ r)/16 within rounding of a tile boundary, differ in < 0.5 %)
@@ -169,18 +196,88 @@ def test_tight_rect_drops_only_invisible_pairs(both):
     assert int((mx[~same] >= 1.0 / 255.0).sum()) <= max(8, int(2e-5 * b["N"]))
 
 
+GMARGIN = 1e-4     # decision margin below which a pixel counts as ambiguous for the GRADIENT classification
+GTOL = 1e-4        # the bar: north_star / BASELINE.md "gradients <= 1e-4 relative"
+
+
+def classify_gaussians(b, extra_unclear=None):
+    """-> (pixel margin map, reaching, clear).  A pixel is decision-clear if every threshold test App. B.6
+    evaluates for it (alpha against 1/255, T' against 1e-4) is further than GMARGIN (relative) from its
+    threshold in the fp64 oracle and its tile's fp32 depth order equals the fp64 order.  A flipped decision at
+    a pixel changes the transmittance of every later Gaussian there, so a GAUSSIAN is clear only if every
+    pixel where it contributes or nearly contributes (alpha >= 0.5 / 255) is clear; `reaching` = has such a pixel."""
+    pm = b["margin"].copy()
+    pm[~b["order_ok"]] = 0.0
+    if extra_unclear is not None:
+        pm[extra_unclear] = 0.0
+    pc = b["pc"]
+    gmin, npix = b["R"].gaussian_min_margin(pc["xy"], pc["conic"], pc["opac"], pc["rect"], pc["tiles_hit"], b["cb"],
+                                            b["W"], b["H"], pm, near=0.5)
+    reach = npix > 0
+    return pm, reach, reach & (gmin > GMARGIN)
+
+
+def max_over(n_clear):
+    """Clear Gaussians allowed above the bar (and then below 10x the bar): 2 per million.  What they are (r4,
+    tools/grad_offenders.py): (a) K7 forms the conic moments sum q (g - u)^2 from tile-centred sums (raster.hip),
+    exact to ~1e-5 of (tile coordinate / footprint)^2 -- a Gaussian a pixel wide sitting 7 px off the tile centre
+    reaches 3e-4 (1 of 2.2 M at 4K); (b) K8's quaternion gradient of a Gaussian whose three scales agree to 1e-5
+    vanishes analytically, so |J| m is ~0 while the fp32 chain rounds at the size of its intermediates."""
+    return max(1, int(2e-6 * n_clear))
+
+
+def assert_gradients(tag, got, ref, mass, reach, clear, keys, report, tol_max=GTOL, tol_q=3e-5):
+    """The gradient bar: on every clear Gaussian  max_c |HIP - oracle| <= tol_max * max_c (un-cancelled magnitude)
+    for each gradient, up to max_over() named exceptions that stay below 10 tol_max, and q99.99 <= tol_q; the
+    unclear ones are counted and bounded; Gaussians that reach no pixel have exactly zero gradients on both sides."""
+    from tests.util import err_over_mass
+    for key in keys:
+        e = err_over_mass(got[key], ref[key], mass[key])
+        ec, eu = e[clear], e[reach & ~clear]
+        report.append(f"{key}: clear max {ec.max():.1e} q99.99 {np.quantile(ec, 0.9999):.1e} | unclear >{GTOL:g}: "
+                      f"{int((eu > GTOL).sum())} of {eu.size}, max {eu.max() if eu.size else 0:.1e}")
+        n_over = int((ec > tol_max).sum())
+        assert n_over <= max_over(ec.size) and ec.max() <= 10 * tol_max and np.quantile(ec, 0.9999) <= tol_q, (
+            tag, key, float(ec.max()), float(np.quantile(ec, 0.9999)), n_over, int(clear.sum()))
+        # an ambiguous pixel flips at most contributions of weight ~1/255 (or the tail behind T = 1e-4): most unclear
+        # Gaussians still agree; a flip can change a Gaussian whose gradient comes from that one pixel by O(1)
+        assert (eu > GTOL).mean() < 0.02 and (eu.max() if eu.size else 0) < 4.0, (tag, key, float((eu > GTOL).mean()))
+        g = np.asarray(got[key], np.float64).reshape(len(reach), -1)
+        r = np.asarray(ref[key], np.float64).reshape(len(reach), -1)
+        if key != "v_sh" and key != "v_means":   # (colour / view-direction gradients exist for unseen Gaussians too)
+            assert np.abs(g[~reach]).max() <= 1e-30 + 1e-3 * np.abs(r[~reach]).max(), (tag, key)
+
+
 def test_gradients_match_oracle_fullsize(both):
+    """All gradients of the raster backward + projection backward against the fp64 C oracle at full size, random
+    upstream gradients.  (1) K7's output -- the ten screen-space gradients per Gaussian (tgs_reduce_partials of the
+    partial records) -- and (2) the five parameter gradients, each asserted at  max <= 1e-4  on every
+    decision-clear Gaussian, relative to the un-cancelled magnitude of the gradient (oracle: the same walk with
+    absolute values; for the parameters |J| times it, J = the oracle's projection backward column by column).
+    Why that scale: with random upstream gradients a Gaussian's ~200 signed pixel contributions cancel to 1e-3 of
+    their magnitude for one Gaussian in a thousand; no fp32 evaluation (the scalar fp32 build of the oracle
+    included: tools/grad_err_k7.py) is accurate relative to such a remainder."""
+    from tests.util import K7_KEYS, PARAM_KEYS, k7_outputs, param_mass
     b = both
-    names = ("means", "log_scales", "quats", "opac_logit", "sh")
-    for name, got, key in zip(names, b["grads"], ("v_means", "v_log_scales", "v_quats", "v_opac_logit", "v_sh")):
-        ref = b["pb"][key].reshape(got.shape)
-        scale = np.abs(ref).max()
-        e = relerr(got, ref, floor=1e-3 * scale)
-        cos = (ref * got).sum() / np.sqrt((ref * ref).sum() * (got * got).sum())
-        rel_l2 = np.sqrt(((got - ref) ** 2).sum() / (ref * ref).sum())
-        assert np.median(e) < 3e-5, (b["name"], name, np.median(e))
-        assert np.quantile(e, 0.98) < 1e-3, (b["name"], name, np.quantile(e, 0.98))
-        assert cos > 0.9999 and rel_l2 < 1e-2, (b["name"], name, cos, rel_l2)
+    pm, reach, clear = classify_gaussians(b)
+    report = [f"{b['name']}: decision-clear pixels {np.mean(pm > GMARGIN):.5f} (forward test, margin 1e-3: "
+              f"{np.mean((b['margin'] > 1e-3) & b['order_ok']):.4f}); Gaussians reaching a pixel {reach.mean():.4f}, "
+              f"of which clear {clear.sum() / max(reach.sum(), 1):.4f}"]
+    assert clear.sum() > 0.3 * reach.sum(), report
+    N = b["N"]
+    ref7 = {k: np.asarray(b["bb"][k], np.float64).reshape(N, -1) for k in K7_KEYS}
+    assert_gradients(b["name"], k7_outputs(b["v_splats"]), ref7, b["m7"], reach, clear, K7_KEYS, report)
+    pmass = param_mass(b["R"], b["Pn"], b["deg"], b["cb"], b["W"], b["H"], b["pc"]["radius"], b["m7"])
+    got = dict(zip(PARAM_KEYS, b["grads"]))
+    assert_gradients(b["name"], got, b["pb"], pmass, reach, clear, PARAM_KEYS, report)
+    print("\n".join(report))
+    b["cache"]["grad_report"] = report
+    # whole-tensor agreement (dominated by the unclear Gaussians)
+    for key in PARAM_KEYS:
+        ref, g = b["pb"][key].reshape(N, -1), np.asarray(got[key]).reshape(N, -1)
+        cos = (ref * g).sum() / np.sqrt((ref * ref).sum() * (g * g).sum())
+        rel_l2 = np.sqrt(((g - ref) ** 2).sum() / (ref * ref).sum())
+        assert cos > 0.9999 and rel_l2 < 1e-2, (b["name"], key, cos, rel_l2)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -227,6 +324,7 @@ def test_train_step_matches_oracle_fullsize(both, dev):
     from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig, View
     from touch_gs_amd.optim import GaussianParams
     from touch_gs_amd.scene import make_view
+    from tests.util import PARAM_KEYS, param_mass
     b = both
     if b["W"] > 2048:
         pytest.skip("train-step parity runs at configs[1] and configs[2]")
@@ -265,14 +363,27 @@ def test_train_step_matches_oracle_fullsize(both, dev):
         assert abs(total - float(L)) < 2e-5 * abs(float(L)), (b["name"], tag, total, float(L))
         assert abs(losses["depth_loss"] - L_depth) < 1e-4 * abs(L_depth) + 1e-9, (b["name"], tag, losses["depth_loss"], L_depth)
         assert abs(ssim_hip - ssim_ref) < 1e-5, (b["name"], tag, ssim_hip, ssim_ref)
-        # ---- gradients ----
+        # ---- gradients: max <= 1e-4 of the un-cancelled magnitude on every decision-clear Gaussian ----
+        # (besides the compositing thresholds, the L1 term's sign(C - gt) is a decision: pixels with a channel
+        # closer than 2e-4 -- the forward's own tolerance -- to the ground truth count as ambiguous)
+        l1_amb = (np.abs(bf["rgb"] - gt64.numpy()) < 2e-4).any(-1)
+        pm, reach, clear = classify_gaussians(b, extra_unclear=l1_amb)
+        m7 = R.blend_bwd(pc["xy"], pc["conic"], pc["opac"], pc["rgb"], pc["depth"], b["g2"], b["ts2"], cb, W, H,
+                         bf["final_T"], bf["final_idx"], rgb_t.grad.numpy(), dacc_t.grad.numpy(), alpha_t.grad.numpy(),
+                         mass=True)
+        pmass = param_mass(R, Pn, deg, cb, W, H, pc["radius"], m7)
+        report = [f"{b['name']} / {tag}: decision-clear pixels {np.mean(pm > GMARGIN):.5f}, clear Gaussians "
+                  f"{clear.sum() / max(reach.sum(), 1):.4f} of the reaching ones"]
+        gotk = {"v_" + k: got[k] for k in GaussianParams.NAMES}
+        # Here the upstream gradient images are themselves computed twice -- fp32 kernels on the HIP image, fp64
+        # torch on the oracle's image -- and the loss curvature (SSIM: 1 / (sigma^2 + C2), C2 = 9e-4) amplifies the
+        # 1e-4 the images may differ by: 99.99 % of the clear Gaussians within 1e-4, every one within 1e-3.  The
+        # bar proper (max <= 1e-4 with the upstream gradients given) is test_gradients_match_oracle_fullsize.
+        assert_gradients(f"{b['name']}/{tag}", gotk, pb, pmass, reach, clear, PARAM_KEYS, report, tol_max=1e-3, tol_q=GTOL)
+        print("\n".join(report))
         for name, key in (("means", "v_means"), ("log_scales", "v_log_scales"), ("quats", "v_quats"),
                           ("opac_logit", "v_opac_logit"), ("sh", "v_sh")):
             ref = pb[key].reshape(got[name].shape)
-            scale = np.abs(ref).max()
-            e = relerr(got[name], ref, floor=1e-3 * scale)
             cos = (ref * got[name]).sum() / np.sqrt((ref * ref).sum() * (got[name] * got[name]).sum())
             rel_l2 = np.sqrt(((got[name] - ref) ** 2).sum() / (ref * ref).sum())
-            assert np.median(e) < 3e-5, (b["name"], tag, name, np.median(e))
-            assert np.quantile(e, 0.98) < 5e-3, (b["name"], tag, name, np.quantile(e, 0.98))
             assert cos > 0.9999 and rel_l2 < 1e-2, (b["name"], tag, name, cos, rel_l2)

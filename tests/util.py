@@ -87,3 +87,49 @@ def rect_from(xy, radius, cam):
     y0 = torch.clamp(((v - r) / 16).to(torch.int64), 0, TH)
     y1 = torch.clamp(((v + r) / 16).to(torch.int64) + 1, 0, TH)
     return torch.stack([x0, y0, x1, y1], 1)
+
+
+# ---------------------------------------------------------------------------------------------
+# condition-aware gradient comparison (full-size oracle tests)
+# ---------------------------------------------------------------------------------------------
+K7_KEYS = ("v_xy", "v_conic", "v_opac", "v_rgb", "v_depth")
+PARAM_KEYS = ("v_means", "v_log_scales", "v_quats", "v_opac_logit", "v_sh")
+
+
+def k7_outputs(v_splats):
+    """tgs_reduce_partials record [N,12] -> the oracle's blend_bwd keys (fp64, [N,c])."""
+    v = np.asarray(v_splats, np.float64)
+    return dict(v_xy=v[:, 0:2], v_depth=v[:, 2:3], v_opac=v[:, 3:4], v_conic=v[:, 4:7], v_rgb=v[:, 7:10])
+
+
+def param_mass(R, Pn, deg, cb, W, H, radius, m7):
+    """|J| m: the un-cancelled magnitude of the five parameter gradients, from the magnitudes ``m7`` of the ten
+    screen-space gradients (oracle blend_bwd(mass=True)).  The projection backward is linear in its inputs and
+    Gaussians are independent, so column c of every Gaussian's Jacobian is the oracle's project_bwd of the c-th
+    unit vector: ten calls.  A sum evaluated in floating point is accurate relative to THIS quantity -- the sum
+    of the magnitudes of its terms -- not relative to a result that happens to cancel."""
+    N = Pn["means"].shape[0]
+    shapes = dict(v_xy=2, v_conic=3, v_opac=1, v_rgb=3, v_depth=1)
+    acc = None
+    for key in K7_KEYS:
+        for c in range(shapes[key]):
+            unit = {k: np.zeros((N, n) if n > 1 else N) for k, n in shapes.items()}
+            if shapes[key] > 1:
+                unit[key][:, c] = 1.0
+            else:
+                unit[key][:] = 1.0
+            col = R.project_bwd(Pn["means"], Pn["log_scales"], Pn["quats"], Pn["opac_logit"], Pn["sh"], deg, cb, W, H,
+                                radius, unit["v_xy"], unit["v_conic"], unit["v_opac"], unit["v_rgb"], unit["v_depth"])
+            w = np.asarray(m7[key], np.float64).reshape(N, -1)[:, c]
+            if acc is None:
+                acc = {k: np.zeros_like(col[k].reshape(N, -1)) for k in PARAM_KEYS}
+            for k in PARAM_KEYS:
+                acc[k] += np.abs(col[k].reshape(N, -1)) * w[:, None]
+    return acc
+
+
+def err_over_mass(got, ref, mass):
+    """Per Gaussian: max_c |got - ref| / max_c mass  (components of one gradient share their unit, and the kernels
+    form them from shared sums, so the Gaussian's largest component magnitude is the scale of all of them)."""
+    got, ref, mass = (np.asarray(a, np.float64).reshape(np.asarray(ref).shape[0], -1) for a in (got, ref, mass))
+    return np.abs(got - ref).max(1) / (mass.max(1) + 1e-300)

@@ -56,3 +56,33 @@ for key in ("v_rgb", "v_depth", "v_opac", "v_xy", "v_conic"):
         e = (np.abs(got - ref).max(1) / (nrm + 0.1 * typ))[clear]
         line += f"| {name}: q50 {np.median(e):.1e} q99 {np.quantile(e, 0.99):.1e} q99.99 {np.quantile(e, 0.9999):.1e} max {e.max():.1e} "
     print(line)
+# ---- error against the un-cancelled magnitude of each gradient (oracle: blend_bwd(mass=True)) ----
+bf64 = R64.blend_fwd(pc64["xy"], pc64["conic"], pc64["opac"], pc64["rgb"], pc64["depth"], g2, ts2, cb64, W, H)
+mass = R64.blend_bwd(pc64["xy"], pc64["conic"], pc64["opac"], pc64["rgb"], pc64["depth"], g2, ts2, cb64, W, H, bf64["final_T"], bf64["final_idx"], n64(v_rgb), n64(v_d), n64(v_a), mass=True)
+print("--- |HIP - oracle| / un-cancelled magnitude, clear Gaussians (margin > 1e-4 / > 1e-5 / all reaching):")
+for key in ("v_rgb", "v_depth", "v_opac", "v_xy", "v_conic"):
+    ref, m = out["f64"][key], np.asarray(mass[key], np.float64).reshape(N, -1)
+    assert (m >= np.abs(ref) * (1 - 1e-12)).all()
+    e = (np.abs(hip[key] - ref) / (m + 1e-300)).max(1)
+    line = f"{key:8s}"
+    for sel in (clear, (npix > 0) & (gmin > 1e-5), npix > 0):
+        v = e[sel]
+        line += f" | n {sel.sum()} q50 {np.median(v):.1e} q99.99 {np.quantile(v, 0.9999):.1e} max {v.max():.1e} n>1e-4 {int((v > 1e-4).sum())}"
+    print(line)
+# ---- K8 in isolation: the oracle's projection backward on HIP's own K7 output against HIP's K8 ----
+grads = ops.project_bwd(cam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], deg, sp, gb, partials)
+pb = R64.project_bwd(Pn["means"], Pn["log_scales"], Pn["quats"], Pn["opac_logit"], Pn["sh"], deg, cb64, W, H, pc64["radius"],
+                     hip["v_xy"], hip["v_conic"], hip["v_opac"][:, 0], hip["v_rgb"], hip["v_depth"][:, 0])
+print("--- K8 alone (oracle project_bwd fed HIP's K7 output), error / (per-Gaussian max-norm + 1e-3 typ), all Gaussians:")
+for name, got, key in zip(("means", "log_scales", "quats", "opac_logit", "sh"), grads[:5], ("v_means", "v_log_scales", "v_quats", "v_opac_logit", "v_sh")):
+    got = got.cpu().double().numpy().reshape(N, -1); ref = pb[key].reshape(N, -1)
+    nrm = np.abs(ref).max(1); typ = np.median(nrm[nrm > 0])
+    e = np.abs(got - ref).max(1) / (nrm + 1e-3 * typ)
+    vis = (pc64["radius"] > 0)
+    print(f"{name:11s} q50 {np.median(e[vis]):.1e} q99.99 {np.quantile(e[vis], 0.9999):.1e} max {e[vis].max():.1e} n>1e-4 {int((e[vis] > 1e-4).sum())}  (invisible: max |got| {np.abs(got[~vis]).max():.1e})")
+# ---- worst v_conic cases among the clear Gaussians ----
+ref, m = out["f64"]["v_conic"], np.asarray(mass["v_conic"], np.float64).reshape(N, -1)
+e = (np.abs(hip["v_conic"] - ref) / (m + 1e-300)).max(1) * clear
+for i in np.argsort(-e)[:8]:
+    print(f"g {i}: err/mass {e[i]:.2e} radius {pc64['radius'][i]} rect {pc64['rect'][i]} xy {pc64['xy'][i]} opac {pc64['opac'][i]:.4f} conic {pc64['conic'][i]} npix {npix[i]}\n"
+          f"     ref {ref[i]} hip {hip['v_conic'][i]} mass {m[i]}  v_opac ref {out['f64']['v_opac'][i]} hip {hip['v_opac'][i]}")
