@@ -120,6 +120,16 @@ class RefC:
                                          self._p(pm), C.c_double(near), self._p(out), self._p(npix))
         return out, npix
 
+    def pairs_max_alpha(self, gid, tile, xy, conic, opac, cam, W, H):
+        """-> max o*exp(-sigma) over the pixel centres of tile[k] for Gaussian gid[k], per pair."""
+        xy, conic, opac = map(self._r, (xy, conic, opac))
+        gid = np.ascontiguousarray(gid, np.int32)
+        tile = np.ascontiguousarray(tile, np.int32)
+        out = np.zeros(len(gid), self.dt)
+        self.lib.ref_pairs_max_alpha(C.c_int64(len(gid)), self._p(gid), self._p(tile), self._p(xy), self._p(conic),
+                                     self._p(opac), self._p(cam), C.c_int(W), C.c_int(H), self._p(out))
+        return out
+
     def blend_bwd(self, xy, conic, opac, rgb, depth, gid, ts, cam, W, H, final_T, final_idx,
                   v_rgb_img, v_depth_img, v_alpha_img, tile_range=None, mass=False):
         """B.7 -> per-Gaussian screen-space gradients; ``mass=True``: the un-cancelled magnitude of each of them

@@ -349,6 +349,28 @@ void ref_gaussian_min_margin(int N, const real *xy, const real *conic, const rea
     }
 }
 
+/* Test aid for the product's tile lists: the largest o*exp(-sigma) of Gaussian gid[k] over the pixel
+ * centres of tile tile[k], for a list of (tile, Gaussian) pairs -- the pairs of the oracle's normative lists
+ * that the product's lists do not hold.  Output preservation requires it to stay below 1/255. */
+void ref_pairs_max_alpha(int64_t n_pairs, const int32_t *gid, const int32_t *tile, const real *xy, const real *conic,
+                   const real *opac, const cam_t *cam, int W, int H, real *o_max_alpha) {
+    int TW = (W + BLK - 1) / BLK;
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int64_t k = 0; k < n_pairs; k++) {
+        int i = gid[k], ty = tile[k] / TW, tx = tile[k] % TW;
+        real best = 0;
+        for (int py = ty * BLK; py < (ty + 1) * BLK && py < H; py++)
+            for (int px = tx * BLK; px < (tx + 1) * BLK && px < W; px++) {
+                real dx = xy[2 * i] - (px + cam->pc), dy = xy[2 * i + 1] - (py + cam->pc);
+                real sig = (real)0.5 * (conic[3 * i] * dx * dx + conic[3 * i + 2] * dy * dy) + conic[3 * i + 1] * dx * dy;
+                if (sig < 0) continue;
+                real al = opac[i] * exp(-sig);
+                if (al > best) best = al;
+            }
+        o_max_alpha[k] = best;
+    }
+}
+
 /* B.7 backward blend.  v_rgb_img [H,W,3], v_depth_img [H,W] (w.r.t. depth_acc), v_alpha_img [H,W].
  * Accumulates (+=) into v_xy [N,2], v_conic [N,3], v_opac [N], v_rgb [N,3], v_depth [N] (caller zeroes). */
 void ref_blend_bwd_range(const real *xy, const real *conic, const real *opac, const real *rgb, const real *depth,

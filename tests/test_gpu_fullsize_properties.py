@@ -17,9 +17,10 @@ def frame(dev):
     cam = make_camera(intr, 0, 8, bg=(0.1, 0.2, 0.3))
     sp, radii, gb, ts, sg, st = ops.project_bin_sort(cam, D["means"], D["log_scales"], D["quats"], D["opac_logit"],
                                                      D["sh"], DEG, want_radii=True)
-    n = st.tolist()[0]
+    n = int(ts[-1])                 # total length of the tile lists
+    assert n == st.tolist()[0]
     rgb, depth, fT, fidx = ops.rasterize_fwd(cam, sp, sg, ts, want_idx=True)
-    return dict(D=D, cam=cam, sp=sp, radii=radii, gb=gb, ts=ts, sg=sg, n=n, rgb=rgb, depth=depth, fT=fT, fidx=fidx)
+    return dict(D=D, cam=cam, sp=sp, radii=radii, gb=gb, ts=ts, sg=sg, n=n, n_index=st.tolist()[0], rgb=rgb, depth=depth, fT=fT, fidx=fidx)
 
 
 def test_tile_lists_sorted_and_complete(frame):

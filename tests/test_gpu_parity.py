@@ -83,7 +83,7 @@ def _blend_inputs(dev, N, W, H, deg, seed, clamp=False, **kw):
     D, sp, _ = _project(dev, P, cam, deg)
     acam = amd_cam(cam)
     gb, ts, sg, st = ops.bin_sort(acam, sp)
-    n = st.tolist()[0]
+    n = int(ts[-1])      # total length of the tile lists
     return P, cam, acam, D, sp, gb, ts, sg, n
 
 
@@ -492,9 +492,9 @@ def test_fused_project_bin_sort_equals_separate_calls(dev):
         gb1, ts1, sg1, st1 = ops.bin_sort(acam, sp1)
         sp2, r2, gb2, ts2, sg2, st2 = ops.project_bin_sort(acam, D["means"], D["log_scales"], D["quats"], D["opac_logit"],
                                                             D["sh"], deg, want_radii=True)
-        n = st1.tolist()[0]
-        assert st2.tolist() == [n, 0] and torch.equal(r1, r2) and torch.equal(ts1, ts2)
-        assert torch.equal(sg1[:n], sg2[:n])
+        n = int(ts1[-1])
+        assert st2.tolist() == st1.tolist() and st1.tolist()[1] == 0 and torch.equal(r1, r2) and torch.equal(ts1, ts2)
+        assert 0 < n <= st1.tolist()[0] and torch.equal(sg1[:n], sg2[:n])
         assert torch.equal(sp1.view(torch.int32), sp2.view(torch.int32))  # records incl. rect + in-group offset
 
 

@@ -334,7 +334,7 @@ def rasterize_fwd(cam: Camera, splats, sorted_gid, tile_start, want_idx: bool = 
 
 def rasterize_bwd(cam: Camera, splats, group_base, sorted_gid, tile_start, rgb, depth, fT,
                   v_rgb=None, v_depth=None, v_alpha=None, loss: Optional[dict] = None,
-                  want_tile_loss: bool = False, stop_pos=None):
+                  want_tile_loss: bool = False, stop_pos=None, partials=None):
     """K7 -> (partials [cap,12], tile_loss [T,2] or None).  (tgs_rasterize_bwd)
 
     ``loss`` = dict(gt_rgb, gt_depth, uncertainty, l1_weight, depth_weight, uncertainty_weight, eps).
@@ -342,7 +342,8 @@ def rasterize_bwd(cam: Camera, splats, group_base, sorted_gid, tile_start, rgb, 
     """
     lib = _lib.load()
     dev = splats.device
-    partials = torch.empty(sorted_gid.shape[0], PARTIAL_FLOATS, dtype=torch.float32, device=dev)
+    if partials is None:     # (a caller may hand in the buffer, e.g. pre-filled to detect reads of unwritten records)
+        partials = torch.empty(sorted_gid.shape[0], PARTIAL_FLOATS, dtype=torch.float32, device=dev)
     tile_loss = torch.empty(cam.num_tiles, 2, dtype=torch.float32, device=dev) if want_tile_loss else None
     cs = cam.c_struct()
     ls = None

@@ -271,9 +271,9 @@ class GradSync:
         n = self.world
         tg, tr = begun.elapsed_time(gathered) * 1e-3, gathered.elapsed_time(reduced) * 1e-3
         return {"all_gather_ms": round(tg * 1e3, 4), "all_gather_bytes_per_rank": block_bytes,
-                "all_gather_busbw_GBs": round(block_bytes * n * (n - 1) / n / tg / 1e9, 1),
+                "all_gather_busbw_GBs": round(block_bytes * n * (n - 1) / n / tg / 1e9, 3),
                 "all_reduce_ms": round(tr * 1e3, 4), "all_reduce_bytes": geom_bytes,
-                "all_reduce_busbw_GBs": round(geom_bytes * 2 * (n - 1) / n / tr / 1e9, 1)}
+                "all_reduce_busbw_GBs": round(geom_bytes * 2 * (n - 1) / n / tr / 1e9, 3)}
 
     def barrier(self):
         if self.active:
