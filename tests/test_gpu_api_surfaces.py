@@ -435,6 +435,44 @@ def test_spherical_harmonics_op_matches_oracle(deg, stride):
 
 
 @pytest.mark.gpu
+def test_resolution_schedule_equals_training_on_downscaled_views(dev):
+    """Splatfacto's coarse-to-fine schedule (ModelConfig.num_downscales / resolution_schedule): the
+    step at downscale factor d is bit for bit the step of a schedule-free model on ``view.downscaled(d)`` (camera
+    intrinsics / d, sides floored, colour image bilinear, depth and uncertainty nearest so that 0 stays
+    "unsupervised"), the factor follows 2^max(n - step // every, 0), under the speculative budget a replayed step is
+    downscaled once, and evaluation renders stay at full resolution."""
+    from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
+    from touch_gs_amd.optim import GaussianParams
+    from touch_gs_amd.scene import make_view, synthetic_gaussians
+    N, W, H, deg = 4000, 200, 120, 1
+    views = [make_view(N, W, H, deg, 17, dev, view=v, n_views=4) for v in range(4)]
+    P, _ = synthetic_gaussians(N, W, H, deg, 18)
+
+    def fresh(**kw):
+        params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
+        return DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=0, **kw), params)
+
+    v2 = views[0].downscaled(2)
+    assert v2.rgb.shape == (60, 100, 3) and v2.depth.shape == (60, 100) and v2.cam.W == 100 and abs(v2.cam.fx - views[0].cam.fx / 2) < 1e-9
+    assert v2 is views[0].downscaled(2) and views[0].downscaled(1) is views[0]
+    assert set(torch.unique(v2.depth).tolist()) <= set(torch.unique(views[0].depth).tolist())   # nearest: no invented depths
+    cfg = ModelConfig(num_downscales=2, resolution_schedule=3)
+    assert [cfg.downscale_factor(s) for s in (0, 2, 3, 5, 6, 100)] == [4, 4, 2, 2, 1, 1]
+    a, b = fresh(num_downscales=2, resolution_schedule=3), fresh()
+    a.enable_speculative_budget(capacity=2000)        # too small: the first steps overflow and are replayed
+    shapes = []
+    for s in range(8):
+        v = views[s % 4]
+        a.train_step(v, next_view=views[(s + 1) % 4])
+        b.train_step(v.downscaled(cfg.downscale_factor(s)))
+        shapes.append(tuple(a.last["rgb"].shape[:2]))
+    a.flush()
+    assert getattr(a, "speculative_replays", 0) > 0
+    assert shapes == [(30, 50)] * 3 + [(60, 100)] * 3 + [(120, 200)] * 2, shapes
+    assert torch.equal(a.params.flat, b.params.flat)
+    assert a.get_outputs(views[0].cam)["rgb"].shape == (H, W, 3)
+
+
 @pytest.mark.parametrize("deg,interval", [(3, 0), (1, 0), (3, 1000)])
 def test_gathered_sh_adam_equals_dense_adam_single_rank(dev, deg, interval):
     """world = 1: tgs_project_bwd_color + tgs_adam_step_sh_gathered + geometry tgs_adam_step equals
@@ -991,11 +1029,13 @@ def _nerfstudio_stub():
             i_train = np.linspace(0, n - 1, n_train, dtype=int)
             idx = i_train if split == "train" else np.setdiff1d(np.arange(n), i_train)
             c2w = torch.tensor(np.stack([np.asarray(fr["transform_matrix"], np.float64) for fr in frames]))
-            c2w[:, :3, 3] -= c2w[:, :3, 3].mean(0)
+            centre = c2w[:, :3, 3].mean(0)
+            c2w[:, :3, 3] -= centre
             scale = 1.0 / float(c2w[:, :3, 3].abs().max())
             c2w[:, :3, 3] *= scale
             sel = [frames[i] for i in idx]
             return DataparserOutputs(
+                dataparser_transform=torch.cat([torch.eye(3, dtype=torch.float64), -centre[:, None]], 1).float(),
                 image_filenames=[os.path.join(root, fr["file_path"]) for fr in sel],
                 cameras=BatchCameras(c2w[idx][:, :3, :].float(), meta["fl_x"], meta["fl_y"], meta["cx"], meta["cy"], meta["w"], meta["h"]),
                 dataparser_scale=scale,
@@ -1106,6 +1146,8 @@ def test_nerfstudio_plugin_shell_executes_against_a_stub(dev):
         view = make_view(N, W, H, 3, 5, dev)
         P, _ = synthetic_gaussians(N, W, H, 3, 99)
         mc.depth_loss_mult, mc.uncertainty_weight = 0.005, 0.01          # scripts/train_bunny_real.sh:52
+        assert (mc.num_downscales, mc.resolution_schedule) == (2, 250)   # Splatfacto's defaults
+        mc.num_downscales = 0                                            # (the schedule is exercised by the on-disk test below)
         model = mc.setup(scene_box=None, num_train_data=1, seed_points=(P["means"], torch.rand(N, 3) * 255))
         groups = model.get_param_groups()
         assert set(groups) == set(plug.PARAM_GROUP_LRS)
@@ -1174,13 +1216,24 @@ def test_nerfstudio_plugin_trains_with_touch_supervision_from_disk(dev, tmp_path
 
         mc = spec.config.pipeline.model
         mc.sh_degree, mc.sh_degree_interval = deg, 4
+        mc.num_downscales, mc.resolution_schedule = 1, 4                 # Splatfacto's schedule: half resolution for 4 steps
         mc.depth_loss_mult, mc.uncertainty_weight = 0.005, 0.01          # scripts/train_bunny_real.sh:52
         mc.warmup_length, mc.refine_every, mc.densify_grad_thresh = 4, 4, 1e-7   # refine early, on any gradient
+        # the dataparser delivers the scene's touch point cloud (points_touch.npy / points_colors.npy, reference
+        # utils/create_point_cloud_from_touches.py:243-244) in ITS frame, and the pipeline hands it to the model as
+        # seed_points -- exactly what nerfstudio's VanillaPipeline does with metadata["points3D_xyz" / "points3D_rgb"]
+        md = outs.metadata
         seeds = torch.from_numpy(np.load(root / "points_touch.npy")).float()
         centre = torch.tensor(np.stack([np.asarray(f["transform_matrix"])[:3, 3] for f in
                                         __import__("json").load(open(root / "transforms.json"))["frames"]]).mean(0)).float()
-        pts = (torch.cat([seeds, (torch.rand(2000, 3) - 0.5) * 3 + torch.tensor([0, 0, 4.0])]) - centre) * sc
-        model = mc.setup(scene_box=None, num_train_data=5, seed_points=(pts, torch.rand(pts.shape[0], 3) * 255))
+        assert md["points3D_xyz"].shape == (200, 3) and md["points3D_rgb"].dtype == torch.uint8
+        assert torch.allclose(md["points3D_xyz"], (seeds - centre) * sc, atol=1e-5)
+        assert torch.equal(md["points3D_rgb"], torch.from_numpy(np.load(root / "points_colors.npy")).float().clamp(0, 255).to(torch.uint8))
+        model = mc.setup(scene_box=None, num_train_data=5, seed_points=(md["points3D_xyz"], md["points3D_rgb"]))
+        assert model.gaussians.num_points == 200          # the model starts from exactly the touch points
+        assert torch.allclose(model.gaussians.params["xyz"].detach().cpu(), md["points3D_xyz"], atol=1e-6)
+        dc = model.gaussians.params["features_dc"].detach().cpu()[:, 0] * 0.28209479177387814 + 0.5
+        assert torch.allclose(dc, md["points3D_rgb"].float() / 255.0, atol=1e-5)
         groups = model.get_param_groups()
         opts = {k: torch.optim.Adam(v, lr=spec.config.optimizers[k]["optimizer"].lr * 10, eps=1e-15) for k, v in groups.items()}
 
@@ -1197,6 +1250,8 @@ def test_nerfstudio_plugin_trains_with_touch_supervision_from_disk(dev, tmp_path
             cam, batch = dm.next_train(step)
             batch = {k: (v.to(dev) if hasattr(v, "to") else v) for k, v in batch.items()}
             out = model.get_outputs(cam)
+            d = 2 if step < 4 else 1                                    # resolution schedule (supervision follows the render)
+            assert out["rgb"].shape == (H // d, W // d, 3) and out["depth"].shape == (H // d, W // d, 1), (step, out["rgb"].shape)
             ld = model.get_loss_dict(out, batch)
             depth_losses.append(float(ld["depth_loss"]))
             degs.append(model.gaussians.active_sh_degree())

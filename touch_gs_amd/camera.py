@@ -41,6 +41,14 @@ class Camera:
         m[:3, 1:3] *= -1.0  # OpenGL (y up, -z forward) -> OpenCV
         return Camera(np.linalg.inv(m), fx, fy, cx, cy, W, H, **kw)
 
+    def downscaled(self, d: int) -> "Camera":
+        """The camera of the image downscaled by the integer factor ``d`` (Splatfacto's resolution schedule;
+        nerfstudio ``Cameras.rescale_output_resolution(1 / d)``: focal lengths and principal point / d, sides floored)."""
+        if d <= 1:
+            return self
+        return dataclasses.replace(self, fx=self.fx / d, fy=self.fy / d, cx=self.cx / d, cy=self.cy / d,
+                                   W=self.W // d, H=self.H // d)
+
     @property
     def tiles(self):
         return (self.W + 15) // 16, (self.H + 15) // 16

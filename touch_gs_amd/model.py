@@ -48,6 +48,11 @@ class ModelConfig:
     uncertainty_weight: float = 1.0
     depth_eps: float = 1e-6
     sh_degree_interval: int = 1000
+    # Splatfacto's coarse-to-fine schedule (num_downscales 2, resolution_schedule 250): training
+    # starts on images downscaled by 2^num_downscales and doubles the resolution every resolution_schedule steps.
+    # 0 = always full resolution (the default of this library's ops and of bench.py; the trainers set 2 / 250)
+    num_downscales: int = 0
+    resolution_schedule: int = 250
     background_color: tuple = (0.0, 0.0, 0.0)
     # Adam learning rates per group (Splatfacto defaults)
     lr_means: float = 1.6e-4
@@ -65,6 +70,12 @@ class ModelConfig:
     spatial_sort: bool = False
     # full Morton re-sort every this many refinements (in between, refine() keeps children next to parents)
     resort_every_refines: int = 10
+
+    def downscale_factor(self, step: int) -> int:
+        """2 ** max(num_downscales - step // resolution_schedule, 0)  (Splatfacto._get_downscale_factor)."""
+        if self.num_downscales <= 0 or self.resolution_schedule <= 0:
+            return 1
+        return 2 ** max(self.num_downscales - step // self.resolution_schedule, 0)
 
     def lr_means_at(self, step: int) -> float:
         """ExponentialDecay schedule: lr_init * (lr_final / lr_init) ** min(step / max_steps, 1)."""
@@ -101,6 +112,24 @@ class View:
         if self.n_valid_depth is None:
             self.n_valid_depth = int((self.depth > 0).sum().item()) if self.depth is not None else 0
         return self.n_valid_depth
+
+    def downscaled(self, d: int) -> "View":
+        """This view at 1/d of its resolution (cached): the colour image resized bilinearly to (H // d, W // d) --
+        what Splatfacto's ``_downscale_if_required`` does (torchvision resize of a tensor, no antialiasing) --
+        depth and uncertainty by nearest neighbour, so that 0 stays "unsupervised" and no depth is invented across
+        an object boundary; camera as ``Camera.downscaled``."""
+        if d <= 1:
+            return self
+        cache = self.__dict__.setdefault("_downscaled", {})
+        if d not in cache:
+            H, W = self.rgb.shape[0] // d, self.rgb.shape[1] // d
+            F = torch.nn.functional
+            rgb = F.interpolate(self.rgb.permute(2, 0, 1)[None], size=(H, W), mode="bilinear", align_corners=False,
+                                antialias=False)[0].permute(1, 2, 0).contiguous()
+            near = lambda t: None if t is None else F.interpolate(t[None, None].float(), size=(H, W), mode="nearest")[0, 0].to(t.dtype).contiguous()
+            cache[d] = View(cam=self.cam.downscaled(d), rgb=rgb, depth=near(self.depth), uncertainty=near(self.uncertainty),
+                            gt_depth=near(self.gt_depth), object_mask=near(self.object_mask))
+        return cache[d]
 
 
 class DepthGaussianSplattingModel:
@@ -272,7 +301,7 @@ class DepthGaussianSplattingModel:
             v_xy = ops.project_bwd(cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, splats,
                                    group_base, partials, out=p.grad_views(), want_v_xy=want_v_xy, guard=guard)[5]
         self.last = dict(rgb=rgb, depth_acc=depth_acc, final_T=fT, splats=splats, v_xy=v_xy, radii=radii,
-                         tile_loss=tile_loss, ssim_sum=ssim_sum, status=status, guard=guard)
+                         tile_loss=tile_loss, ssim_sum=ssim_sum, status=status, guard=guard, view=view)
         return tile_loss, ssim_sum
 
     def loss_from(self, tile_loss, ssim_sum, view: View) -> Dict[str, torch.Tensor]:
@@ -429,6 +458,11 @@ class DepthGaussianSplattingModel:
         distributed = dp is not None and dp.active
         opt = self.optimizer
         opt.lrs["means"] = self.config.lr_means_at(self.step)   # scheduled position learning rate
+        full_view = view    # what the speculative budget replays (the schedule is applied again on the replay)
+        if self.config.num_downscales > 0:   # coarse-to-fine: this step (and the announced next one) at their resolutions
+            view = view.downscaled(self.config.downscale_factor(self.step))
+            if next_view is not None:
+                next_view = next_view.downscaled(self.config.downscale_factor(self.step + 1))
         deg = self.active_sh_degree()
         pre, self._prefetch_ready = getattr(self, "_prefetch_ready", None), None
         graphs = getattr(self, "_graphs", None)
@@ -536,7 +570,7 @@ class DepthGaussianSplattingModel:
             self.optimizer.step(guard=self.last["guard"])
         self.step += 1
         if self.budget.speculative:
-            self._speculative_track(view, distributed)
+            self._speculative_track(full_view, distributed)
         if density is not None and density.due(self.step) and getattr(self, "_refined_at", None) != self.step:
             if self.budget.speculative:
                 # barrier: settle every pending overflow verdict first (a drain that finds one replays the

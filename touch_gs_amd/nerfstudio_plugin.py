@@ -103,6 +103,26 @@ def load_supervision_maps(depth_path, uncertainty_path, H: int, W: int, depth_un
     return out[0], out[1]
 
 
+def load_touch_seed_points(data_dir: str, transform=None, scale: float = 1.0):
+    """The touch point cloud the reference's pipeline writes to seed the Gaussians -- ``points_touch.npy`` [M,3] and
+    ``points_colors.npy`` [M,3] in 0..255 (utils/create_point_cloud_from_touches.py:243-244; colours x 255 at :171)
+    -- moved into the dataparser's frame exactly as nerfstudio moves a COLMAP point cloud: homogeneous points times
+    ``dataparser_transform`` (3x4), then times ``dataparser_scale``.  -> (xyz float32 [M,3], rgb float32 [M,3] in
+    0..255) or None if the scene has no seed files.  (touch_gs_amd.dataset.Scene.seed_points is the same for the
+    self-contained trainer.)"""
+    import os
+    import numpy as np
+    p, c = os.path.join(data_dir, "points_touch.npy"), os.path.join(data_dir, "points_colors.npy")
+    if not (os.path.exists(p) and os.path.exists(c)):
+        return None
+    xyz = np.load(p).astype(np.float64).reshape(-1, 3)
+    rgb = np.load(c).astype(np.float32).reshape(-1, 3)
+    if transform is not None:
+        T = np.asarray(transform, dtype=np.float64).reshape(-1, 4)[:3]
+        xyz = xyz @ T[:, :3].T + T[:, 3]
+    return (xyz * float(scale)).astype(np.float32), rgb
+
+
 class AutogradGaussians:
     """What a nerfstudio ``Model`` needs from this library, free of nerfstudio imports so that it is
     exercised by the GPU tests: the Gaussian parameters as six ``torch.nn.Parameter`` groups (the
@@ -137,6 +157,11 @@ class AutogradGaussians:
         self.sh_degree = config.sh_degree
         # Splatfacto's SH ramp: one more band every `sh_degree_interval` steps (0 = full degree at once)
         self.sh_degree_interval = int(getattr(config, "sh_degree_interval", 0) or 0)
+        # Splatfacto's resolution schedule: render and supervise at 1 / 2^(num_downscales - step //
+        # resolution_schedule) of the camera's resolution; evaluation always at full resolution
+        self.num_downscales = int(getattr(config, "num_downscales", 0) or 0)
+        self.resolution_schedule = int(getattr(config, "resolution_schedule", 250) or 0)
+        self.training = True
         self.step = 0
         self.track_xy_grad = False      # set by ParamGroupRefiner: render() then keeps the screen-space gradient
         self.last_xy = self.last_radii = self.last_wh = None
@@ -153,10 +178,16 @@ class AutogradGaussians:
             return self.sh_degree
         return min(self.step // self.sh_degree_interval, self.sh_degree)
 
+    def downscale_factor(self) -> int:
+        if not self.training or self.num_downscales <= 0 or self.resolution_schedule <= 0:
+            return 1
+        return 2 ** max(self.num_downscales - self.step // self.resolution_schedule, 0)
+
     def render(self, cam, sh_degree=None):
         import torch
         from . import ops
         p = self.params
+        cam = cam.downscaled(self.downscale_factor())
         sh = torch.cat([p["features_dc"], p["features_rest"]], dim=1)
         xy = None
         if self.track_xy_grad and torch.is_grad_enabled():
@@ -174,10 +205,18 @@ class AutogradGaussians:
     @staticmethod
     def view_from_batch(batch, like):
         """nerfstudio batch -> View: depth_image / uncertainty arrive as [H,W,1]."""
+        import torch
         from .model import View
-        sq = lambda t: None if t is None else t.to(like.device).reshape(like.shape[0], like.shape[1]).float()
-        return View(cam=None, rgb=batch["image"].to(like).float(), depth=sq(batch.get("depth_image")),
-                    uncertainty=sq(batch.get("uncertainty")))
+        H, W = like.shape[0], like.shape[1]
+        img = batch["image"].to(like).float()
+        sq = lambda t: None if t is None else t.to(like.device).reshape(t.shape[0], t.shape[1]).float()
+        d, u = sq(batch.get("depth_image")), sq(batch.get("uncertainty"))
+        if img.shape[0] != H or img.shape[1] != W:   # the render is downscaled (resolution schedule): so is the supervision
+            F = torch.nn.functional
+            img = F.interpolate(img.permute(2, 0, 1)[None], size=(H, W), mode="bilinear", align_corners=False)[0].permute(1, 2, 0).contiguous()
+            near = lambda t: None if t is None else F.interpolate(t[None, None], size=(H, W), mode="nearest")[0, 0].contiguous()
+            d, u = near(d), near(u)
+        return View(cam=None, rgb=img, depth=d, uncertainty=u)
 
     def loss_dict(self, outputs, batch):
         return self.core.get_loss_dict(outputs, self.view_from_batch(batch, outputs["rgb"]))
@@ -262,7 +301,11 @@ class ParamGroupRefiner:
                 o = optimizers[grp]
                 o.state.pop(old, None)
                 st = {"exp_avg": m.clone().contiguous().view_as(newp), "exp_avg_sq": v.clone().contiguous().view_as(newp)}
-                st["step"] = steps[grp] if steps[grp] is not None else torch.tensor(0.0)
+                if steps[grp] is not None:
+                    st["step"] = steps[grp]
+                else:   # a capturable / fused torch Adam keeps `step` on the parameter's device
+                    on_dev = any(pg.get("capturable") or pg.get("fused") for pg in o.param_groups)
+                    st["step"] = torch.zeros((), dtype=torch.float32, device=newp.device if on_dev else "cpu")
                 o.state[newp] = st
                 for pg in o.param_groups:
                     pg["params"] = [newp if q is old else q for q in pg["params"]]
@@ -312,12 +355,23 @@ if available:  # pragma: no cover
             md["uncertainty_filenames"] = [r[1] for r in rows] if any(r[1] for r in rows) else None
             md.setdefault("depth_unit_scale_factor", self.config.depth_unit_scale_factor)
             md["uncertainty_scaling"] = self.config.uncertainty_scaling
+            # the touch point cloud is what seeds the model (the Touch-GS scenes have no COLMAP ply for
+            # load_3D_points to find): nerfstudio hands metadata["points3D_xyz"/"points3D_rgb"] to the model as
+            # `seed_points`
+            if md.get("points3D_xyz") is None:
+                import torch
+                seeds = load_touch_seed_points(str(self.config.data), getattr(out, "dataparser_transform", None),
+                                               getattr(out, "dataparser_scale", 1.0))
+                if seeds is not None:
+                    md["points3D_xyz"] = torch.from_numpy(seeds[0])
+                    md["points3D_rgb"] = torch.from_numpy(seeds[1]).clamp(0, 255).to(torch.uint8)
             return out
 
     class TactileDepthDataset(InputDataset):
         """InputDataset + ``depth_image`` / ``uncertainty`` [H,W,1] per frame (what nerfstudio's
         DepthDataset does for depth, config_tactile.py:33, extended to the second map)."""
-        exclude_batch_keys_from_device = list(InputDataset.exclude_batch_keys_from_device) + ["depth_image", "uncertainty"]
+        # depth_image / uncertainty are NOT excluded from the datamanager's host-to-device move: they are read by
+        # every loss / metrics call (ADVICE r3)
 
         def __init__(self, dataparser_outputs, scale_factor: float = 1.0):
             super().__init__(dataparser_outputs, scale_factor)
@@ -356,6 +410,8 @@ if available:  # pragma: no cover
         sh_degree_interval: int = 1000
         ssim_lambda: float = 0.2
         num_random: int = 50000
+        num_downscales: int = 2            # Splatfacto's coarse-to-fine schedule
+        resolution_schedule: int = 250
         # refinement (Splatfacto defaults)
         refine: bool = True
         warmup_length: int = 500
@@ -416,6 +472,7 @@ if available:  # pragma: no cover
                                           float(camera.cy[0]), int(camera.width[0]), int(camera.height[0]))
 
         def get_outputs(self, camera):
+            self.gaussians.training = bool(self.training)     # nn.Module flag: eval renders at full resolution
             return self.gaussians.render(self._camera(camera))
 
         def get_loss_dict(self, outputs, batch, metrics_dict=None):

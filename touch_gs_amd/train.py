@@ -114,6 +114,9 @@ def main(argv=None):
     ap.add_argument("--densify", dest="densify", action="store_true", default=True,
                     help="Splatfacto-style clone/split/cull refinement (default: on, as in the method the reference trains)")
     ap.add_argument("--no-densify", dest="densify", action="store_false", help="fixed set of Gaussians")
+    ap.add_argument("--num-downscales", type=int, default=2,
+                    help="Splatfacto's coarse-to-fine schedule: start at 1/2^n resolution (default 2; 0 = off)")
+    ap.add_argument("--resolution-schedule", type=int, default=250, help="double the resolution every this many steps")
     ap.add_argument("--refine-every", type=int, default=100)
     ap.add_argument("--warmup-length", type=int, default=500)
     args = ap.parse_args(argv)
@@ -138,15 +141,30 @@ def main(argv=None):
         scene_name = os.path.basename(os.path.normpath(args.data))
     cfg = ModelConfig(sh_degree=args.sh_degree, depth_loss_mult=args.depth_loss_mult,
                       depth_loss_type=args.depth_loss_type, uncertainty_weight=args.uncertainty_weight,
-                      spatial_sort=not args.no_spatial_sort)
+                      spatial_sort=not args.no_spatial_sort, num_downscales=args.num_downscales,
+                      resolution_schedule=args.resolution_schedule)
     model = DepthGaussianSplattingModel(cfg, params)
     if cfg.spatial_sort:
         model.spatial_sort()
     if args.densify:
         from .densify import DensifyConfig
         model.enable_densification(DensifyConfig(refine_every=args.refine_every, warmup_length=args.warmup_length))
+    trainer_state = dict(uncertainty_scaling=args.uncertainty_scaling, densify=bool(args.densify),
+                         num_downscales=args.num_downscales)
     if args.load_checkpoint:
-        model.load_state_dict(torch.load(args.load_checkpoint, map_location=dev))
+        sd = torch.load(args.load_checkpoint, map_location=dev)
+        model.load_state_dict(sd)
+        # the defaults of these three changed between rounds (uncertainty maps linear instead of squared, densification
+        # and the resolution schedule on by default): resuming under different settings silently trains a different
+        # objective, so the checkpoint records them and a mismatch is reported
+        was = sd.get("trainer")
+        if was is None:
+            print("warning: the checkpoint predates the recorded trainer settings; this run uses "
+                  f"{trainer_state} -- pass the flags of the original run explicitly if they differed", flush=True)
+        else:
+            for k, v in trainer_state.items():
+                if k in was and was[k] != v:
+                    print(f"warning: checkpoint was trained with {k}={was[k]!r}, this run uses {k}={v!r}", flush=True)
     run_dir = os.path.join(args.output_dir, scene_name, "depth-gaussian-splatting", time.strftime("%Y-%m-%d_%H%M%S"))
     if dp.rank == 0:
         os.makedirs(run_dir, exist_ok=True)
@@ -177,11 +195,11 @@ def main(argv=None):
             # collectives unmatched (and break "every rank inspects step s - L at step s")
             model.flush()
         if dp.rank == 0 and at_eval:
-            loss = model.loss_from(model.last["tile_loss"], model.last["ssim_sum"], view)
+            loss = model.loss_from(model.last["tile_loss"], model.last["ssim_sum"], model.last["view"])
             print(f"step {step + 1}: " + " ".join(f"{k}={float(v):.5f}" for k, v in loss.items()) +
                   f"  {(step + 1 - 0) / (time.time() - t0):.1f} it/s", flush=True)
         if dp.rank == 0 and at_save:
-            torch.save(model.state_dict(), os.path.join(run_dir, f"step-{step + 1:09d}.ckpt"))
+            torch.save(dict(model.state_dict(), trainer=trainer_state), os.path.join(run_dir, f"step-{step + 1:09d}.ckpt"))
     model.flush()
     if dp.world > 1:
         dp.assert_replicas_identical(model.params.flat)
