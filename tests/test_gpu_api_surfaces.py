@@ -1492,6 +1492,90 @@ if dp.rank == 0: print("DP4_OK", d)
 '''
 
 
+_DP_FULL_WORKER = r'''
+import json, os, sys, time, torch
+sys.path.insert(0, sys.argv[1])
+from touch_gs_amd import parallel
+from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
+from touch_gs_amd.optim import GaussianParams
+from touch_gs_amd.scene import make_view, synthetic_gaussians
+N, W, H, seed, steps = (int(v) for v in sys.argv[2:7])
+deg = 3
+dp = parallel.init_from_env(backend="gloo")           # all ranks share the single GPU of the test box
+world = dp.world
+dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+views = [make_view(N, W, H, deg, seed, dev, view=v, n_views=8) for v in range(8)]
+P, _ = synthetic_gaussians(N, W, H, deg, seed)
+def fresh():
+    params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
+    m = DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=0), params)
+    m.spatial_sort()
+    return m
+m = fresh()
+m.enable_speculative_budget()                         # the trainer's default: no read-back of the intersection count
+assert dp.color_chunks == (4 if world >= 4 else 1)    # pipelined exchange: the trainer's default from 4 ranks on
+t0 = time.time()
+for step in range(steps):                             # the rank's next view is announced: front prefetch of the DP step
+    m.train_step(views[dp.views_for_step(step, 8)], dp, next_view=views[dp.views_for_step(step + 1, 8)])
+m.flush()
+torch.cuda.synchronize()
+t_dp = time.time() - t0
+dp.assert_replicas_identical(m.params.flat)           # bit for bit on every rank
+stats = None
+if dp.rank == 0:
+    ref = fresh()                                     # a single process that averages the ranks' views by hand
+    for step in range(steps):
+        ref.optimizer.lrs["means"] = ref.config.lr_means_at(step)
+        g = torch.zeros_like(ref.params.grad)
+        for r in range(world):
+            ref.forward_backward(views[(step * world + r) % 8])
+            g += ref.params.grad
+        ref.params.grad.copy_(g / world)
+        ref.optimizer.step()
+    torch.cuda.synchronize()
+    d = (ref.params.flat - m.params.flat).abs()
+    moved = (ref.params.flat - fresh().params.flat).abs() > 0
+    stats = dict(world=world, N=N, replays=getattr(m, "speculative_replays", 0), seconds=round(t_dp, 1),
+                 moved=float(moved.float().mean()), q999=float(torch.quantile(d[::max(7, d.numel() // 8_000_000)].float(), 0.999)),
+                 frac_gt_1e5=float((d > 1e-5).float().mean()), max=float(d.max()),
+                 front_prefetch=bool(m._prefetch_ready is not None and m._prefetch_ready.front_issued))
+dp.barrier()
+if stats is not None: print("DPFULL " + json.dumps(stats), flush=True)
+'''
+
+
+@pytest.mark.parametrize("world,N,W,H,seed", [(4, 1_000_000, 1920, 1080, 1236), (8, 5_000_000, 3840, 2160, 1238)])
+def test_data_parallel_fullsize(dev, tmp_path, world, N, W, H, seed):
+    """BASELINE configs[3] (a batch of 4 views of the 1 M / 1080p scene on 4 ranks) and the data-parallel part of
+    configs[4] (5 M Gaussians, SH 3, 4K, 8 ranks) at FULL size: the ranks share the one GPU of the test box over gloo
+    (the exchange logic, chunking and kernels are the ones that run over RCCL; only the transport differs).  Two
+    steps of the trainer's default data-parallel form -- pipelined factored exchange in 4 row chunks, sync-free
+    intersection budget, the rank's next view announced (front prefetch inside the geometry Adam) -- leave every
+    replica bit-identical and agree with a single process that averages the ranks' gradients by hand.  The
+    agreement is statistical, as in the miniature: a sum over ranks is not order-identical to the sequential sum and
+    Adam's first steps are lr * sign(g), so a 1-ulp difference in a near-zero gradient flips a whole step."""
+    import json, os, subprocess, sys
+    if torch.cuda.mem_get_info()[1] < 150e9:
+        pytest.skip("needs a 288 GB MI355X: 8 replicas of the 5 M scene share the device")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "dp_full_worker.py"
+    script.write_text(_DP_FULL_WORKER)
+    port = str(29680 + world)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script), root,
+                        str(N), str(W), str(H), str(seed), "2"],
+                       env=env, capture_output=True, text=True, timeout=2400)
+    line = [l for l in r.stdout.splitlines() if l.startswith("DPFULL ")]
+    assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-4000:]
+    st = json.loads(line[-1][7:])
+    print(st)
+    assert st["world"] == world and st["front_prefetch"] and st["moved"] > 0.5
+    # measured (r4): 4 x 1 M: q99.9 of |difference| 3.7e-9, 1.0e-7 of the entries differ by more than 1e-5, max 8.6e-5;
+    # 8 x 5 M: 3.0e-8, 2.3e-7, 2.8e-4.  (A flipped first Adam step would be 2 lr <= 0.1, opacity logit.)
+    assert st["q999"] < 1e-6 and st["frac_gt_1e5"] < 1e-5 and st["max"] < 0.11, st
+
+
 def test_data_parallel_four_ranks_batch_of_four(dev, tmp_path):
     """BASELINE configs[3] in miniature: a batch of 4 views, one per rank, 4 ranks (sharing the one GPU
     of the test box, gloo): the factored exchange equals a single process that averages the 4 views'
