@@ -413,6 +413,33 @@ int tgs_ssim_fwd_bwd_rows(int W, int H, const float* img, const float* gt, float
                           float* block_partials, int n_partials, float* v_img, float* scratch,
                           int y0, int y1, int count_y0, int count_y1, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Peer exchange: the data-parallel gradient exchange by direct stores into IPC-mapped peer memory (all 7 xGMI
+ * links of a rank at once, no collective launch) -- the alternative to RCCL that touch_gs_amd.parallel selects
+ * with TGS_DP_TRANSPORT=ipc (csrc/peer.hip).  The reference has no counterpart (single GPU).
+ * tgs_peer_alloc: `bytes` of zeroed, uncached device memory + its 64-byte IPC handle (send it to the other
+ *     processes by any means); tgs_peer_open maps another process's buffer; _close / _free undo them.
+ * Flags are int32 words inside such buffers; `seq` must grow from call to call (compared as seq - flag <= 0);
+ * `ticket` = a zeroed device int32 private to each (call site, stream).
+ * tgs_peer_push:        src[0, bytes) -> dsts[i][0, bytes) for i < n_dst, then flags[i] = seq (release, system scope)
+ * tgs_peer_scatter:     src[q * slice_bytes, ...) -> dsts[q][0, ...) for q < n_dst, then flags
+ * tgs_peer_reduce_push: sum over r < world of srcs[r] in rank order -> every dsts[i], then flags
+ * tgs_peer_wait:        the stream waits until all n flags (local memory) have reached seq; after timeout_s
+ *     seconds (<= 0: 20 s) it gives up and sets *err = 1 + index of the missing flag (check it at a sync point).
+ * All pointer arrays are HOST arrays of device pointers; at most 8 receivers; sizes and pointers are multiples of
+ * 16 bytes (tgs_peer_push also takes multiples of 4 bytes, on a slower scalar path). */
+int tgs_peer_alloc(size_t bytes, void** dptr, unsigned char* handle64);
+int tgs_peer_open(const unsigned char* handle64, void** dptr);
+int tgs_peer_close(void* dptr);
+int tgs_peer_free(void* dptr);
+int tgs_peer_push(int n_dst, void* const* dsts, int32_t* const* flags, const void* src, size_t bytes,
+                  int32_t seq, int32_t* ticket, void* stream);
+int tgs_peer_scatter(int n_dst, void* const* dsts, int32_t* const* flags, const void* src,
+                     size_t slice_bytes, size_t total_bytes, int32_t seq, int32_t* ticket, void* stream);
+int tgs_peer_reduce_push(int world, const void* const* srcs, int n_dst, void* const* dsts,
+                         int32_t* const* flags, size_t bytes, int32_t seq, int32_t* ticket, void* stream);
+int tgs_peer_wait(int n, const int32_t* const* flags, int32_t seq, int32_t* err, float timeout_s, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1492,6 +1492,81 @@ if dp.rank == 0: print("DP4_OK", d)
 '''
 
 
+_DP_TRANSPORT_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+from touch_gs_amd import parallel
+from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
+from touch_gs_amd.optim import GaussianParams
+from touch_gs_amd.scene import make_view, synthetic_gaussians
+N, W, H, steps = (int(v) for v in sys.argv[3:7])
+deg = 3
+dp = parallel.init_from_env(backend="gloo")           # the ranks share the single GPU of the test box
+dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+views = [make_view(N, W, H, deg, 7, dev, view=v, n_views=8) for v in range(8)]
+P, _ = synthetic_gaussians(N, W, H, deg, 99)
+params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
+m = DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=0), params)
+m.spatial_sort()
+m.enable_speculative_budget()
+dp.color_chunks = int(os.environ.get("CHUNKS", "2"))
+first = None
+for step in range(steps):
+    m.train_step(views[dp.views_for_step(step, 8)], dp, next_view=views[dp.views_for_step(step + 1, 8)])
+    if step == 0:
+        m.flush()
+        first = m.params.flat.cpu()
+m.flush()
+dp.check_transport()
+torch.cuda.synchronize()
+dp.assert_replicas_identical(m.params.flat)
+if dp.transport == "ipc":
+    assert dp.peer is not None and dp.peer.seq == steps and dp.peer.bytes_pushed > 0
+if dp.rank == 0:
+    torch.save(dict(flat=m.params.flat.cpu(), first=first, geom_end=m.optimizer.geom_end()), sys.argv[2])
+dp.barrier()
+if dp.peer is not None: dp.peer.close()
+if dp.rank == 0: print("DPT_OK", dp.transport, flush=True)
+'''
+
+
+@pytest.mark.parametrize("world,N,W,H", [(2, 20000, 320, 208), (4, 20000, 320, 208), (3, 4001, 160, 96)])
+def test_peer_transport_equals_collective_transport(dev, tmp_path, world, N, W, H):
+    """TGS_DP_TRANSPORT=ipc (csrc/peer.hip: the factored exchange as direct stores into IPC-mapped peer buffers --
+    colour blocks pushed to every rank's gather slots, geometry gradients as a direct reduce-scatter + rank-order sum
+    + all-gather, flag words with system-scope release / acquire) against the collective form, with 2 / 4 / 3
+    processes sharing the one GPU of the test box (IPC handles work across processes on one device; on a node
+    the same stores cross xGMI).  Three steps of the trainer's data-parallel form (2 row chunks, sync-free budget,
+    DP front prefetch).  The SH update of a step only depends on the gathered colour blocks (a copy): after the first
+    step the SH segment is bit-identical for any number of ranks.  The geometry segment sums `world` gradients: a + b
+    is order-free, so 2 ranks stay bit-identical throughout; with more ranks the rank-order sum and gloo's tree differ
+    by rounding (statistical agreement from then on, as between the collective form and the hand-averaged single
+    process).  Replicas are bit-identical in every case.  N = 4001: block sizes that are not multiples of 16 bytes
+    (scalar path of the push kernel)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "dp_transport_worker.py"
+    script.write_text(_DP_TRANSPORT_WORKER)
+    out = {}
+    for i, transport in enumerate(("rccl", "ipc")):
+        port = str(29720 + 2 * world + i)
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   TGS_DP_TRANSPORT=transport, CHUNKS="2")
+        f = tmp_path / f"{transport}.pt"
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                            "--master-addr", "127.0.0.1", "--master-port", port, str(script), root, str(f),
+                            str(N), str(W), str(H), "3"], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and f"DPT_OK {transport}" in r.stdout, r.stdout[-2000:] + r.stderr[-6000:]
+        out[transport] = torch.load(f)
+    a, b, ge = out["rccl"]["flat"], out["ipc"]["flat"], out["rccl"]["geom_end"]
+    assert torch.equal(out["rccl"]["first"][ge:], out["ipc"]["first"][ge:])     # SH rows after step 1: any number of ranks
+    if world == 2:
+        assert torch.equal(a, b) and torch.equal(out["rccl"]["first"], out["ipc"]["first"])
+    else:
+        d = (a - b).abs()
+        assert float(torch.quantile(d[::5].float(), 0.999)) < 2e-6 and float(d.max()) < 0.11, (float(d.max()),)
+
+
 _DP_FULL_WORKER = r'''
 import json, os, sys, time, torch
 sys.path.insert(0, sys.argv[1])
@@ -1518,9 +1593,11 @@ t0 = time.time()
 for step in range(steps):                             # the rank's next view is announced: front prefetch of the DP step
     m.train_step(views[dp.views_for_step(step, 8)], dp, next_view=views[dp.views_for_step(step + 1, 8)])
 m.flush()
+dp.check_transport()                                  # (peer transport: no wait timed out)
 torch.cuda.synchronize()
 t_dp = time.time() - t0
 dp.assert_replicas_identical(m.params.flat)           # bit for bit on every rank
+assert (dp.peer is not None) == (os.environ.get("TGS_DP_TRANSPORT") == "ipc")
 stats = None
 if dp.rank == 0:
     ref = fresh()                                     # a single process that averages the ranks' views by hand
@@ -1544,14 +1621,17 @@ if stats is not None: print("DPFULL " + json.dumps(stats), flush=True)
 '''
 
 
+@pytest.mark.parametrize("transport", ["rccl", "ipc"])
 @pytest.mark.parametrize("world,N,W,H,seed", [(4, 1_000_000, 1920, 1080, 1236), (8, 5_000_000, 3840, 2160, 1238)])
-def test_data_parallel_fullsize(dev, tmp_path, world, N, W, H, seed):
+def test_data_parallel_fullsize(dev, tmp_path, world, N, W, H, seed, transport):
     """BASELINE configs[3] (a batch of 4 views of the 1 M / 1080p scene on 4 ranks) and the data-parallel part of
     configs[4] (5 M Gaussians, SH 3, 4K, 8 ranks) at FULL size: the ranks share the one GPU of the test box over gloo
     (the exchange logic, chunking and kernels are the ones that run over RCCL; only the transport differs).  Two
     steps of the trainer's default data-parallel form -- pipelined factored exchange in 4 row chunks, sync-free
     intersection budget, the rank's next view announced (front prefetch inside the geometry Adam) -- leave every
-    replica bit-identical and agree with a single process that averages the ranks' gradients by hand.  The
+    replica bit-identical and agree with a single process that averages the ranks' gradients by hand -- with the
+    collective transport ("rccl": torch.distributed, here gloo) and with the peer transport ("ipc": direct stores into
+    IPC-mapped buffers, csrc/peer.hip).  The
     agreement is statistical, as in the miniature: a sum over ranks is not order-identical to the sequential sum and
     Adam's first steps are lr * sign(g), so a 1-ulp difference in a near-zero gradient flips a whole step."""
     import json, os, subprocess, sys
@@ -1560,8 +1640,9 @@ def test_data_parallel_fullsize(dev, tmp_path, world, N, W, H, seed):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "dp_full_worker.py"
     script.write_text(_DP_FULL_WORKER)
-    port = str(29680 + world)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = str(29680 + world + (20 if transport == "ipc" else 0))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0",
+               TGS_DP_TRANSPORT=transport)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                         "--master-addr", "127.0.0.1", "--master-port", port, str(script), root,
                         str(N), str(W), str(H), str(seed), "2"],

@@ -83,6 +83,15 @@ SIGNATURES = {
     "tgs_adam_step": (C.c_int, [_I, _I, _P, _P, _P, _P, C.POINTER(TgsAdamSpec), C.c_float, C.c_int64, C.c_int64, _P, _P]),
     "tgs_ssim_fwd_bwd": (C.c_int, [_I, _I, _P, _P, C.c_float, _P, _P, _P, _P]),
     "tgs_ssim_fwd_bwd_rows": (C.c_int, [_I, _I, _P, _P, C.c_float, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "tgs_peer_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_ubyte)]),
+    "tgs_peer_open": (C.c_int, [C.POINTER(C.c_ubyte), C.POINTER(C.c_void_p)]),
+    "tgs_peer_close": (C.c_int, [_P]),
+    "tgs_peer_free": (C.c_int, [_P]),
+    "tgs_peer_push": (C.c_int, [_I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _P, C.c_size_t, C.c_int32, _P, _P]),
+    "tgs_peer_scatter": (C.c_int, [_I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _P, C.c_size_t, C.c_size_t, C.c_int32, _P, _P]),
+    "tgs_peer_reduce_push": (C.c_int, [_I, C.POINTER(C.c_void_p), _I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t,
+                                       C.c_int32, _P, _P]),
+    "tgs_peer_wait": (C.c_int, [_I, C.POINTER(C.c_void_p), C.c_int32, _P, C.c_float, _P]),
 }
 
 _lib = None

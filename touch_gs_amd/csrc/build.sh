@@ -6,7 +6,7 @@ OUT="$HERE/../lib"
 mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wall -Wno-unused-function $TGS_EXTRA_FLAGS"
-SRCS="api project binning raster optim imgloss"
+SRCS="api project binning raster optim imgloss peer"
 # raster.hip: the SLP vectoriser pairs the per-pixel FMAs into v_pk_fma_f32, which on gfx950 costs
 # 1.84x a plain v_fma_f32 and needs register-pair shuffles (v_mov) around it: K7 127 -> 100 VGPRs and
 # -7 % time, K6 -3 % without it (measured, same box)

@@ -42,6 +42,161 @@ def init_from_env(backend: Optional[str] = None) -> "GradSync":
     return GradSync(rank, world, local, force_collectives=force)
 
 
+class _RawDeviceArray:
+    """__cuda_array_interface__ view of raw device memory (IPC-mapped peer buffers) for torch.as_tensor."""
+
+    def __init__(self, ptr: int, n: int, typestr: str):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 3}
+
+
+class PeerExchange:
+    """The factored gradient exchange by direct stores into IPC-mapped peer memory (csrc/peer.hip; SURVEY section 5's
+    alternative to RCCL: xGMI is point-to-point, so every rank writes to its 7 peers at once, one hop, no collective).
+
+    Every rank owns ONE receive buffer (uncached device memory, zeroed), mapped into all other processes:
+
+        per parity (2):  colour[C][world][chunk_c] | rs[world][slice] | ag[world * slice]        (floats)
+        then:            flags colour[C][world] | rs[world] | ag[world] | err | tickets[C + 2]    (int32)
+
+    * all-gather of chunk c's colour block: the sender stores it into slot `rank` of colour[c] on every rank (itself
+      included) and raises flag colour[c][rank] there; the SH Adam of chunk c waits for the `world` flags of its own buffer;
+    * all-reduce of the geometry gradients = reduce-scatter + all-gather: slice q of the local gradient goes to rank
+      q's rs[rank]; rank q sums its `world` received slices IN RANK ORDER and stores the result into ag[q * slice] on
+      every rank -- each element is summed once, by one rank, so all replicas receive the same bits.
+    Data slots alternate with the parity of the exchange's sequence number; a sender cannot run two exchanges ahead
+    of a receiver (each exchange ends with flags from every peer), so a slot is never overwritten while it is read.
+    Bit-identical to the collective form for the colour part (a copy) and for two ranks (a + b); with more ranks the
+    rank-order sum differs from a ring's association by rounding -- the replicas stay identical either way."""
+
+    def __init__(self, dp: "GradSync", device, chunk_floats: Sequence[int], geom_floats: int):
+        import ctypes as C
+        from . import _lib
+        self.lib = lib = _lib.load()
+        self.W, self.r, self.dev = dp.world, dp.rank, device
+        W = self.W
+        if W > 8:
+            raise ValueError("the peer transport addresses at most 8 ranks (one node)")
+        self.chunk = [int(m) for m in chunk_floats]
+        self.C = len(self.chunk)
+        self.G = int(geom_floats)
+        self.slice = -(-(-(-self.G // W)) // 4) * 4
+        pad = lambda n: -(-n // 4) * 4
+        self.col_off, off = [], 0
+        for m in self.chunk:
+            self.col_off.append(off)
+            off += pad(W * m)
+        self.rs_off, off = off, off + W * self.slice
+        self.ag_off, off = off, off + W * self.slice
+        self.parity_floats = pad(off)
+        self.n_float = 2 * self.parity_floats
+        self.f_col, self.f_rs, self.f_ag = 0, self.C * W, self.C * W + W
+        self.f_err = self.C * W + 2 * W
+        self.f_ticket = self.f_err + 1
+        self.n_int = -(-(self.f_ticket + self.C + 2) // 4) * 4
+        nbytes = 4 * (self.n_float + self.n_int)
+        base, handle = C.c_void_p(), (C.c_ubyte * 64)()
+        _lib.check(lib.tgs_peer_alloc(nbytes, C.byref(base), handle), "tgs_peer_alloc")
+        self._own = base.value
+        handles = [None] * W
+        dist.all_gather_object(handles, bytes(handle))
+        self.base = []
+        for q in range(W):
+            if q == self.r:
+                self.base.append(self._own)
+            else:
+                p, h = C.c_void_p(), (C.c_ubyte * 64).from_buffer_copy(handles[q])
+                _lib.check(lib.tgs_peer_open(h, C.byref(p)), "tgs_peer_open")
+                self.base.append(p.value)
+        self.seq = 0
+        self.bytes_pushed = 0
+        dist.barrier()            # every mapping exists before the first store
+
+    # -- addresses ---------------------------------------------------------------------------------------------
+    def _f(self, q: int, parity: int, off: int) -> int:
+        return self.base[q] + 4 * (parity * self.parity_floats + off)
+
+    def _i(self, q: int, idx: int) -> int:
+        return self.base[q] + 4 * (self.n_float + idx)
+
+    @staticmethod
+    def _arr(vals):
+        import ctypes as C
+        return (C.c_void_p * len(vals))(*vals)
+
+    def colour_all(self, parity: int, c: int) -> torch.Tensor:
+        """This rank's receive slots of chunk c as a [world, chunk_c] tensor (what the SH Adam reads)."""
+        W, m = self.W, self.chunk[c]
+        t = torch.as_tensor(_RawDeviceArray(self._f(self.r, parity, self.col_off[c]), W * m, "<f4"), device=self.dev)
+        return t.view(W, m)
+
+    def geom_reduced(self, parity: int) -> torch.Tensor:
+        return torch.as_tensor(_RawDeviceArray(self._f(self.r, parity, self.ag_off), self.G, "<f4"), device=self.dev)
+
+    # -- operations (enqueued on the current stream) -------------------------------------------------------------
+    def begin(self) -> int:
+        self.seq += 1
+        return self.seq & 1
+
+    def push_colour(self, c: int, block: torch.Tensor) -> None:
+        from . import _lib
+        W, r, p, m = self.W, self.r, self.seq & 1, self.chunk[c]
+        dsts = self._arr([self._f(q, p, self.col_off[c] + r * m) for q in range(W)])
+        flags = self._arr([self._i(q, self.f_col + c * W + r) for q in range(W)])
+        _lib.check(self.lib.tgs_peer_push(W, dsts, flags, _lib.ptr(block), 4 * m, self.seq, self._i(r, self.f_ticket + c),
+                                          torch.cuda.current_stream().cuda_stream), "tgs_peer_push")
+        self.bytes_pushed += 4 * m * (W - 1)
+
+    def wait_colour(self, c: int) -> None:
+        self._wait([self._i(self.r, self.f_col + c * self.W + s) for s in range(self.W)])
+
+    def _wait(self, flags) -> None:
+        from . import _lib
+        _lib.check(self.lib.tgs_peer_wait(len(flags), self._arr(flags), self.seq, self._i(self.r, self.f_err), 0.0,
+                                          torch.cuda.current_stream().cuda_stream), "tgs_peer_wait")
+
+    def all_reduce_geom(self, geom_grad: torch.Tensor) -> None:
+        """reduce-scatter (direct) -> rank-order sum of the own slice -> all-gather (direct); comm stream."""
+        from . import _lib
+        W, r, p, sl = self.W, self.r, self.seq & 1, self.slice
+        s = torch.cuda.current_stream().cuda_stream
+        dsts = self._arr([self._f(q, p, self.rs_off + r * sl) for q in range(W)])
+        flags = self._arr([self._i(q, self.f_rs + r) for q in range(W)])
+        _lib.check(self.lib.tgs_peer_scatter(W, dsts, flags, _lib.ptr(geom_grad), 4 * sl, 4 * self.G, self.seq,
+                                             self._i(r, self.f_ticket + self.C), s), "tgs_peer_scatter")
+        self._wait([self._i(r, self.f_rs + q) for q in range(W)])
+        mine = max(0, min(sl, self.G - r * sl))
+        srcs = self._arr([self._f(r, p, self.rs_off + q * sl) for q in range(W)])
+        dsts = self._arr([self._f(q, p, self.ag_off + r * sl) for q in range(W)])
+        flags = self._arr([self._i(q, self.f_ag + r) for q in range(W)])
+        _lib.check(self.lib.tgs_peer_reduce_push(W, srcs, W, dsts, flags, 4 * mine, self.seq,
+                                                 self._i(r, self.f_ticket + self.C + 1), s), "tgs_peer_reduce_push")
+        self.bytes_pushed += 4 * (self.G - mine) + 4 * mine * (W - 1)
+
+    def wait_geom(self) -> None:
+        self._wait([self._i(self.r, self.f_ag + q) for q in range(self.W)])
+
+    def check(self) -> None:
+        """Raises if a wait timed out (a peer never delivered): synchronises the device."""
+        torch.cuda.synchronize(self.dev)
+        err = torch.as_tensor(_RawDeviceArray(self._i(self.r, self.f_err), 1, "<i4"), device=self.dev)
+        e = int(err.item())
+        if e:
+            raise RuntimeError(f"peer exchange: rank {self.r} timed out waiting for the flag of rank {e - 1}")
+
+    def close(self) -> None:
+        from . import _lib
+        if self.base is None:
+            return
+        torch.cuda.synchronize(self.dev)
+        dist.barrier()            # nobody stores into a buffer that is about to be unmapped
+        for q, b in enumerate(self.base):
+            if q != self.r:
+                self.lib.tgs_peer_close(b)
+        dist.barrier()
+        self.lib.tgs_peer_free(self._own)
+        self.base = None
+
+
 class GradSync:
     """Gradient exchange for data-parallel training.
 
@@ -72,6 +227,10 @@ class GradSync:
         self._comm_stream = None
         self.timing = False        # record events around the collectives of the factored step
         self._comm_events = None
+        # transport of the factored exchange: "rccl" = torch.distributed collectives (default), "ipc" = direct stores
+        # into IPC-mapped peer buffers (PeerExchange; one node, <= 8 ranks).  TGS_DP_TRANSPORT selects it.
+        self.transport = os.environ.get("TGS_DP_TRANSPORT", "rccl").lower()
+        self.peer = None
 
     def all_reduce_(self, flat_grad: torch.Tensor) -> float:
         if self.active:
@@ -219,6 +378,8 @@ class GradSync:
                 dist.all_gather(list(blocks_all[c].view(self.world, -1).unbind(0)), blocks[c])
 
         self.bytes_per_step = 4 * (sum(b.numel() for b in blocks) * self.world + geom_grad.numel())
+        if self.transport == "ipc" and self.active and geom_grad.is_cuda and self.world > 1:
+            return self._peer_exchange_and_step(geom_grad, blocks, backward_chunk, step_sh_chunk, step_geom, scale)
         if not self.active or not geom_grad.is_cuda:
             for c in range(C_):
                 backward_chunk(c)
@@ -259,6 +420,53 @@ class GradSync:
             step_sh_chunk(c, blocks_all[c], scale)
         comp.wait_event(reduced)
         step_geom(0, geom_grad.numel(), scale)
+
+    def _peer_exchange_and_step(self, geom_grad, blocks, backward_chunk, step_sh_chunk, step_geom, scale) -> None:
+        """The pipelined exchange over the peer transport: same schedule, the collectives replaced by direct stores.
+
+        compute stream:  K8(0) ... K8(C-1)   [wait flags 0] SH-Adam(0) ... [wait flags C-1] SH-Adam(C-1)   [wait ag] copy, geometry Adam
+        side stream:         push(0) ... push(C-1)   scatter slices -> [wait rs] rank-order sum + push to all"""
+        sizes = [int(b.numel()) for b in blocks]
+        if self.peer is None or self.peer.chunk != sizes or self.peer.G != geom_grad.numel():
+            if self.peer is not None:
+                self.peer.close()
+            self.peer = PeerExchange(self, geom_grad.device, sizes, geom_grad.numel())
+        peer, C_ = self.peer, len(blocks)
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=geom_grad.device)
+        comp, comm = torch.cuda.current_stream(geom_grad.device), self._comm_stream
+        parity = peer.begin()
+        t = self.timing
+        begun = gathered = None
+        for c in range(C_):
+            backward_chunk(c)
+            done = torch.cuda.Event()
+            done.record(comp)
+            comm.wait_event(done)
+            with torch.cuda.stream(comm):
+                if c == 0:
+                    begun = torch.cuda.Event(enable_timing=t)
+                    begun.record(comm)
+                peer.push_colour(c, blocks[c])
+        with torch.cuda.stream(comm):
+            gathered = torch.cuda.Event(enable_timing=t)
+            gathered.record(comm)
+            peer.all_reduce_geom(geom_grad)
+            reduced = torch.cuda.Event(enable_timing=t)
+            reduced.record(comm)
+        if t:
+            self._comm_events = (begun, gathered, reduced, sum(sizes) * 4, geom_grad.numel() * 4)
+        for c in range(C_):
+            peer.wait_colour(c)
+            step_sh_chunk(c, peer.colour_all(parity, c), scale)
+        peer.wait_geom()
+        geom_grad.copy_(peer.geom_reduced(parity))
+        step_geom(0, geom_grad.numel(), scale)
+
+    def check_transport(self) -> None:
+        """Raises if a peer-exchange wait timed out (synchronises); no-op for the collective transport."""
+        if self.peer is not None:
+            self.peer.check()
 
     def comm_report(self) -> Optional[dict]:
         """Times and bus bandwidths of the last factored exchange recorded with ``timing = True``
