@@ -245,6 +245,7 @@ def main():
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-busbw-sweep", action="store_true", help="skip the message-size sweep of the exchange (N > 1)")
     ap.add_argument("--no-densify-run", action="store_true",
                     help="skip the densifying-training measurement reported as `train_densify` (N = 1 only)")
     ap.add_argument("--ssim-pipeline", action="store_true",
@@ -354,6 +355,12 @@ def main():
             step(done[0]); done[0] += 1
         comm = dp.comm_report()
         dp.timing = False
+    # message-size sweep of the exchange primitives on this job's ranks (every rank takes part): replaces the link
+    # figures assumed in DESIGN.md section 6 by measurements the moment a multi-GPU node runs this
+    busbw = None
+    if dp.world > 1 and not args.no_busbw_sweep:
+        dp.check_transport()
+        busbw = dp.busbw_sweep(dev)
 
     # ---- per-kernel timing of the same step (HIP events on the launch stream), rank 0 ----
     out = None
@@ -486,8 +493,10 @@ def main():
                                   "payload_bytes_per_rank_per_step": int(dp.bytes_per_step),
                                   "dense_all_reduce_bytes": int(model.params.grad.numel() * 4)}
             out["dp_exchange"]["replicas_identical"] = replicas_identical
+            out["dp_exchange"]["transport"] = dp.transport
             if comm:
                 out["dp_exchange"].update(comm)
+            out["dp_exchange"]["busbw_sweep"] = busbw
         if dp.world == 1 and not args.no_densify_run:
             try:
                 del sp, partials, rgb, dacc

@@ -817,7 +817,10 @@ def test_bench_two_gpus_rccl(dev, tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0
-    assert line["dp_exchange"]["all_gather_busbw_GBs"] > 0 and line["dp_exchange"]["replicas_identical"] is True
+    assert line["dp_exchange"]["all_gather_busbw_GBs"] > 0 and line["dp_exchange"]["transport"] == transport
+    sweep = line["dp_exchange"]["busbw_sweep"]          # message-size sweep of the exchange primitives (token sizes on gloo)
+    assert set(sweep) == {"12MB", "44MB"} and all(v["all_gather"]["busbw_GBs"] > 0 for v in sweep.values())
+    assert ("peer_push" in sweep["12MB"]) == (transport == "ipc") and line["dp_exchange"]["replicas_identical"] is True
 
 
 def test_bench_two_ranks_share_one_gpu(dev):
@@ -841,13 +844,14 @@ def test_bench_two_ranks_share_one_gpu(dev):
     assert line["config"]["parallelism"] == "dp2"
 
 
-def test_bench_bare_command_launches_its_own_ranks(dev):
+@pytest.mark.parametrize("transport", ["rccl", "ipc"])
+def test_bench_bare_command_launches_its_own_ranks(dev, transport):
     """`python bench.py --gpus 2` exactly as the driver invokes it (no torchrun, no rank environment):
     bench.py starts its own two ranks (here sharing cuda:0 over gloo) and prints ONE JSON line with
     n_gpus = 2, the exchange report and the replica check."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, TGS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, TGS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", TGS_DP_TRANSPORT=transport)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",

@@ -33,16 +33,20 @@ struct PeerDst {
   int32_t* flag[PEER_MAX];
 };
 
-// The last workgroup of a launch to get here (device-scope ticket) publishes: everything this launch stored is
-// ordered before the flags by the system-scope release fence each workgroup issues before taking its ticket.
+// The last workgroup of a launch to get here (ticket) publishes the flags.  Ordering: the receive buffers are
+// UNCACHED memory, so every data store is written through to its destination and its completion (vmcnt) means it has
+// arrived; a workgroup waits for the completion of its own stores (workgroup-scope release + barrier: s_waitcnt, no
+// cache maintenance) before it takes a ticket, and the one wave that sees the last ticket issues the single
+// system-scope release of the launch.  (A system- or agent-scope fence per wave -- the textbook form -- writes back
+// the XCD's whole L2 every time: 8192 waves doing that took the 12 MB push to 165 us and the 44 MB rank-order sum to
+// 525 us; this form runs at copy speed.)
 __device__ __forceinline__ void publish(const PeerDst& d, int n, int32_t seq, int32_t* ticket) {
-  __threadfence_system();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   if (threadIdx.x == 0) {
     const int total = gridDim.x * gridDim.y;
-    if (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
-      *ticket = 0;                                   // ready for the next launch on this stream
-      __threadfence_system();
+    if (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
+      __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch on this stream
       for (int i = 0; i < n; i++)
         if (d.flag[i]) __hip_atomic_store(d.flag[i], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -54,11 +58,20 @@ __device__ __forceinline__ void publish(const PeerDst& d, int n, int32_t seq, in
 template <typename T>
 __global__ __launch_bounds__(256) void k_peer_push(PeerDst d, int n, const T* __restrict__ src, size_t nT,
                                                    int32_t seq, int32_t* ticket) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nT; i += (size_t)gridDim.x * 256) {
-    const T v = src[i];
+  // four independent loads in flight per thread (one load per iteration left the copy at 1 TB/s)
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nT; i += 4 * stride) {
+    T v[4];
 #pragma unroll
-    for (int q = 0; q < PEER_MAX; q++)
-      if (q < n) reinterpret_cast<T*>(d.dst[q])[i] = v;
+    for (int u = 0; u < 4; u++)
+      if (i + u * stride < nT) v[u] = src[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (i + u * stride < nT) {
+#pragma unroll
+        for (int q = 0; q < PEER_MAX; q++)
+          if (q < n) reinterpret_cast<T*>(d.dst[q])[i + u * stride] = v[u];
+      }
   }
   publish(d, n, seq, ticket);
 }
@@ -69,7 +82,16 @@ __global__ __launch_bounds__(256) void k_peer_scatter(PeerDst d, int n, const fl
   const int q = blockIdx.y;
   const size_t b = (size_t)q * slice4, e = min(b + slice4, total4);
   float4* __restrict__ o = reinterpret_cast<float4*>(d.dst[q]);
-  for (size_t i = b + (size_t)blockIdx.x * 256 + threadIdx.x; i < e; i += (size_t)gridDim.x * 256) o[i - b] = src[i];
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = b + (size_t)blockIdx.x * 256 + threadIdx.x; i < e; i += 4 * stride) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (i + u * stride < e) v[u] = src[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (i + u * stride < e) o[i + u * stride - b] = v[u];
+  }
   publish(d, n, seq, ticket);
 }
 
@@ -79,14 +101,14 @@ struct PeerSrc { const float* src[PEER_MAX]; };
 __global__ __launch_bounds__(256) void k_peer_reduce_push(PeerSrc s, int world, PeerDst d, int n, size_t n4, int32_t seq,
                                                           int32_t* ticket) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-    float4 a = reinterpret_cast<const float4*>(s.src[0])[i];
+    float4 v[PEER_MAX];          // all ranks' values in flight at once, then summed in rank order
 #pragma unroll
-    for (int r = 1; r < PEER_MAX; r++) {
-      if (r < world) {
-        const float4 v = reinterpret_cast<const float4*>(s.src[r])[i];
-        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-      }
-    }
+    for (int r = 0; r < PEER_MAX; r++)
+      if (r < world) v[r] = reinterpret_cast<const float4*>(s.src[r])[i];
+    float4 a = v[0];
+#pragma unroll
+    for (int r = 1; r < PEER_MAX; r++)
+      if (r < world) { a.x += v[r].x; a.y += v[r].y; a.z += v[r].z; a.w += v[r].w; }
 #pragma unroll
     for (int q = 0; q < PEER_MAX; q++)
       if (q < n) reinterpret_cast<float4*>(d.dst[q])[i] = a;
@@ -102,15 +124,16 @@ __global__ __launch_bounds__(64) void k_peer_wait(PeerFlags f, int n, int32_t se
   const int i = threadIdx.x;
   if (i < n && f.flag[i]) {
     const long long t0 = (long long)__builtin_readcyclecounter();
-    while (__hip_atomic_load(f.flag[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq < 0) {
-      __builtin_amdgcn_s_sleep(32);
+    // relaxed polls (the flag word is uncached: every load goes to memory), ONE acquire after the last
+    while (__hip_atomic_load(f.flag[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq < 0) {
+      __builtin_amdgcn_s_sleep(16);
       if ((long long)__builtin_readcyclecounter() - t0 > timeout_ticks) {
         if (err) *err = 1 + i;
         break;
       }
     }
   }
-  __threadfence_system();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // system scope: the kernels behind this one read the payload
 }
 
 int fill_dst(PeerDst& d, int n, void* const* dsts, int32_t* const* flags) {
@@ -191,7 +214,7 @@ extern "C" int tgs_peer_scatter(int n_dst, void* const* dsts, int32_t* const* fl
   TGS_CHECK_ARG(ticket && dsts && src && slice_bytes * (size_t)n_dst >= total_bytes, "null pointer / slices do not cover the buffer");
   PeerDst d;
   fill_dst(d, n_dst, dsts, flags);
-  hipLaunchKernelGGL(k_peer_scatter, dim3(max(grid_for(slice_bytes / 16) / 4, 1), n_dst), dim3(256), 0, (hipStream_t)stream, d,
+  hipLaunchKernelGGL(k_peer_scatter, dim3(max(grid_for(slice_bytes / 16 / 4), 1), n_dst), dim3(256), 0, (hipStream_t)stream, d,
                      n_dst, (const float4*)src, slice_bytes / 16, total_bytes / 16, seq, ticket);
   TGS_CHECK_LAUNCH();
   return TGS_OK;

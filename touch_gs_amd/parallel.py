@@ -109,6 +109,27 @@ class PeerExchange:
                 self.base.append(p.value)
         self.seq = 0
         self.bytes_pushed = 0
+        # everything a step needs is built ONCE: tensor views of the receive slots (torch.as_tensor on a raw pointer
+        # queries the pointer's attributes: ~0.3 ms of host time each) and the host arrays of peer addresses
+        A, r = self._arr, self.r
+        self._views = {(p_, c): torch.as_tensor(_RawDeviceArray(self._f(r, p_, self.col_off[c]), W * self.chunk[c], "<f4"),
+                                                device=device).view(W, self.chunk[c])
+                       for p_ in (0, 1) for c in range(self.C)}
+        self._geom_views = [torch.as_tensor(_RawDeviceArray(self._f(r, p_, self.ag_off), self.G, "<f4"), device=device)
+                            for p_ in (0, 1)]
+        self._err_view = torch.as_tensor(_RawDeviceArray(self._i(r, self.f_err), 1, "<i4"), device=device)
+        sl = self.slice
+        self._a_col = {(p_, c): (A([self._f(q, p_, self.col_off[c] + r * self.chunk[c]) for q in range(W)]),
+                                 A([self._i(q, self.f_col + c * W + r) for q in range(W)]))
+                       for p_ in (0, 1) for c in range(self.C)}
+        self._a_col_wait = [A([self._i(r, self.f_col + c * W + s) for s in range(W)]) for c in range(self.C)]
+        self._a_rs = [(A([self._f(q, p_, self.rs_off + r * sl) for q in range(W)]), A([self._i(q, self.f_rs + r) for q in range(W)]))
+                      for p_ in (0, 1)]
+        self._a_rs_wait = A([self._i(r, self.f_rs + q) for q in range(W)])
+        self._a_red = [(A([self._f(r, p_, self.rs_off + q * sl) for q in range(W)]),
+                        A([self._f(q, p_, self.ag_off + r * sl) for q in range(W)]),
+                        A([self._i(q, self.f_ag + r) for q in range(W)])) for p_ in (0, 1)]
+        self._a_ag_wait = A([self._i(r, self.f_ag + q) for q in range(W)])
         dist.barrier()            # every mapping exists before the first store
 
     # -- addresses ---------------------------------------------------------------------------------------------
@@ -125,12 +146,10 @@ class PeerExchange:
 
     def colour_all(self, parity: int, c: int) -> torch.Tensor:
         """This rank's receive slots of chunk c as a [world, chunk_c] tensor (what the SH Adam reads)."""
-        W, m = self.W, self.chunk[c]
-        t = torch.as_tensor(_RawDeviceArray(self._f(self.r, parity, self.col_off[c]), W * m, "<f4"), device=self.dev)
-        return t.view(W, m)
+        return self._views[(parity, c)]
 
     def geom_reduced(self, parity: int) -> torch.Tensor:
-        return torch.as_tensor(_RawDeviceArray(self._f(self.r, parity, self.ag_off), self.G, "<f4"), device=self.dev)
+        return self._geom_views[parity]
 
     # -- operations (enqueued on the current stream) -------------------------------------------------------------
     def begin(self) -> int:
@@ -140,18 +159,17 @@ class PeerExchange:
     def push_colour(self, c: int, block: torch.Tensor) -> None:
         from . import _lib
         W, r, p, m = self.W, self.r, self.seq & 1, self.chunk[c]
-        dsts = self._arr([self._f(q, p, self.col_off[c] + r * m) for q in range(W)])
-        flags = self._arr([self._i(q, self.f_col + c * W + r) for q in range(W)])
+        dsts, flags = self._a_col[(p, c)]
         _lib.check(self.lib.tgs_peer_push(W, dsts, flags, _lib.ptr(block), 4 * m, self.seq, self._i(r, self.f_ticket + c),
                                           torch.cuda.current_stream().cuda_stream), "tgs_peer_push")
         self.bytes_pushed += 4 * m * (W - 1)
 
     def wait_colour(self, c: int) -> None:
-        self._wait([self._i(self.r, self.f_col + c * self.W + s) for s in range(self.W)])
+        self._wait(self._a_col_wait[c])
 
     def _wait(self, flags) -> None:
         from . import _lib
-        _lib.check(self.lib.tgs_peer_wait(len(flags), self._arr(flags), self.seq, self._i(self.r, self.f_err), 0.0,
+        _lib.check(self.lib.tgs_peer_wait(len(flags), flags, self.seq, self._i(self.r, self.f_err), 0.0,
                                           torch.cuda.current_stream().cuda_stream), "tgs_peer_wait")
 
     def all_reduce_geom(self, geom_grad: torch.Tensor) -> None:
@@ -159,27 +177,23 @@ class PeerExchange:
         from . import _lib
         W, r, p, sl = self.W, self.r, self.seq & 1, self.slice
         s = torch.cuda.current_stream().cuda_stream
-        dsts = self._arr([self._f(q, p, self.rs_off + r * sl) for q in range(W)])
-        flags = self._arr([self._i(q, self.f_rs + r) for q in range(W)])
+        dsts, flags = self._a_rs[p]
         _lib.check(self.lib.tgs_peer_scatter(W, dsts, flags, _lib.ptr(geom_grad), 4 * sl, 4 * self.G, self.seq,
                                              self._i(r, self.f_ticket + self.C), s), "tgs_peer_scatter")
-        self._wait([self._i(r, self.f_rs + q) for q in range(W)])
+        self._wait(self._a_rs_wait)
         mine = max(0, min(sl, self.G - r * sl))
-        srcs = self._arr([self._f(r, p, self.rs_off + q * sl) for q in range(W)])
-        dsts = self._arr([self._f(q, p, self.ag_off + r * sl) for q in range(W)])
-        flags = self._arr([self._i(q, self.f_ag + r) for q in range(W)])
+        srcs, dsts, flags = self._a_red[p]
         _lib.check(self.lib.tgs_peer_reduce_push(W, srcs, W, dsts, flags, 4 * mine, self.seq,
                                                  self._i(r, self.f_ticket + self.C + 1), s), "tgs_peer_reduce_push")
         self.bytes_pushed += 4 * (self.G - mine) + 4 * mine * (W - 1)
 
     def wait_geom(self) -> None:
-        self._wait([self._i(self.r, self.f_ag + q) for q in range(self.W)])
+        self._wait(self._a_ag_wait)
 
     def check(self) -> None:
         """Raises if a wait timed out (a peer never delivered): synchronises the device."""
         torch.cuda.synchronize(self.dev)
-        err = torch.as_tensor(_RawDeviceArray(self._i(self.r, self.f_err), 1, "<i4"), device=self.dev)
-        e = int(err.item())
+        e = int(self._err_view.item())
         if e:
             raise RuntimeError(f"peer exchange: rank {self.r} timed out waiting for the flag of rank {e - 1}")
 
@@ -378,8 +392,8 @@ class GradSync:
                 dist.all_gather(list(blocks_all[c].view(self.world, -1).unbind(0)), blocks[c])
 
         self.bytes_per_step = 4 * (sum(b.numel() for b in blocks) * self.world + geom_grad.numel())
-        if self.transport == "ipc" and self.active and geom_grad.is_cuda and self.world > 1:
-            return self._peer_exchange_and_step(geom_grad, blocks, backward_chunk, step_sh_chunk, step_geom, scale)
+        if self.transport == "ipc" and self.active and geom_grad.is_cuda:
+            return self._peer_exchange_and_step(geom_grad, blocks, blocks_all, backward_chunk, step_sh_chunk, step_geom, scale)
         if not self.active or not geom_grad.is_cuda:
             for c in range(C_):
                 backward_chunk(c)
@@ -421,11 +435,14 @@ class GradSync:
         comp.wait_event(reduced)
         step_geom(0, geom_grad.numel(), scale)
 
-    def _peer_exchange_and_step(self, geom_grad, blocks, backward_chunk, step_sh_chunk, step_geom, scale) -> None:
+    def _peer_exchange_and_step(self, geom_grad, blocks, blocks_all, backward_chunk, step_sh_chunk, step_geom, scale) -> None:
         """The pipelined exchange over the peer transport: same schedule, the collectives replaced by direct stores.
 
         compute stream:  K8(0) ... K8(C-1)   [wait flags 0] SH-Adam(0) ... [wait flags C-1] SH-Adam(C-1)   [wait ag] copy, geometry Adam
         side stream:         push(0) ... push(C-1)   scatter slices -> [wait rs] rank-order sum + push to all"""
+        # ``blocks_all`` are the caller's ordinary (cached) buffers: a received chunk is copied out of the uncached
+        # receive slots by one vectorised copy before the SH Adam reads it with 4-byte loads (which crawl on uncached
+        # memory: 759 instead of 200 us)
         sizes = [int(b.numel()) for b in blocks]
         if self.peer is None or self.peer.chunk != sizes or self.peer.G != geom_grad.numel():
             if self.peer is not None:
@@ -458,7 +475,8 @@ class GradSync:
             self._comm_events = (begun, gathered, reduced, sum(sizes) * 4, geom_grad.numel() * 4)
         for c in range(C_):
             peer.wait_colour(c)
-            step_sh_chunk(c, peer.colour_all(parity, c), scale)
+            blocks_all[c].copy_(peer.colour_all(parity, c))
+            step_sh_chunk(c, blocks_all[c], scale)
         peer.wait_geom()
         geom_grad.copy_(peer.geom_reduced(parity))
         step_geom(0, geom_grad.numel(), scale)
@@ -482,6 +500,64 @@ class GradSync:
                 "all_gather_busbw_GBs": round(block_bytes * n * (n - 1) / n / tg / 1e9, 3),
                 "all_reduce_ms": round(tr * 1e3, 4), "all_reduce_bytes": geom_bytes,
                 "all_reduce_busbw_GBs": round(geom_bytes * 2 * (n - 1) / n / tr / 1e9, 3)}
+
+    def busbw_sweep(self, device, sizes_mb=(12, 44, 96, 236), reps: int = 5) -> Optional[dict]:
+        """rccl-tests style message-size sweep on the job's own process group: for every size S the
+        time and bus bandwidth of an all-gather of S per rank, an all-reduce of an S-byte buffer, and -- peer
+        transport -- a push of S to every peer + flags.  busbw: all-gather S (n-1) / t (per-rank receive rate),
+        all-reduce 2 S (n-1)/n / t, push S (n-1) / t.  12 / 44 MB are the colour block and the geometry gradient of the
+        1 M-Gaussian step, 96 / 236 MB the gathered block and the dense gradient.  Returns None with one rank."""
+        if not self.active or self.world < 2:
+            return None
+        n, out = self.world, {}
+        nccl = dist.get_backend() == "nccl"
+        if not nccl:        # gloo (tests: ranks sharing one GPU, payloads through host memory): a token sweep
+            sizes_mb, reps = tuple(sizes_mb)[:2], 1
+        peer = None
+        for mb in sizes_mb:
+            m = mb * 1_000_000 // 16 * 4                       # floats, 16-byte multiple
+            src = torch.ones(m, dtype=torch.float32, device=device)
+            allb = torch.empty(n * m, dtype=torch.float32, device=device)
+
+            def gather():
+                if nccl:
+                    dist.all_gather_into_tensor(allb, src)
+                else:
+                    dist.all_gather(list(allb.view(n, m).unbind(0)), src)
+
+            ops_ = {"all_gather": gather, "all_reduce": lambda: dist.all_reduce(src, op=dist.ReduceOp.SUM)}
+            if self.transport == "ipc":
+                if peer is not None:
+                    peer.close()
+                peer = PeerExchange(self, device, [m], 4)
+
+                def push():
+                    peer.begin()
+                    peer.push_colour(0, src)
+                    peer.wait_colour(0)
+                ops_["peer_push"] = push
+            row = {}
+            for name, fn in ops_.items():
+                for _ in range(2):
+                    fn()
+                torch.cuda.synchronize(device)
+                dist.barrier()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    fn()
+                e1.record()
+                e1.synchronize()
+                t = self.max_over_ranks(e0.elapsed_time(e1) / reps * 1e-3)
+                S = 4 * m
+                bw = (2 * S * (n - 1) / n if name == "all_reduce" else S * (n - 1)) / t / 1e9
+                row[name] = {"ms": round(t * 1e3, 4), "busbw_GBs": round(bw, 2)}
+            out[f"{mb}MB"] = row
+            del src, allb
+        if peer is not None:
+            peer.check()
+            peer.close()
+        return out
 
     def barrier(self):
         if self.active:
