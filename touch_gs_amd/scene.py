@@ -95,3 +95,37 @@ def make_view(N: int, W: int, H: int, deg: int, seed: int, device, view: int = 0
     depth = torch.where(masked.to(device), torch.zeros_like(depth), depth)
     return View(cam=cam, rgb=rgb.clamp(0, 1).contiguous(), depth=depth.contiguous(),
                 uncertainty=unc.to(device).contiguous())
+
+
+def write_scene_dir(root: str, views, points=None, colors255=None) -> None:
+    """Writes views to disk in the format the reference's plumbing leaves behind, i.e. what
+    ``touch_gs_amd.train --data`` and the nerfstudio dataparser read: ``transforms.json`` (fl_x .. h, per frame
+    ``file_path`` / OpenGL camera->world ``transform_matrix`` / ``depth_file_path`` / ``uncertainty_file_path``,
+    reference utils/add_depth_file_path_to_transforms.py:37-50), 8-bit RGB PNGs under images/, 16-bit millimetre
+    depth and uncertainty PNGs (utils/fuse_touch_vision.py:372-376) and, if given, the touch seed points
+    ``points_touch.npy`` / ``points_colors.npy`` (utils/create_point_cloud_from_touches.py:243-244)."""
+    import json
+    import os
+    import numpy as np
+    from PIL import Image
+    from . import plumbing
+    for d in ("images", "fused_output_dir", "fused_output_dir_uncertainty"):
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+    frames = []
+    for i, v in enumerate(views):
+        name = f"{i:04d}.png"
+        Image.fromarray((v.rgb.clamp(0, 1) * 255).to(torch.uint8).cpu().numpy()).save(os.path.join(root, "images", name))
+        plumbing.write_png16(os.path.join(root, "fused_output_dir", name),
+                             plumbing.to_uint16_mm(v.depth.cpu().numpy().astype(np.float64)))
+        plumbing.write_png16(os.path.join(root, "fused_output_dir_uncertainty", name),
+                             plumbing.to_uint16_mm(v.uncertainty.cpu().numpy().astype(np.float64)))
+        c2w = np.linalg.inv(np.asarray(v.cam.viewmat, dtype=np.float64)) @ np.diag([1.0, -1.0, -1.0, 1.0])
+        frames.append({"file_path": f"images/{name}", "transform_matrix": c2w.tolist()})
+    cam = views[0].cam
+    meta = {"fl_x": cam.fx, "fl_y": cam.fy, "cx": cam.cx, "cy": cam.cy, "w": cam.W, "h": cam.H, "frames": frames}
+    plumbing.add_depth_file_paths(meta, "fused_output_dir", "fused_output_dir_uncertainty")
+    with open(os.path.join(root, "transforms.json"), "w") as f:
+        json.dump(meta, f)
+    if points is not None:
+        np.save(os.path.join(root, "points_touch.npy"), np.asarray(points, dtype=np.float64))
+        np.save(os.path.join(root, "points_colors.npy"), np.asarray(colors255, dtype=np.float64))
