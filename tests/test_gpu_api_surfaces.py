@@ -272,6 +272,36 @@ assert ds.params.N == dm.params.N and torch.equal(ds.params.flat, dm.params.flat
 assert torch.equal(ds.optimizer.exp_avg_sq, dm.optimizer.exp_avg_sq)
 dp.assert_replicas_identical(ds.params.flat)
 dp.barrier()
+# ADVICE r3: the capacity fits ONE rank's frames but not the other's (rank 1 renders at half resolution: a quarter of
+# the pairs).  Every step rank 0 overflows is voided on both ranks (agreed verdict) and replayed; rank 1, whose own
+# frames fitted, must not count them twice in the refinement statistics (density.accumulate is guarded by the agreed
+# verdict, not by the rank's own status word): bit-identical to the synchronous budget
+from touch_gs_amd import ops
+views2 = [views[v] if v % 2 == 0 else make_view(N, W // 2, H // 2, deg, 7, dev, view=v, n_views=4) for v in range(4)]
+b0 = ops.IntersectBudget()
+v0 = views2[dp.views_for_step(0, 4)]
+p0 = fresh().params
+ops.project_bin_sort(v0.cam, p0.means, p0.log_scales, p0.quats, p0.opac_logit, p0.sh, deg, b0)
+mine = [None, None]
+dist.all_gather_object(mine, (int(b0.last_n), int(b0.last_need)))
+cap = (mine[1][1] + mine[0][0]) // 2
+assert mine[1][1] < cap < mine[0][0], mine        # rank 1 certainly fits, rank 0 certainly does not
+def run_asym(speculative):
+    m = fresh()
+    m.enable_densification(DensifyConfig(warmup_length=2, refine_every=4, densify_grad_thresh=1e-5,
+                                         densify_size_thresh=0.02, cull_alpha_thresh=0.01, reset_alpha_every=0))
+    if speculative:
+        m.enable_speculative_budget(capacity=cap, max_in_flight=2)
+    for step in range(9):
+        m.train_step(views2[dp.views_for_step(step, 4)], dp)
+    m.flush()
+    torch.cuda.synchronize()
+    return m
+da, db = run_asym(True), run_asym(False)
+assert da.speculative_replays > 0 and da.step == db.step == 9
+assert da.params.N == db.params.N != N and torch.equal(da.params.flat, db.params.flat), (da.params.N, db.params.N, mine, cap)
+dp.assert_replicas_identical(da.params.flat)
+dp.barrier()
 # front prefetch of the data-parallel form: with the rank's next view announced, the geometry Adam (last kernel of
 # the step) also runs that view's K1 (tgs_adam_geom_project_next) and the next step only scans, fills and sorts --
 # bit-identical to the unannounced sequence, also with densification statistics (radii) and the sync-free budget
@@ -318,14 +348,16 @@ def test_data_parallel_train_step_two_ranks_one_gpu(dev, tmp_path):
     assert r.returncode == 0 and "DP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-def test_trainer_two_ranks_overflow_before_eval_boundary(dev, tmp_path):
+@pytest.mark.parametrize("transport", ["rccl", "ipc"])
+def test_trainer_two_ranks_overflow_before_eval_boundary(dev, tmp_path, transport):
     """the trainer CLI with two ranks (sharing the GPU over gloo), the sync-free budget forced to
     overflow (TGS_SPEC_CAPACITY), refinement every 4 steps and eval / save boundaries every 5: every rank
     drains its pending verdicts at the same steps (a rank-0-only flush left the replayed collectives
     unmatched), so the run completes, refines, and ends with identical replicas (train.main asserts it)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, TGS_DIST_BACKEND="gloo", TGS_SPEC_CAPACITY="3000", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, TGS_DIST_BACKEND="gloo", TGS_SPEC_CAPACITY="3000", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               TGS_DP_TRANSPORT=transport)     # "ipc": the peer buffers are rebuilt at every refinement (N changes)
     out = tmp_path / "out"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                         "--master-addr", "127.0.0.1", "--master-port", "29671", "-m", "touch_gs_amd.train",

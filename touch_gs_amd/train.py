@@ -194,6 +194,7 @@ def main(argv=None):
             # overflow replays steps, collectives included, so a rank-0-only flush would leave the ranks'
             # collectives unmatched (and break "every rank inspects step s - L at step s")
             model.flush()
+            dp.check_transport()      # peer transport: a wait that timed out (a rank never delivered) raises here
         if dp.rank == 0 and at_eval:
             loss = model.loss_from(model.last["tile_loss"], model.last["ssim_sum"], model.last["view"])
             print(f"step {step + 1}: " + " ".join(f"{k}={float(v):.5f}" for k, v in loss.items()) +
@@ -220,6 +221,9 @@ def main(argv=None):
             render_views(model, eval_views, args.render_output,
                          None if args.synthetic is not None else [scene.names[i] for i in i_eval] if i_eval else None)
     dp.barrier()
+    if dp.peer is not None:
+        dp.peer.close()
+        dp.peer = None
     return run_dir
 
 
