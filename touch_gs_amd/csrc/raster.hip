@@ -17,9 +17,11 @@
 //    alpha >= 1/255).  The blend loop reads the record back as wave-uniform broadcast
 //    ds_read_b128 and skips whole quadrants with scalar branches; the per-pixel update is
 //    branch-free (v_cndmask), so the 4 pixels of a lane pipeline through the exp unit.
-//  * backward: walks the list front to back like the forward (identical decisions, no stored
-//    last-contributor index, no T/(1-alpha) division chain); per-pixel state is (T, prefix.v)
-//    only; each lane accumulates, over its <= 4 pixels,
+//  * backward (k_raster_bwd, round 4): walks the list BACK TO FRONT from the per-pixel stop positions the forward
+//    leaves (the forward's alpha compare on the same bits: identical decisions; T in front of a Gaussian =
+//    T behind * rcp(1 - alpha)); k_raster_bwd_f2b is the front-to-back form of rounds 1-3 (colour behind =
+//    final - prefix: 300x less accurate for occluded Gaussians, see the comment at k_raster_bwd).  Per-pixel state
+//    is (T, sum behind . v) only; each lane accumulates, over its <= 4 pixels,
 //    8 sums per Gaussian (v_rgb, v_depth, and S / Sx / Sy / Quv of q = alpha * v_alpha, from which the
 //    six pixel-coordinate moments follow linearly); the 64-lane sums go through LDS: every lane scatters
 //    its 8 values into a padded [8][68] image, lane (part, c) forms a weighted sum of 16 lane
@@ -29,8 +31,10 @@
 //    butterfly needs 37 VALU and the kernel is VALU bound); at the end of the batch lane j converts Gaussian j's moments into (v_xy, v_conic, v_opacity) and stores
 //    one 48-B partial record.  There are NO float atomics: cross-tile accumulation is a segmented
 //    sum in K8 (deterministic, and it avoids cross-XCD memory-side atomics).
-//  * blockIdx -> tile mapping gives each XCD a contiguous band of tiles so the gathered splat
-//    records of neighbouring tiles stay in that XCD's 4 MB L2.
+//  * blockIdx -> tile mapping (tile_order, built by the sort launch; tgs_common.h): block b runs on XCD b % 8; the
+//    row-major tiles are dealt to the XCDs in granules of 8 consecutive tiles (horizontal neighbours share most of
+//    their Gaussians and stay in one L2; any view is balanced across the XCDs), each XCD visiting its tiles longest
+//    list first.
 #include <stdlib.h>
 #include <type_traits>
 #include "tgs_common.h"
