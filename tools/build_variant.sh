@@ -19,7 +19,7 @@ for a in "$@"; do
   esac
 done
 pids=()
-for s in api project binning raster optim imgloss; do
+for s in api project binning raster optim imgloss peer; do
   f=${ALT[$s]:-$SRC/$s.hip}
   /opt/rocm/bin/hipcc $FLAGS ${EXTRA[$s]} "${ARGS[@]}" -c "$f" -o $OUT/$s.o &
   pids+=($!)

@@ -959,8 +959,8 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
       centre_rel(a0, a2, tx, ty, cam.pix_center, gx, gy);
       a0.x = gx; a0.y = gy;                       // kept for the conversion of the moments below
       const TileRec t = make_tile_rec(a0, a1, a2, gx, gy);
-      recs[lane * 3] = t.a; recs[lane * 3 + 1] = t.b; recs[lane * 3 + 2] = t.c;
       my_mask = __float_as_uint(t.c.w);
+      recs[lane * 3] = t.a; recs[lane * 3 + 1] = t.b; recs[lane * 3 + 2] = t.c;
       P = pair_index(group_base, gid, a2, tx, ty);
     }
     sums[lane * 4] = z4; sums[lane * 4 + 1] = z4; sums[lane * 4 + 2] = z4; sums[lane * 4 + 3] = z4;
@@ -974,15 +974,16 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
       const unsigned long long keep = r >= 64 ? ~0ull : (r <= 0 ? 0ull : ((1ull << r) - 1ull));
       qm[k] = __ballot((my_mask >> k) & 1u) & keep;
     }
+    const unsigned long long rem0 = qm[0] | qm[1] | qm[2] | qm[3];
     auto walk = [&](auto mayclamp) {
     constexpr bool MAYCLAMP = decltype(mayclamp)::value;
-    unsigned long long rem = qm[0] | qm[1] | qm[2] | qm[3];
+    unsigned long long rem = rem0;
     while (rem) {
       const int j = 63 - __builtin_clzll(rem);
       rem &= ~(1ull << j);
+      const float4 qa = recs[j * 3], qb = recs[j * 3 + 1], qc = recs[j * 3 + 2];
       const unsigned m = (unsigned)((qm[0] >> j) & 1ull) | ((unsigned)((qm[1] >> j) & 1ull) << 1) |
                          ((unsigned)((qm[2] >> j) & 1ull) << 2) | ((unsigned)((qm[3] >> j) & 1ull) << 3);
-      const float4 qa = recs[j * 3], qb = recs[j * 3 + 1], qc = recs[j * 3 + 2];
       const int pos = rel + j;
       // acc: 0..2 v_rgb, 3 v_depth, 4 S = sum q, 5 Sx, 6 Sy, 7 Quv   (rows of the reduction scratch)
       float acc[RED_ROWS];
