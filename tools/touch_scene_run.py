@@ -15,11 +15,12 @@ few thousand touch seed points and GROWS under Splatfacto's refinement schedule.
   reference's format (PNG decoding and uploads included in the wall time)."""
 import argparse, json, os, sys, tempfile, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from touch_gs_amd import ops, train
-from touch_gs_amd.densify import DensifyConfig
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from touch_gs_amd import train
 from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
-from touch_gs_amd.scene import make_view, synthetic_gaussians, write_scene_dir
+from touch_gs_amd.scene import write_scene_dir
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=3000)
@@ -28,63 +29,26 @@ ap.add_argument("--target", type=int, default=300_000)
 ap.add_argument("--seeds", type=int, default=5000)
 args = ap.parse_args()
 dev = torch.device("cuda:0")
-W, H, deg, NV, seed = 1280, 720, 3, 30, 77
-t0 = time.time()
-views = [make_view(args.target, W, H, deg, seed, dev, view=v, n_views=NV, clustered=True) for v in range(NV)]
-P, _ = synthetic_gaussians(args.target, W, H, deg, seed + 1000, clustered=True)     # the scene make_view renders
-g = torch.Generator().manual_seed(1)
-pick = torch.randperm(args.target, generator=g)[:args.seeds]
-pts = P["means"][pick].float()
-cols = (P["sh"][pick, 0].float() * 0.28209479177387814 + 0.5).clamp(0, 1) * 255
-setup_s = time.time() - t0
+deg, NV = 3, 30
+# ---- 1. the growing run (the function behind `train_touch_scene` of the bench line) ----
+grow, views, (pts, cols) = bench.touch_scene_run(dev, steps=args.steps, target=args.target, seeds=args.seeds)
+out = {"growing_run": grow}
+print(json.dumps(grow), flush=True)
 
 
-def fresh(densify=True, num_downscales=2):
+def fresh():
     params = train.init_params(args.seeds, 16, dev, (pts, cols), seed=0)
-    cfg = ModelConfig(sh_degree=deg, depth_loss_mult=0.2, depth_loss_type="DEPTH_UNCERTAINTY_WEIGHTED_LOSS",
-                      uncertainty_weight=1.0, spatial_sort=True, num_downscales=num_downscales, resolution_schedule=250)
+    cfg = ModelConfig(sh_degree=deg, sh_degree_interval=0, depth_loss_mult=0.2, depth_loss_type="DEPTH_UNCERTAINTY_WEIGHTED_LOSS",
+                      uncertainty_weight=1.0, spatial_sort=True)
     m = DepthGaussianSplattingModel(cfg, params)
     m.spatial_sort()
-    if densify:
-        m.enable_densification(DensifyConfig())
     return m
 
 
-out = {"workload": f"{W}x{H}, SH {deg}, {NV} views, target {args.target} Gaussians (clustered), start {args.seeds} seeds",
-       "setup_s": round(setup_s, 1)}
-# ---- 1. the growing run ----
-m = fresh()
-m.enable_speculative_budget()
-windows, t_ref, n_ref = [], 0.0, 0
-torch.cuda.synchronize()
-tw = t_all = time.perf_counter()
-for step in range(args.steps):
-    due = m.density.due(m.step + 1)
-    if due:
-        torch.cuda.synchronize(); tr = time.perf_counter()
-    m.train_step(views[step % NV], next_view=views[(step + 1) % NV])
-    if due:
-        torch.cuda.synchronize(); t_ref += time.perf_counter() - tr; n_ref += 1
-    if (step + 1) % 500 == 0:
-        m.flush(); torch.cuda.synchronize()
-        now = time.perf_counter()
-        windows.append({"steps": f"{step - 498}-{step + 1}", "iters_per_s": round(500 / (now - tw), 1), "N": m.params.N,
-                        "sh_degree": m.active_sh_degree(), "downscale": m.config.downscale_factor(m.step),
-                        "refinement_steps_s": round(t_ref, 3), "refinements": n_ref,
-                        "replayed_steps": getattr(m, "speculative_replays", 0)})
-        tw, t_ref, n_ref = now, 0.0, 0
-total = time.perf_counter() - t_all
-out["growing_run"] = {"iters_per_s": round(args.steps / total, 1), "seconds": round(total, 2), "final_N": m.params.N,
-                      "replayed_steps": getattr(m, "speculative_replays", 0), "windows": windows}
-ev = m.get_outputs(views[0].cam)
-out["growing_run"]["psnr_view0"] = round(float(-10 * torch.log10(((ev["rgb"] - views[0].rgb) ** 2).mean())), 2)
-print(json.dumps(out["growing_run"]), flush=True)
-del m
 # ---- 2. small N: eager launches vs hipGraph replay (no refinement, full resolution) ----
 res = {}
 for mode in ("eager", "graphs"):
-    m = fresh(densify=False, num_downscales=0)
-    m.config.sh_degree_interval = 0
+    m = fresh()
     if mode == "graphs":
         m.capture_step_graphs(views)
     else:
