@@ -438,6 +438,9 @@ int tgs_peer_scatter(int n_dst, void* const* dsts, int32_t* const* flags, const 
                      size_t slice_bytes, size_t total_bytes, int32_t seq, int32_t* ticket, void* stream);
 int tgs_peer_reduce_push(int world, const void* const* srcs, int n_dst, void* const* dsts,
                          int32_t* const* flags, size_t bytes, int32_t seq, int32_t* ticket, void* stream);
+ /* tgs_peer_signal: flags[i] = seq (release, system scope) as a launch of its own -- the conservative way to publish
+ *     after a push / scatter / reduce_push that was given flags = NULL (the kernel boundary orders the data). */
+int tgs_peer_signal(int n, int32_t* const* flags, int32_t seq, void* stream);
 int tgs_peer_wait(int n, const int32_t* const* flags, int32_t seq, int32_t* err, float timeout_s, void* stream);
 
 #ifdef __cplusplus

@@ -1566,8 +1566,9 @@ if dp.rank == 0: print("DPT_OK", dp.transport, flush=True)
 '''
 
 
-@pytest.mark.parametrize("world,N,W,H", [(2, 20000, 320, 208), (4, 20000, 320, 208), (3, 4001, 160, 96)])
-def test_peer_transport_equals_collective_transport(dev, tmp_path, world, N, W, H):
+@pytest.mark.parametrize("world,N,W,H,safe", [(2, 20000, 320, 208, "0"), (4, 20000, 320, 208, "0"), (3, 4001, 160, 96, "0"),
+                                               (2, 20000, 320, 208, "1")])
+def test_peer_transport_equals_collective_transport(dev, tmp_path, world, N, W, H, safe):
     """TGS_DP_TRANSPORT=ipc (csrc/peer.hip: the factored exchange as direct stores into IPC-mapped peer buffers --
     colour blocks pushed to every rank's gather slots, geometry gradients as a direct reduce-scatter + rank-order sum
     + all-gather, flag words with system-scope release / acquire) against the collective form, with 2 / 4 / 3
@@ -1578,7 +1579,7 @@ def test_peer_transport_equals_collective_transport(dev, tmp_path, world, N, W, 
     is order-free, so 2 ranks stay bit-identical throughout; with more ranks the rank-order sum and gloo's tree differ
     by rounding (statistical agreement from then on, as between the collective form and the hand-averaged single
     process).  Replicas are bit-identical in every case.  N = 4001: block sizes that are not multiples of 16 bytes
-    (scalar path of the push kernel)."""
+    (scalar path of the push kernel).  safe = "1": TGS_PEER_SAFE_FLAGS, the flags raised by a launch of their own."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "dp_transport_worker.py"
@@ -1587,7 +1588,7 @@ def test_peer_transport_equals_collective_transport(dev, tmp_path, world, N, W, 
     for i, transport in enumerate(("rccl", "ipc")):
         port = str(29720 + 2 * world + i)
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0",
-                   TGS_DP_TRANSPORT=transport, CHUNKS="2")
+                   TGS_DP_TRANSPORT=transport, CHUNKS="2", TGS_PEER_SAFE_FLAGS=safe)
         f = tmp_path / f"{transport}.pt"
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                             "--master-addr", "127.0.0.1", "--master-port", port, str(script), root, str(f),

@@ -91,6 +91,7 @@ SIGNATURES = {
     "tgs_peer_scatter": (C.c_int, [_I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _P, C.c_size_t, C.c_size_t, C.c_int32, _P, _P]),
     "tgs_peer_reduce_push": (C.c_int, [_I, C.POINTER(C.c_void_p), _I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t,
                                        C.c_int32, _P, _P]),
+    "tgs_peer_signal": (C.c_int, [_I, C.POINTER(C.c_void_p), C.c_int32, _P]),
     "tgs_peer_wait": (C.c_int, [_I, C.POINTER(C.c_void_p), C.c_int32, _P, C.c_float, _P]),
 }
 

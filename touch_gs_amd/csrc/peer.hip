@@ -37,7 +37,10 @@ struct PeerDst {
 // UNCACHED memory, so every data store is written through to its destination and its completion (vmcnt) means it has
 // arrived; a workgroup waits for the completion of its own stores (workgroup-scope release + barrier: s_waitcnt, no
 // cache maintenance) before it takes a ticket, and the one wave that sees the last ticket issues the single
-// system-scope release of the launch.  (A system- or agent-scope fence per wave -- the textbook form -- writes back
+// system-scope release of the launch.  ASSUMPTION (never exercised across GPUs -- all ranks of every run so far shared
+// one device): the completion of a store to uncached memory means it is performed at its destination, also across
+// xGMI.  TGS_PEER_SAFE_FLAGS=1 (parallel.PeerExchange) does not rely on it: the data kernels then publish nothing and a
+// separate one-wave launch (tgs_peer_signal) raises the flags behind the kernel boundary.  (A system- or agent-scope fence per wave -- the textbook form -- writes back
 // the XCD's whole L2 every time: 8192 waves doing that took the 12 MB push to 165 us and the 44 MB rank-order sum to
 // 525 us; this form runs at copy speed.)
 __device__ __forceinline__ void publish(const PeerDst& d, int n, int32_t seq, int32_t* ticket) {
@@ -114,6 +117,13 @@ __global__ __launch_bounds__(256) void k_peer_reduce_push(PeerSrc s, int world, 
       if (q < n) reinterpret_cast<float4*>(d.dst[q])[i] = a;
   }
   publish(d, n, seq, ticket);
+}
+
+// flags[i] = seq with a system-scope release, as a launch of its own: everything earlier launches on the stream
+// stored is complete at the kernel boundary whatever the memory type (the conservative form of publish())
+__global__ __launch_bounds__(64) void k_peer_signal(PeerDst d, int n, int32_t seq) {
+  const int i = threadIdx.x;
+  if (i < n && d.flag[i]) __hip_atomic_store(d.flag[i], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 struct PeerFlags { const int32_t* flag[2 * PEER_MAX]; };
@@ -231,6 +241,16 @@ extern "C" int tgs_peer_reduce_push(int world, const void* const* srcs, int n_ds
   const size_t n4 = bytes / 16;
   hipLaunchKernelGGL(k_peer_reduce_push, dim3(max(grid_for(n4), 1)), dim3(256), 0, (hipStream_t)stream, s, world, d, n_dst,
                      n4, seq, ticket);
+  TGS_CHECK_LAUNCH();
+  return TGS_OK;
+}
+
+extern "C" int tgs_peer_signal(int n, int32_t* const* flags, int32_t seq, void* stream) {
+  TGS_CHECK_ARG(n >= 0 && n <= PEER_MAX && (n == 0 || flags), "at most 8 flags");
+  if (n == 0) return TGS_OK;
+  PeerDst d;
+  for (int i = 0; i < PEER_MAX; i++) { d.dst[i] = nullptr; d.flag[i] = i < n ? flags[i] : nullptr; }
+  hipLaunchKernelGGL(k_peer_signal, dim3(1), dim3(64), 0, (hipStream_t)stream, d, n, seq);
   TGS_CHECK_LAUNCH();
   return TGS_OK;
 }

@@ -109,6 +109,9 @@ class PeerExchange:
                 self.base.append(p.value)
         self.seq = 0
         self.bytes_pushed = 0
+        # TGS_PEER_SAFE_FLAGS=1: the data kernels publish nothing, a separate launch raises the flags behind the kernel
+        # boundary (does not assume that a completed uncached store has arrived at a remote GPU; csrc/peer.hip)
+        self.safe_flags = os.environ.get("TGS_PEER_SAFE_FLAGS", "0") not in ("", "0")
         # everything a step needs is built ONCE: tensor views of the receive slots (torch.as_tensor on a raw pointer
         # queries the pointer's attributes: ~0.3 ms of host time each) and the host arrays of peer addresses
         A, r = self._arr, self.r
@@ -160,9 +163,16 @@ class PeerExchange:
         from . import _lib
         W, r, p, m = self.W, self.r, self.seq & 1, self.chunk[c]
         dsts, flags = self._a_col[(p, c)]
-        _lib.check(self.lib.tgs_peer_push(W, dsts, flags, _lib.ptr(block), 4 * m, self.seq, self._i(r, self.f_ticket + c),
-                                          torch.cuda.current_stream().cuda_stream), "tgs_peer_push")
+        s = torch.cuda.current_stream().cuda_stream
+        _lib.check(self.lib.tgs_peer_push(W, dsts, None if self.safe_flags else flags, _lib.ptr(block), 4 * m, self.seq,
+                                          self._i(r, self.f_ticket + c), s), "tgs_peer_push")
+        self._signal(flags, s)
         self.bytes_pushed += 4 * m * (W - 1)
+
+    def _signal(self, flags, stream) -> None:
+        if self.safe_flags:
+            from . import _lib
+            _lib.check(self.lib.tgs_peer_signal(self.W, flags, self.seq, stream), "tgs_peer_signal")
 
     def wait_colour(self, c: int) -> None:
         self._wait(self._a_col_wait[c])
@@ -178,13 +188,15 @@ class PeerExchange:
         W, r, p, sl = self.W, self.r, self.seq & 1, self.slice
         s = torch.cuda.current_stream().cuda_stream
         dsts, flags = self._a_rs[p]
-        _lib.check(self.lib.tgs_peer_scatter(W, dsts, flags, _lib.ptr(geom_grad), 4 * sl, 4 * self.G, self.seq,
-                                             self._i(r, self.f_ticket + self.C), s), "tgs_peer_scatter")
+        _lib.check(self.lib.tgs_peer_scatter(W, dsts, None if self.safe_flags else flags, _lib.ptr(geom_grad), 4 * sl, 4 * self.G,
+                                             self.seq, self._i(r, self.f_ticket + self.C), s), "tgs_peer_scatter")
+        self._signal(flags, s)
         self._wait(self._a_rs_wait)
         mine = max(0, min(sl, self.G - r * sl))
         srcs, dsts, flags = self._a_red[p]
-        _lib.check(self.lib.tgs_peer_reduce_push(W, srcs, W, dsts, flags, 4 * mine, self.seq,
+        _lib.check(self.lib.tgs_peer_reduce_push(W, srcs, W, dsts, None if self.safe_flags else flags, 4 * mine, self.seq,
                                                  self._i(r, self.f_ticket + self.C + 1), s), "tgs_peer_reduce_push")
+        self._signal(flags, s)
         self.bytes_pushed += 4 * (self.G - mine) + 4 * mine * (W - 1)
 
     def wait_geom(self) -> None:
