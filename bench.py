@@ -603,6 +603,10 @@ def main():
             except Exception as ex:  # the oracle is test infrastructure; never fail the bench on it
                 out["cpu_baseline"] = {"value": None, "error": repr(ex)}
     dp.barrier()
+    if dp.peer is not None:      # peer transport: unmap the other ranks' buffers before the group goes away
+        dp.check_transport()
+        dp.peer.close()
+        dp.peer = None
     if dp.active:
         import torch.distributed as dist
         dist.destroy_process_group()
