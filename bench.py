@@ -58,9 +58,9 @@ def algorithmic_bytes(N, I, P, T, K):
     b = {}
     # K1 (+ fused tile count): params in, record out; rank w/r, pair w/r, sorted id w, rect re-read by fill
     b["project_bin_sort"] = N * (A + 48) + N * 16 + I * (4 + 4 + 8 + 8 + 4) + 12 * T
-    b["raster_fwd"] = I * (4 + 48) + P * 24 + 8 * T
+    b["raster_fwd"] = I * (4 + 48) + P * (24 + 4) + 8 * T        # + the per-pixel stop position (round 4)
     b["ssim"] = P * (24 + 36 + 36 + 12 + 24)
-    b["raster_bwd"] = I * (4 + 48 + 48) + P * (24 + 12 + 28) + 8 * T
+    b["raster_bwd"] = I * (4 + 48 + 48) + P * (24 + 4 + 12 + 28) + 8 * T
     b["project_bwd"] = N * (A + 48 + A) + I * 48
     b["adam"] = 28 * (A // 4) * N
     return b
