@@ -14,6 +14,7 @@ declare -A ALT
 ARGS=()
 for a in "$@"; do
   case "$a" in
+    -*) ARGS+=("$a");;
     *=*) k=${a%%=*}; ALT[${k,,}]=${a#*=};;
     *) ARGS+=("$a");;
   esac

@@ -828,6 +828,7 @@ __global__ __launch_bounds__(64) void k_raster_bwd_f2b(
 //   * everything else -- staging, quadrant masks, the weighted transposed LDS reduction, the partial record
 //     -- is k_raster_bwd_f2b's.  Batches behind the last pixel's stop position are never staged; their
 //     partial records are zero-filled up front.
+// (5 waves per SIMD -- amdgpu_waves_per_eu(5, 8): 96 VGPRs + 14 spilled -- 386 -> 508 us, same-box A/B: 112 VGPRs / 4 waves stay)
 __global__ __launch_bounds__(64) void k_raster_bwd(
     CamK cam, int T_total, const float* __restrict__ splats, const int32_t* __restrict__ group_base,
     const int32_t* __restrict__ sorted_gid, const int32_t* __restrict__ tile_start,
