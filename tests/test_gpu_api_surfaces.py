@@ -1537,8 +1537,11 @@ from touch_gs_amd.optim import GaussianParams
 from touch_gs_amd.scene import make_view, synthetic_gaussians
 N, W, H, steps = (int(v) for v in sys.argv[3:7])
 deg = 3
-dp = parallel.init_from_env(backend="gloo")           # the ranks share the single GPU of the test box
-dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+# the ranks share the single GPU of the test box over gloo; on a box with a GPU per rank they take one each over RCCL
+# (and the peer transport's stores cross xGMI for real)
+multi = torch.cuda.device_count() >= int(os.environ["WORLD_SIZE"])
+dp = parallel.init_from_env(backend="nccl" if multi else "gloo")
+dev = torch.device("cuda", dp.local_rank if multi else 0); torch.cuda.set_device(dev)
 views = [make_view(N, W, H, deg, 7, dev, view=v, n_views=8) for v in range(8)]
 P, _ = synthetic_gaussians(N, W, H, deg, 99)
 params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
@@ -1613,9 +1616,11 @@ from touch_gs_amd.optim import GaussianParams
 from touch_gs_amd.scene import make_view, synthetic_gaussians
 N, W, H, seed, steps = (int(v) for v in sys.argv[2:7])
 deg = 3
-dp = parallel.init_from_env(backend="gloo")           # all ranks share the single GPU of the test box
+# all ranks share the single GPU of the test box over gloo; with a GPU per rank they take one each over RCCL
+multi = torch.cuda.device_count() >= int(os.environ["WORLD_SIZE"])
+dp = parallel.init_from_env(backend="nccl" if multi else "gloo")
 world = dp.world
-dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+dev = torch.device("cuda", dp.local_rank if multi else 0); torch.cuda.set_device(dev)
 views = [make_view(N, W, H, deg, seed, dev, view=v, n_views=8) for v in range(8)]
 P, _ = synthetic_gaussians(N, W, H, deg, seed)
 def fresh():
@@ -1672,7 +1677,7 @@ def test_data_parallel_fullsize(dev, tmp_path, world, N, W, H, seed, transport):
     agreement is statistical, as in the miniature: a sum over ranks is not order-identical to the sequential sum and
     Adam's first steps are lr * sign(g), so a 1-ulp difference in a near-zero gradient flips a whole step."""
     import json, os, subprocess, sys
-    if torch.cuda.mem_get_info()[1] < 150e9:
+    if torch.cuda.device_count() < world and torch.cuda.mem_get_info()[1] < 150e9:
         pytest.skip("needs a 288 GB MI355X: 8 replicas of the 5 M scene share the device")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "dp_full_worker.py"
