@@ -411,6 +411,11 @@ def main():
     value = args.steps * dp.world / elapsed
     if args.loop_only:
         if dp.rank == 0:
+            import ctypes
+            try:
+                ctypes.CDLL(None).fflush(None)   # RCCL's banner (C stdio) first, the JSON line last
+            except Exception:  # noqa: BLE001
+                pass
             print(json.dumps({"metric": "train iters/s (timed loop only)", "value": round(value, 3), "unit": "iters/s",
                               "n_gpus": dp.world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": round(ms_per_step, 4), "launched_steps": done[0],

@@ -9,6 +9,7 @@ import sys
 
 import numpy as np
 import pytest
+from tests.util import free_port
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -271,9 +272,10 @@ if dp.rank == 0: print("GLOO_OK", bytes_dense)
 def test_data_parallel_gloo_world2(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611")
+    port = free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29611", str(script), ROOT],
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script), ROOT],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "GLOO_OK 4012" in r.stdout  # bytes of the last exchanged buffer (1003 floats)

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import torch_oracle as O
-from tests.util import amd_cam, relerr, scene, to_dev
+from tests.util import amd_cam, free_port, relerr, scene, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -341,9 +341,10 @@ def test_data_parallel_train_step_two_ranks_one_gpu(dev, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "dp_worker.py"
     script.write_text(_DP_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29633")
+    port = free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29633", str(script), root],
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script), root],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
@@ -360,7 +361,7 @@ def test_trainer_two_ranks_overflow_before_eval_boundary(dev, tmp_path, transpor
                TGS_DP_TRANSPORT=transport)     # "ipc": the peer buffers are rebuilt at every refinement (N changes)
     out = tmp_path / "out"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29671", "-m", "touch_gs_amd.train",
+                        "--master-addr", "127.0.0.1", "--master-port", free_port(), "-m", "touch_gs_amd.train",
                         "--synthetic", "4000", "160", "96", "--sh-degree", "1", "--max-num-iterations", "14",
                         "--steps-per-eval", "5", "--steps-per-save", "10", "--warmup-length", "4", "--refine-every", "4",
                         "--output-dir", str(out)],
@@ -826,7 +827,7 @@ def test_rccl_single_rank_process_group(dev, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "rccl_worker.py"
     script.write_text(_RCCL_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=free_port(), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                TGS_DP_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("TGS_DIST_BACKEND", None)
     r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
@@ -843,7 +844,7 @@ def test_bench_two_gpus_rccl(dev, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29651", os.path.join(root, "bench.py"),
+                        "--master-addr", "127.0.0.1", "--master-port", free_port(), os.path.join(root, "bench.py"),
                         "--gpus", "2", "--steps", "5", "--warmup", "2", "--config", "cfg2"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -864,7 +865,7 @@ def test_bench_two_ranks_share_one_gpu(dev):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, TGS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29657", os.path.join(root, "bench.py"),
+                        "--master-addr", "127.0.0.1", "--master-port", free_port(), os.path.join(root, "bench.py"),
                         "--gpus", "2", "--steps", "4", "--warmup", "2", "--config", "cfg2", "--no-cpu-baseline"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -1589,7 +1590,7 @@ def test_peer_transport_equals_collective_transport(dev, tmp_path, world, N, W, 
     script.write_text(_DP_TRANSPORT_WORKER)
     out = {}
     for i, transport in enumerate(("rccl", "ipc")):
-        port = str(29720 + 2 * world + i)
+        port = free_port()
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0",
                    TGS_DP_TRANSPORT=transport, CHUNKS="2", TGS_PEER_SAFE_FLAGS=safe)
         f = tmp_path / f"{transport}.pt"
@@ -1682,7 +1683,7 @@ def test_data_parallel_fullsize(dev, tmp_path, world, N, W, H, seed, transport):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "dp_full_worker.py"
     script.write_text(_DP_FULL_WORKER)
-    port = str(29680 + world + (20 if transport == "ipc" else 0))
+    port = free_port()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0",
                TGS_DP_TRANSPORT=transport)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
@@ -1707,8 +1708,9 @@ def test_data_parallel_four_ranks_batch_of_four(dev, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "dp4_worker.py"
     script.write_text(_DP4_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29671")
+    port = free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4",
-                        "--master-addr", "127.0.0.1", "--master-port", "29671", str(script), root],
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script), root],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DP4_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -133,3 +133,12 @@ def err_over_mass(got, ref, mass):
     form them from shared sums, so the Gaussian's largest component magnitude is the scale of all of them)."""
     got, ref, mass = (np.asarray(a, np.float64).reshape(np.asarray(ref).shape[0], -1) for a in (got, ref, mass))
     return np.abs(got - ref).max(1) / (mass.max(1) + 1e-300)
+
+
+def free_port() -> str:
+    """A TCP port nobody listens on right now (for torch.distributed.run --master-port): fixed numbers collide when two
+    multi-process tests run back to back and the first one's listener is still closing."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])

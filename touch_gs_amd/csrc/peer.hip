@@ -39,8 +39,8 @@ struct PeerDst {
 // cache maintenance) before it takes a ticket, and the one wave that sees the last ticket issues the single
 // system-scope release of the launch.  ASSUMPTION (never exercised across GPUs -- all ranks of every run so far shared
 // one device): the completion of a store to uncached memory means it is performed at its destination, also across
-// xGMI.  TGS_PEER_SAFE_FLAGS=1 (parallel.PeerExchange) does not rely on it: the data kernels then publish nothing and a
-// separate one-wave launch (tgs_peer_signal) raises the flags behind the kernel boundary.  (A system- or agent-scope fence per wave -- the textbook form -- writes back
+// xGMI.  parallel.PeerExchange's DEFAULT does not rely on it: it passes no flags to the data kernels and raises them with
+// a separate one-wave launch (tgs_peer_signal) behind the kernel boundary; TGS_PEER_SAFE_FLAGS=0 selects this in-kernel form.  (A system- or agent-scope fence per wave -- the textbook form -- writes back
 // the XCD's whole L2 every time: 8192 waves doing that took the 12 MB push to 165 us and the 44 MB rank-order sum to
 // 525 us; this form runs at copy speed.)
 __device__ __forceinline__ void publish(const PeerDst& d, int n, int32_t seq, int32_t* ticket) {

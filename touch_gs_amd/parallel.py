@@ -109,9 +109,11 @@ class PeerExchange:
                 self.base.append(p.value)
         self.seq = 0
         self.bytes_pushed = 0
-        # TGS_PEER_SAFE_FLAGS=1: the data kernels publish nothing, a separate launch raises the flags behind the kernel
-        # boundary (does not assume that a completed uncached store has arrived at a remote GPU; csrc/peer.hip)
-        self.safe_flags = os.environ.get("TGS_PEER_SAFE_FLAGS", "0") not in ("", "0")
+        # default: the data kernels publish nothing, a separate one-wave launch raises the flags behind the kernel
+        # boundary -- ordered by the stream alone.  TGS_PEER_SAFE_FLAGS=0: the last workgroup of the data kernel
+        # raises them itself (one launch less per transfer); that form assumes that a completed store to uncached
+        # memory has arrived at its destination (csrc/peer.hip), which no run has exercised across GPUs
+        self.safe_flags = os.environ.get("TGS_PEER_SAFE_FLAGS", "1") not in ("", "0")
         # everything a step needs is built ONCE: tensor views of the receive slots (torch.as_tensor on a raw pointer
         # queries the pointer's attributes: ~0.3 ms of host time each) and the host arrays of peer addresses
         A, r = self._arr, self.r
