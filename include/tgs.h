@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TGS_VERSION 200         /* 0.2.0 -- ABI break against 100: tgs_rasterize_fwd / tgs_rasterize_bwd[_band]
+#define TGS_VERSION 201         /* 0.2.1 -- 201: tile_start buffers are T+513 ints (512 scratch ints behind the starts); adds tgs_set_k7_quad.  200 broke the ABI of 100: tgs_rasterize_fwd / tgs_rasterize_bwd[_band]
                                    gained stop_pos; earlier (round 3, then unversioned): status is int32[4], the
                                    rasterize calls carry slot_ok, splat slots 0/1 are rect-relative */
 #define TGS_BLOCK 16            /* tile edge in pixels */
@@ -126,7 +126,10 @@ int tgs_sh_bwd(int N, int sh_deg, int sh_stride, const float* dirs, const float*
  * in : splats[N,12] (slot 11 is overwritten with the in-group intersection offset)
  * out: group_base[G]    start of each 256-Gaussian group's contiguous range in the pair index
  *                       space (G = tgs_num_groups; ranges are disjoint, their order is arbitrary)
- *      tile_start[T+1]  [start,end) of every tile's list; tile_start[T] = #intersections
+ *      tile_start[T+513] [start,end) of every tile's list; tile_start[T] = #intersections; the 512 ints behind it are
+ *                       scratch of the rasterizer: a pair of words per XCD, 256 B apart, that tgs_rasterize_fwd folds the
+ *                       frame's deepest walk and the sum of its walks into (zeroed here) and tgs_rasterize_bwd reads --
+ *                       tgs_set_k7_quad -- and, 128 B behind each pair, a slot counter of tgs_rasterize_bwd.  Since TGS_VERSION 201 the buffer is T+513 ints
  *      sorted_gid[cap]  Gaussian ids, per tile, front to back, ties by id
  *      tile_order[L]    (may be NULL; L = tgs_tile_order_len) tile visited by block b of K6 / K7:
  *                       block b runs on XCD b % 8; XCD x owns every 8th granule of 8 consecutive
@@ -212,6 +215,18 @@ size_t tgs_slot_ok_len(int W, int H, int64_t capacity);
  * setting as it is.  Defaults: environment TGS_K6_BLOCKS (1), TGS_K7_F2B (0), read once at first use.
  * Returns the settings in force: bit 0 = block-form K6, bit 1 = front-to-back K7. */
 int tgs_set_raster_variant(int k6_blocks_on, int k7_front_to_back);
+
+/* In a CHAIN-BOUND frame K7 gives every tile that walks more than min_walk list entries to a workgroup of FOUR waves
+ * (one per 8x8 quadrant) instead of one wave: in an object-centric scene a few hundred tiles carry walks of 700 - 1600
+ * entries while the whole frame would fit 100 - 200 per wave slot, and the launch lasted as long as its longest tile.
+ * A walk = how far into its list a tile's pixels reach; tgs_rasterize_fwd leaves the frame's deepest walk and the sum
+ * of all walks behind tile_start.  A frame is chain-bound if the deepest walk exceeds factor / 2 times the sum spread
+ * evenly over K7's 4096 wave slots.  Defaults: factor 8 (object-centric scenes of 100 - 300 k Gaussians at 720p qualify:
+ * K7 0.58 - 0.78 of its one-wave time; a uniform scene such as configs[2] or 1 M clustered Gaussians at 1080p do not),
+ * min_walk 48; environment TGS_K7_QUAD / TGS_K7_QUAD_MIN.  factor 0 = always one wave per tile; a negative argument
+ * leaves that setting.  Returns factor | min_walk << 8 in effect.  Results of the two forms differ by the rounding
+ * of one four-term sum per (tile, Gaussian). */
+int tgs_set_k7_quad(int factor, int min_walk);
 
 /* K7  compositing backward with the tactile depth/uncertainty loss fused in  (stands behind
  *     gsplat `rasterize_gaussians` bwd; spec App. B.7).

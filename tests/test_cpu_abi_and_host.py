@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"{s} declared in include/tgs.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in touch_gs_amd/_lib.py"
     assert set(_lib.SIGNATURES) == set(syms)
-    assert lib.tgs_version() == 200
+    assert lib.tgs_version() == 201
 
 
 def _declared_prototypes():

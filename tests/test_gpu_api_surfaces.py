@@ -935,7 +935,7 @@ def test_nerfstudio_adapter_core_trains(dev):
 
 
 @pytest.mark.parametrize("W,H", [(160, 96), (208, 144), (1920, 1080)])
-def test_pipelined_ssim_and_k7_bands_equal_the_sequential_step(dev, W, H):
+def test_pipelined_ssim_and_k7_bands_equal_the_sequential_step(dev, W, H, request):
     """SSIM pipelined by image bands behind K7 on a second stream (ModelConfig.pipeline_ssim;
     tgs_ssim_fwd_bwd_rows + tgs_rasterize_bwd_band): the bands partition the tiles, the band-wise SSIM
     gradient equals the whole-image one bit for bit, and three train steps leave the same parameters and
@@ -944,6 +944,10 @@ def test_pipelined_ssim_and_k7_bands_equal_the_sequential_step(dev, W, H):
     from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
     from touch_gs_amd.optim import GaussianParams
     from touch_gs_amd.scene import make_view, synthetic_gaussians
+    # a band launch of K7 keeps one wave per tile: the whole-image launch it is compared with bit for bit must too
+    # (in a chain-bound frame it would hand its long tiles to the four-wave kernel, tgs_set_k7_quad)
+    request.addfinalizer(lambda before=ops.set_k7_quad(): ops.set_k7_quad(*before))
+    ops.set_k7_quad(0)
     N = 4100 if W < 1000 else 60000
     views = [make_view(N, W, H, 3, 7, dev, view=v, n_views=4) for v in range(2)]
     P, _ = synthetic_gaussians(N, W, H, 3, 99)

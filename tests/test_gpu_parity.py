@@ -109,13 +109,27 @@ def test_rasterize_fwd(dev, N, W, H, deg, seed, clamp):
     assert np.abs(rgb.cpu().numpy() - out["rgb"].numpy()).max() < 0.02
 
 
+@pytest.fixture
+def k7_quad_everywhere():
+    """K7's four-waves-per-tile form (k_raster_bwd_quad) for every tile that walks more than 8 entries of (almost) any
+    frame, instead of only in chain-bound frames (the rule of tgs_set_k7_quad)."""
+    from touch_gs_amd import ops
+    before = ops.set_k7_quad()
+    ops.set_k7_quad(1, 8)
+    yield
+    ops.set_k7_quad(*before)
+
+
+@pytest.mark.parametrize("quad", [False, True])
 @pytest.mark.parametrize("N,W,H,deg,seed,clamp", [(2000, 128, 80, 3, 21, False), (500, 50, 35, 0, 22, False),
                                                    (2000, 128, 80, 3, 23, True), (2500, 64, 64, 1, 24, True)])
-def test_rasterize_bwd(dev, N, W, H, deg, seed, clamp):
+def test_rasterize_bwd(dev, N, W, H, deg, seed, clamp, quad, request):
     """clamp=True: a third of the Gaussians have opacity > 0.999 and e^2 larger axes, so that
     thousands of (pixel, Gaussian) pairs sit ON the alpha = 0.999 clamp, whose gradient App. B.7
-    passes through (K7: raster.hip `q *= max(exp2(-s)/0.999, 1)`)."""
+    passes through (K7: raster.hip `q *= max(exp2(-s)/0.999, 1)`).  quad: the same through K7's four-wave form."""
     from touch_gs_amd import ops
+    if quad:
+        request.getfixturevalue("k7_quad_everywhere")
     P, cam, acam, D, sp, gb, ts, sg, n = _blend_inputs(dev, N, W, H, deg, seed, clamp=clamp)
     rgb, depth, fT, fidx = ops.rasterize_fwd(acam, sp, sg, ts)
     g = torch.Generator().manual_seed(seed)
@@ -146,6 +160,72 @@ def test_rasterize_bwd(dev, N, W, H, deg, seed, clamp):
         bad = (err > 1e-3 * scale + 1e-4 * ref[k].abs()).double().mean().item()
         assert bad < 0.02 + 5 * (1 - frac_clear), (k, bad, frac_clear)
         assert np.median(relerr(got[k].numpy(), ref[k].numpy(), floor=1e-3 * scale)) < 3e-5, k
+
+
+@pytest.mark.parametrize("rule", [(8, 48), (1, 8)])
+def test_k7_quad_form_on_an_object_centric_scene(dev, rule):
+    """An object-centric scene (80 % of the Gaussians in the central tenth of the image) is chain-bound: a few tiles walk
+    hundreds of entries while the frame's balanced load is a few dozen per wave slot.  K7 then gives every tile that walks
+    more than min_walk entries to k_raster_bwd_quad (default rule (8, 48); (1, 8): almost every tile).  Against one wave per tile: the same tile losses bit for
+    bit (k_raster_bwd computes them for every tile), every (tile, Gaussian) partial record within rounding of the
+    record's own magnitude -- the quadrant totals are added in a different order, nothing else differs -- with the fused
+    loss of the train step (L1 + tactile depth / uncertainty) and with plain upstream gradients; poisoned partial
+    buffers show that every record of every listed pair is written by exactly one of the two kernels."""
+    from touch_gs_amd import ops
+    from touch_gs_amd.scene import make_camera, synthetic_gaussians
+    N, W, H, deg = 60_000, 640, 400, 3
+    P, intr = synthetic_gaussians(N, W, H, deg, 5, clustered=True)
+    D = {k: v.to(dev).float().contiguous() for k, v in P.items()}
+    cam = make_camera(intr, 1, 8, bg=(0.1, 0.2, 0.3))
+    sp, radii, gb, ts, sg, st = ops.project_bin_sort(cam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], deg)
+    rgb, depth, fT, _ = ops.rasterize_fwd(cam, sp, sg, ts)
+    n = (ts[1:cam.num_tiles + 1] - ts[:cam.num_tiles]).long()
+    I = int(n.sum())
+    TW, TH = (W + 15) // 16, (H + 15) // 16
+    pad = torch.zeros(TH * 16, TW * 16, dtype=torch.int64, device=dev)
+    pad[:H, :W] = fT.stop_pos.long().clamp(max=int(n.max()))
+    tmax = torch.minimum(pad.view(TH, 16, TW, 16).permute(0, 2, 1, 3).reshape(TH * TW, 256).max(1).values, n)
+    assert int(tmax.max()) * 8192 > int(tmax.sum()) * rule[0], (int(tmax.max()), int(tmax.sum()))   # chain-bound by tgs_set_k7_quad's rule
+    n_long = int((tmax > rule[1]).sum())
+    assert 0 < n_long < cam.num_tiles, (n_long, cam.num_tiles, I, int(tmax.max()))
+    g = torch.Generator().manual_seed(3)
+    gt = torch.rand(H, W, 3, generator=g).to(dev)
+    gd = (2 + 4 * torch.rand(H, W, generator=g)).to(dev)
+    gd[torch.rand(H, W, generator=g).to(dev) < 0.3] = 0.0
+    unc = (0.001 + 5 * torch.rand(H, W, generator=g)).to(dev)
+    loss = dict(gt_rgb=gt, l1_weight=0.8 / (3 * H * W), gt_depth=gd, depth_weight=0.2 / (H * W), uncertainty=unc,
+                uncertainty_weight=1.0, eps=1e-6)
+    v_rgb = torch.randn(H, W, 3, generator=g).to(dev)
+    v_d, v_a = torch.randn(H, W, generator=g).to(dev), torch.randn(H, W, generator=g).to(dev)
+    modes = {"loss": dict(v_rgb=v_rgb * 1e-6, loss=loss, want_tile_loss=True),          # the fused train step's form
+             "plain": dict(v_rgb=v_rgb, v_depth=v_d, v_alpha=v_a)}
+    before = ops.set_k7_quad()
+    try:
+        out = {}
+        for name, (f, mw) in (("one", (0, 192)), ("quad", rule)):
+            ops.set_k7_quad(f, mw)
+            for mode, kw in modes.items():
+                buf = torch.full((sg.shape[0], 12), float("nan"), device=dev)
+                partials, tl = ops.rasterize_bwd(cam, sp, gb, sg, ts, rgb, depth, fT, partials=buf, **kw)
+                out[name, mode] = (partials[:, :10].clone(), None if tl is None else tl.clone())
+    finally:
+        ops.set_k7_quad(*before)
+    for mode in modes:
+        a, ta = out["one", mode]
+        b, tb = out["quad", mode]
+        wa, wb = ~torch.isnan(a).any(dim=1), ~torch.isnan(b).any(dim=1)
+        assert torch.equal(wa, wb) and int(wa.sum()) == I      # every listed pair's record written, nothing else
+        assert torch.equal(torch.isnan(a), torch.isnan(b))
+        if ta is not None:
+            assert torch.equal(ta, tb)
+        a, b = a[wa], b[wa]
+        assert not torch.equal(a, b)                                    # the long tiles did take the other kernel
+        mag = a.abs().amax(dim=1, keepdim=True).clamp(min=1e-30)       # a record's own magnitude
+        rel = ((a - b).abs() / mag).amax(dim=1)
+        # (the moment terms of a record are differences of sums 10 - 100x their size: tile-centred second moments)
+        q99 = float(torch.quantile(rel[::max(1, rel.numel() // 4_000_000)], 0.99))
+        print(f"k7 quad vs one wave, {mode}: {n_long} long tiles of {cam.num_tiles}, max {float(rel.max()):.2e}, q99 {q99:.2e}")
+        assert float(rel.max()) < 3e-4 and q99 < 1e-5, (float(rel.max()), q99)
 
 
 @pytest.mark.parametrize("N,W,H,deg,seed", [(1500, 128, 80, 3, 31), (400, 64, 48, 2, 32), (400, 64, 48, 0, 33)])

@@ -162,6 +162,9 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int T, int NB, int32_t* __r
     }
   }
   if (b == NB - 1 && tid == 0) tile_start[T] = s_base + tot;
+  // 16 of the 512 scratch ints behind the tile starts collect the frame's deepest walk and the sum of its walks (K6,
+  // raster.hip publish_walk: a pair of words per XCD, 256 B apart) for K7
+  if (b == NB - 1 && tid >= 1 && tid <= 16) tile_start[T + 1 + 64 * ((tid - 1) >> 1) + ((tid - 1) & 1)] = 0;
 }
 
 // K3b: scatter (gid, depth bits) into the tile bins.  slot = tile_start + arrival rank.

@@ -190,6 +190,30 @@ __device__ __forceinline__ int stop_of(float smax) {
   return smax > 0.f ? TGS_NO_STOP : (int)(__float_as_uint(smax) & 0x3fffffffu);
 }
 
+// The frame's deepest walk -- how far into its list the busiest tile's pixels reach, = the length of K7's longest
+// chain -- is what decides whether K7 splits its tiles over four waves (frame_is_chain_bound).  Every K6 block folds
+// its tile's walk into two of the words behind the tile starts (maximum and sum, TGS_WALK_AT / TGS_WALKSUM_AT(T, XCC
+// id): one pair per L2, the scan kernel zeroed them); a pixel that never stopped walks the whole list.  Pixels outside the image keep smax > 0.
+#define TGS_WALK_WORDS 8
+// word x of the 512 scratch ints behind the tile starts: one XCD's words sit 256 B from the next one's and its two
+// words 128 B apart -- eight L2s updating neighbouring words of ONE line pass the line around for every atomic
+#define TGS_WALK_AT(T, x) ((T) + 1 + 64 * (x))
+#define TGS_WALKSUM_AT(T, x) ((T) + 1 + 64 * (x) + 1)
+#define TGS_SLOTCTR_AT(T, x) ((T) + 1 + 64 * (x) + 32)
+#define TGS_TILE_START_SCRATCH 512
+__device__ __forceinline__ void publish_walk(const int32_t* __restrict__ tile_start, int T_total, const float (&smax)[4],
+                                             int n, int lane) {
+  int wl = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) wl = max(wl, min(stop_of(smax[k]), n));
+  wl = wave_minmax_i<true>(wl);
+  if (lane == 0 && wl > 0) {
+    const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & (TGS_WALK_WORDS - 1));
+    atomicMax(const_cast<int32_t*>(tile_start) + TGS_WALK_AT(T_total, xcc), wl);
+    atomicAdd(const_cast<int32_t*>(tile_start) + TGS_WALKSUM_AT(T_total, xcc), wl);   // sum of the walks = K7's work
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K6 forward
 // ---------------------------------------------------------------------------------------------
@@ -327,6 +351,7 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
       if (stop_pos) stop_pos[p] = stop_of(smax[k]);
     }
   }
+  publish_walk(tile_start, T_total, smax, end - start, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -526,6 +551,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TGS_BLK_WAVE
       if (stop_pos) stop_pos[p] = stop_of(smax[k]);
     }
   }
+  publish_walk(tile_start, T_total, smax, end - start, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -806,6 +832,29 @@ __global__ __launch_bounds__(64) void k_raster_bwd_f2b(
 }
 
 
+// Which tiles go to the four-wave form of K7 (k_raster_bwd_quad).  Two launches in one stream run one after the other,
+// each as long as its longest chain, so the split is decided per FRAME: a frame is chain-bound if its deepest walk
+// (publish_walk: K6 leaves it behind the tile starts) exceeds factor / 2 times the load a wave slot would get if the
+// frame's walks (their sum, next to it) were spread evenly over the 4096 slots K7 has (256 CUs x 4 SIMDs x 4 waves).  Then every tile that walks more than min_walk entries is the
+// four-wave kernel's and the one-wave kernel only keeps the trivial rest; otherwise the four-wave launch returns at
+// once.  Measured per view (tools/k7_quad_probe.py, four waves / one wave): 0.58 - 0.69 at 100 k object-centric
+// Gaussians / 720p (ratios 5.6 - 12), 0.68 - 0.78 at 300 k (4.5 - 16); 0.97 - 1.30 at 1 M clustered / 1080p (1.7 - 7.9:
+// the four-wave form does 1.5x the work) and 1.4 - 1.6 on the uniform cfg3 (0.6 - 1.3).  The default factor 8 (ratio > 4)
+// takes the first two and leaves the others alone.  Both kernels evaluate the same predicate on the same words.
+// factor 0: never.
+struct QuadRule { int factor, min_walk; };
+__device__ __forceinline__ bool frame_is_chain_bound(const int32_t* __restrict__ tile_start, int T, QuadRule q) {
+  if (q.factor <= 0) return false;
+  int walk = 0;
+  long long work = 0;
+#pragma unroll
+  for (int i = 0; i < TGS_WALK_WORDS; i++) {
+    walk = max(walk, tile_start[TGS_WALK_AT(T, i)]);
+    work += tile_start[TGS_WALKSUM_AT(T, i)];
+  }
+  return (long long)walk * 8192 > work * q.factor;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K7 backward, back to front (round 4; the default)
 // ---------------------------------------------------------------------------------------------
@@ -836,7 +885,7 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
     const float* __restrict__ final_T, const int32_t* __restrict__ stop_pos, const float* __restrict__ v_rgb,
     const float* __restrict__ v_depth, const float* __restrict__ v_alpha, LossK loss,
     float* __restrict__ partials, float* __restrict__ tile_loss,
-    const int32_t* __restrict__ tile_order) {
+    const int32_t* __restrict__ tile_order, QuadRule quad) {
   const int tile = tile_order ? tile_order[blockIdx.x] : xcd_tile(blockIdx.x, T_total);
   if (tile >= T_total) return;
   const int lane = threadIdx.x;
@@ -905,6 +954,12 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
 #pragma unroll
   for (int k = 0; k < 4; k++) qlim[k] = wave_minmax_i<true>(lim[k]);
   const int tmax = max(max(qlim[0], qlim[1]), max(qlim[2], qlim[3]));
+  // (the slot counters of the four-wave launch that follows in the stream: 8 words behind the walk words)
+  if (blockIdx.x == 0 && lane < TGS_WALK_WORDS && quad.factor > 0)
+    const_cast<int32_t*>(tile_start)[TGS_SLOTCTR_AT(T_total, lane)] = 0;
+  // in a chain-bound frame every tile with a walk worth splitting is k_raster_bwd_quad's (four waves); its losses were
+  // written above
+  if (tmax > quad.min_walk && frame_is_chain_bound(tile_start, T_total, quad)) return;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   // behind the last stop position nothing received a gradient
   for (int i = start + tmax + lane; i < end; i += 64) {
@@ -1064,21 +1119,283 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// K7 for LONG tiles: four waves per tile, one per 8x8 quadrant
+// ---------------------------------------------------------------------------------------------
+// k_raster_bwd gives a tile to ONE wave, which walks the list entry by entry (~750 - 1000 cycles each when the wave is
+// alone on its SIMD).  In an object-centric scene -- the reference's kind: one object on a table -- a few hundred tiles
+// carry walks of 700 - 1600 entries while the frame's whole work would fit 100 - 200 entries per wave slot: the launch
+// lasts as long as its longest tile (tools/tile_load.py: critical path 4.5 - 16x the balanced load at 300 k Gaussians,
+// 720p) and most of the GPU idles.  Here a workgroup of four waves owns the tile: wave k keeps ONE pixel per lane (its
+// quadrant), walks only the entries whose quadrant bit is set and that its own pixels still reach, and reduces its 64
+// lanes with the same weighted transposed LDS read; the four quadrant totals of an entry meet in LDS at the end of the
+// batch.  Per entry a wave executes a third of the instructions, so the chain is ~2.5 - 3x shorter; the sum of the
+// work is ~25 % larger (one reduction per quadrant instead of one per tile), which is why only chain-bound frames
+// (frame_is_chain_bound) take this path.  Same decisions (the forward's compare on the same bits), same per-pixel arithmetic;
+// the quadrant totals are added in the order k = 0, 1, 2, 3 (deterministic; differs from the one-wave kernel's order
+// by rounding).  Losses (tile_loss) are k_raster_bwd's, which visits every tile first.
+__global__ __launch_bounds__(256) void k_raster_bwd_quad(
+    CamK cam, int T_total, const float* __restrict__ splats, const int32_t* __restrict__ group_base,
+    const int32_t* __restrict__ sorted_gid, const int32_t* __restrict__ tile_start,
+    const float* __restrict__ out_rgb, const float* __restrict__ out_depth,
+    const float* __restrict__ final_T, const int32_t* __restrict__ stop_pos, const float* __restrict__ v_rgb,
+    const float* __restrict__ v_depth, const float* __restrict__ v_alpha, LossK loss,
+    float* __restrict__ partials, const int32_t* __restrict__ tile_order, QuadRule quad, int n_slots) {
+  if (!frame_is_chain_bound(tile_start, T_total, quad)) return;   // the usual case: nothing to do (every wave alike)
+  const int tid = threadIdx.x, lane = tid & 63, k = tid >> 6;   // k = this wave's quadrant
+  __shared__ int s_qlim[4];
+  __shared__ int s_clamp;
+  __shared__ float4 recs[64 * 3];
+  __shared__ float4 sums[4 * 64 * 4];   // [quadrant][Gaussian j][16 slots]
+  constexpr int RED_RS = 68;
+  constexpr int RED_ROWS = 8;
+  __shared__ float4 red4[4 * RED_ROWS * RED_RS / 4];
+  // A resident grid takes the schedule's slots (block b of the one-wave kernel = entry b of tile_order) as workgroups
+  // become free: slot 8 i + x belongs to XCD x, whose workgroups draw i from the XCD's counter (zeroed by k_raster_bwd,
+  // the launch before this one) -- longest lists first, every tile on the XCD whose L2 holds its neighbours' records.
+  __shared__ int s_slot;
+  const int xcc = blockIdx.x & (TGS_XCDS - 1);    // workgroup b runs on XCD b % 8
+  int32_t* ctr = const_cast<int32_t*>(tile_start);
+  int turn = 0;     // own XCD first, then the others' leftovers (correct wherever the workgroups were placed)
+  for (;;) {
+  __syncthreads();                          // (the previous tile's s_slot / s_qlim have been read)
+  if (tid == 0) {
+    const int x = (xcc + turn) & (TGS_XCDS - 1);
+    s_slot = TGS_XCDS * atomicAdd(ctr + TGS_SLOTCTR_AT(T_total, x), 1) + x;
+  }
+  __syncthreads();
+  const int slot = __builtin_amdgcn_readfirstlane(s_slot);   // wave-uniform for the compiler too (scalar loads, scalar loops)
+  if (slot >= n_slots) {
+    if (++turn == TGS_XCDS) break;
+    continue;
+  }
+  const int tile = tile_order ? tile_order[slot] : xcd_tile(slot, T_total);
+  if (tile >= T_total) continue;
+  const int ty = tile / cam.TW, tx = tile - ty * cam.TW;
+  const int start = tile_start[tile], end = tile_start[tile + 1];
+  const int n = end - start;
+  if (n <= quad.min_walk) continue;
+  const int px = tx * TGS_BLOCK + 8 * (k & 1) + (lane & 7);
+  const int py = ty * TGS_BLOCK + 8 * (k >> 1) + (lane >> 3);
+  const bool inb = px < cam.W && py < cam.H;
+  const size_t p = (size_t)py * cam.W + px;
+  const int lim = inb ? min(stop_pos[p], n) : 0;   // number of leading list positions that may contribute to this pixel
+  const int qlim = wave_minmax_i<true>(lim);
+  if (lane == 0) s_qlim[k] = qlim;
+  __syncthreads();
+  const int tmax = max(max(s_qlim[0], s_qlim[1]), max(s_qlim[2], s_qlim[3]));
+  if (tmax <= quad.min_walk) continue;   // k_raster_bwd's tile
+
+  // per-pixel state, the arithmetic of k_raster_bwd's prologue for pixel slot k of the lane
+  float T = 1.f, vCr = 0.f, vCg = 0.f, vCb = 0.f, vD = 0.f, SX = 0.f;
+  if (inb) {
+    const float Tf = final_T[p];
+    T = Tf;
+    float vA = v_alpha ? v_alpha[p] : 0.f;
+    if (v_rgb) { vCr = v_rgb[3 * p]; vCg = v_rgb[3 * p + 1]; vCb = v_rgb[3 * p + 2]; }
+    if (v_depth) vD = v_depth[p];
+    if (loss.on) {
+      if (loss.gt_rgb) {
+        const float d0 = out_rgb[3 * p] - loss.gt_rgb[3 * p];
+        const float d1 = out_rgb[3 * p + 1] - loss.gt_rgb[3 * p + 1];
+        const float d2 = out_rgb[3 * p + 2] - loss.gt_rgb[3 * p + 2];
+        vCr += loss.l1w * ((d0 > 0.f) - (d0 < 0.f));
+        vCg += loss.l1w * ((d1 > 0.f) - (d1 < 0.f));
+        vCb += loss.l1w * ((d2 > 0.f) - (d2 < 0.f));
+      }
+      if (loss.gt_depth) {
+        const float gd = loss.gt_depth[p];
+        if (gd > 0.f) {
+          const float alpha = fmaxf(1.f - Tf, 1e-10f);
+          const float ia = 1.0f / alpha;
+          const float dhat = out_depth[p] * ia;
+          const float r = dhat - gd;
+          float wgt = loss.dw;
+          if (loss.unc) wgt = wgt / (loss.uw * loss.unc[p] + loss.eps);
+          const float gdh = 2.f * wgt * r;
+          vD += gdh * ia;
+          if (1.f - Tf > 1e-10f) vA += -gdh * dhat * ia;
+        }
+      }
+    }
+    const float bgdot = cam.bg[0] * vCr + cam.bg[1] * vCg + cam.bg[2] * vCb;
+    SX = -Tf * (vA - bgdot);
+  }
+  // pixel constants of the quadrant (the operands eval_s takes for slot k)
+  const PixConst pc = make_pix_const(lane);
+  const float pu = (k & 1) ? pc.u[1] : pc.u[0], pv = (k >> 1) ? pc.v[1] : pc.v[0];
+  const float puu = (k & 1) ? pc.uu[1] : pc.uu[0], pvv = (k >> 1) ? pc.vv[1] : pc.vv[0];
+  const float puv = k == 0 ? pc.uv[0] : (k == 1 ? pc.uv[1] : (k == 2 ? pc.uv[2] : pc.uv[3]));
+  const float q5 = (k & 1) ? 1.f : 0.f, q6 = (k >> 1) ? 1.f : 0.f;   // Sx / Sy rows: the quadrant's 8-pixel offset
+
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = start + tmax + tid; i < end; i += 256) {   // behind the last stop position nothing received a gradient
+    const int gid = sorted_gid[i];
+    const size_t P = pair_index(group_base, gid, ld4(splats + (size_t)gid * TGS_SPLAT_FLOATS + 8), tx, ty);
+    float* o = partials + P * TGS_PARTIAL_FLOATS;
+    st4(o, z4); st4(o + 4, z4); st4(o + 8, z4);
+  }
+
+  float* red = reinterpret_cast<float*>(red4) + k * (RED_ROWS * RED_RS);
+  float4* sums_k = sums + k * (64 * 4);
+  const int red_c = lane & 15;
+  const int red_part = (lane >> 4) ^ ((red_c >= 4 && red_c < 12) ? 1 : 0);
+  float wt[16];
+  const float* red_rd;
+  {
+    const unsigned long long ROWS = 0x0076454645443210ull;
+    red_rd = red + (int)((ROWS >> (4 * red_c)) & 15ull) * RED_RS + red_part * 16;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const float u0 = (float)(i & 7) - 7.5f;
+      const float v0 = (float)(2 * red_part + (i >> 3)) - 7.5f;
+      float w = 1.f;                                   // c 0..4, 13
+      w = (red_c == 5) ? u0 : w;
+      w = (red_c == 7) ? v0 : w;
+      w = (red_c == 6 || red_c == 8) ? 8.f : w;
+      w = (red_c == 9) ? u0 * u0 : w;
+      w = (red_c == 11) ? v0 * v0 : w;
+      w = (red_c == 10) ? 16.f * u0 + 64.f : w;
+      w = (red_c == 12) ? 16.f * v0 + 64.f : w;
+      w = (red_c >= 14) ? 0.f : w;
+      wt[i] = w;
+    }
+  }
+  for (int base = start + ((tmax - 1) & ~63); base >= start; base -= 64) {
+    const int rel = base - start;
+    const int cnt = min(64, tmax - rel);
+    size_t P = 0;
+    float4 a0 = z4, a1 = z4;
+    __syncthreads();                        // the previous batch's records and totals have been consumed
+    if (k == 0) {
+      if (lane < cnt) {
+        const int gid = sorted_gid[base + lane];
+        const float* r = splats + (size_t)gid * TGS_SPLAT_FLOATS;
+        a0 = ld4(r); a1 = ld4(r + 4);
+        const float4 a2 = ld4(r + 8);
+        float gx, gy;
+        centre_rel(a0, a2, tx, ty, cam.pix_center, gx, gy);
+        a0.x = gx; a0.y = gy;                       // kept for the conversion of the moments below
+        const TileRec t = make_tile_rec(a0, a1, a2, gx, gy);
+        recs[lane * 3] = t.a; recs[lane * 3 + 1] = t.b; recs[lane * 3 + 2] = t.c;
+        P = pair_index(group_base, gid, a2, tx, ty);
+      }
+      const unsigned long long hot = __ballot(lane < cnt && a0.w > CLAMP_FREE_OPACITY);
+      if (lane == 0) s_clamp = hot != 0ull;
+    }
+    sums_k[lane * 4] = z4; sums_k[lane * 4 + 1] = z4; sums_k[lane * 4 + 2] = z4; sums_k[lane * 4 + 3] = z4;
+    __syncthreads();
+
+    // this quadrant's entries: mask bit k, below the quadrant's own furthest stop position
+    const unsigned my_mask = lane < cnt ? __float_as_uint(recs[lane * 3 + 2].w) : 0u;
+    const int r = qlim - rel;
+    const unsigned long long keep = r >= 64 ? ~0ull : (r <= 0 ? 0ull : ((1ull << r) - 1ull));
+    const unsigned long long rem0 = __ballot((my_mask >> k) & 1u) & keep;
+    auto walk = [&](auto mayclamp) {
+    constexpr bool MAYCLAMP = decltype(mayclamp)::value;
+    unsigned long long rem = rem0;
+    while (rem) {
+      const int j = 63 - __builtin_clzll(rem);
+      rem &= ~(1ull << j);
+      const float4 qa = recs[j * 3], qb = recs[j * 3 + 1], qc = recs[j * 3 + 2];
+      const int pos = rel + j;
+      float s = fmaf(qa.y, pu, qa.x);          // eval_s for slot k
+      s = fmaf(qa.z, pv, s);
+      s = fmaf(qa.w, puu, s);
+      s = fmaf(qb.x, puv, s);
+      s = fmaf(qb.y, pvv, s);
+      const float e = __builtin_amdgcn_exp2f(-s);
+      const float al0 = MAYCLAMP ? fminf(ALPHA_MAX, e) : e;
+      const bool ok = s <= LOG2_255, in = pos < lim;
+      const bool go = ok & in;
+      const unsigned long long gob = __builtin_amdgcn_ballot_w64(ok) & __builtin_amdgcn_ballot_w64(in);
+      const float al = go ? al0 : 0.f;
+      const float ra = __builtin_amdgcn_rcpf(1.0f - al);
+      const float Tp = T * ra;
+      const float w = al * Tp;
+      float cv = qb.w * vCr;
+      cv = fmaf(qc.x, vCg, cv); cv = fmaf(qc.y, vCb, cv); cv = fmaf(qb.z, vD, cv);
+      const float z = w * cv;
+      float q = fmaf(-(al * ra), SX, z);
+      if constexpr (MAYCLAMP) q *= fmaxf(e * (1.0f / ALPHA_MAX), 1.0f);
+      SX += z;
+      T = Tp;
+      if (gob != 0ull) {
+        red[0 * RED_RS + lane] = w * vCr; red[1 * RED_RS + lane] = w * vCg;
+        red[2 * RED_RS + lane] = w * vCb; red[3 * RED_RS + lane] = w * vD;
+        red[4 * RED_RS + lane] = q; red[5 * RED_RS + lane] = q * q5;
+        red[6 * RED_RS + lane] = q * q6; red[7 * RED_RS + lane] = q * puv;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float4 r0 = ld4(red_rd), r1 = ld4(red_rd + 4), r2 = ld4(red_rd + 8), r3 = ld4(red_rd + 12);
+        float o0 = r0.x * wt[0], o1 = r1.x * wt[4], o2 = r2.x * wt[8], o3 = r3.x * wt[12];
+        o0 = fmaf(r0.y, wt[1], o0); o1 = fmaf(r1.y, wt[5], o1); o2 = fmaf(r2.y, wt[9], o2); o3 = fmaf(r3.y, wt[13], o3);
+        o0 = fmaf(r0.z, wt[2], o0); o1 = fmaf(r1.z, wt[6], o1); o2 = fmaf(r2.z, wt[10], o2); o3 = fmaf(r3.z, wt[14], o3);
+        o0 = fmaf(r0.w, wt[3], o0); o1 = fmaf(r1.w, wt[7], o1); o2 = fmaf(r2.w, wt[11], o2); o3 = fmaf(r3.w, wt[15], o3);
+        float O = (o0 + o1) + (o2 + o3);
+        O = fold_xor16(O);
+        O = fold_xor32(O);
+        if (lane < 16) reinterpret_cast<float*>(sums_k)[j * 16 + lane] = O;
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    };
+    if (s_clamp) walk(std::true_type{});
+    else walk(std::false_type{});
+    __syncthreads();
+    if (k == 0 && lane < cnt) {
+      float4 s0 = sums[lane * 4], s1 = sums[lane * 4 + 1], s2 = sums[lane * 4 + 2], s3 = sums[lane * 4 + 3];
+#pragma unroll
+      for (int w = 1; w < 4; w++) {        // quadrant totals in the order 0, 1, 2, 3
+        const float4* sw = sums + w * (64 * 4) + lane * 4;
+        const float4 t0 = sw[0], t1 = sw[1], t2 = sw[2], t3 = sw[3];
+        s0.x += t0.x; s0.y += t0.y; s0.z += t0.z; s0.w += t0.w;
+        s1.x += t1.x; s1.y += t1.y; s1.z += t1.z; s1.w += t1.w;
+        s2.x += t2.x; s2.y += t2.y; s2.z += t2.z; s2.w += t2.w;
+        s3.x += t3.x; s3.y += t3.y; s3.z += t3.z; s3.w += t3.w;
+      }
+      const float gx = a0.x, gy = a0.y;           // centre relative to the tile centre (set while staging)
+      const float A = a1.x, B = a1.y, Cc = a1.z;
+      const float Q0 = s1.x, Qu = s1.y + s1.z, Qv = s1.w + s2.x, Quu = s2.y + s2.z, Qvv = s2.w + s3.x, Quv = s3.y;
+      const float Mx = -(gx * Q0 - Qu), My = -(gy * Q0 - Qv);
+      const float Mxx = -(gx * gx * Q0 - 2.f * gx * Qu + Quu);
+      const float Mxy = -(gx * gy * Q0 - gx * Qv - gy * Qu + Quv);
+      const float Myy = -(gy * gy * Q0 - 2.f * gy * Qv + Qvv);
+      float* o = partials + P * TGS_PARTIAL_FLOATS;
+      st4(o, make_float4(A * Mx + B * My, B * Mx + Cc * My, s0.w, Q0 / a0.w));
+      st4(o + 4, make_float4(0.5f * Mxx, Mxy, 0.5f * Myy, s0.x));
+      st4(o + 8, make_float4(s0.y, s0.z, 0.f, 0.f));
+    }
+  }
+  }   // slots
+}
+
 }  // namespace
 
 // Run-time switches, read from the environment ONCE (first use) and settable through the C ABI afterwards
 // (tgs_rasterize_fwd used to call getenv on every launch).
-static int g_k6_blocks = -1, g_k7_f2b = -1;
+static int g_k6_blocks = -1, g_k7_f2b = -1, g_k7_quad = -1, g_k7_quad_min = -1;
 static int env_flag(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
 static int k6_blocks() { if (g_k6_blocks < 0) g_k6_blocks = env_flag("TGS_K6_BLOCKS", 1) != 0; return g_k6_blocks; }
 static int k7_f2b() { if (g_k7_f2b < 0) g_k7_f2b = env_flag("TGS_K7_F2B", 0) != 0; return g_k7_f2b; }
+// TGS_K7_QUAD: frame_is_chain_bound()'s factor (default 8: deepest walk beyond 4x the balanced per-slot load); 0 = one wave per tile always
+static int k7_quad() { if (g_k7_quad < 0) g_k7_quad = max(env_flag("TGS_K7_QUAD", 8), 0); return g_k7_quad; }
+static int k7_quad_min() { if (g_k7_quad_min < 0) g_k7_quad_min = max(env_flag("TGS_K7_QUAD_MIN", 48), 0); return g_k7_quad_min; }
 extern "C" int tgs_set_raster_variant(int k6_blocks_on, int k7_front_to_back) {
   if (k6_blocks_on >= 0) g_k6_blocks = k6_blocks_on != 0;
   if (k7_front_to_back >= 0) g_k7_f2b = k7_front_to_back != 0;
   return (k6_blocks() ? 1 : 0) | (k7_f2b() ? 2 : 0);
+}
+
+extern "C" int tgs_set_k7_quad(int factor, int min_walk) {
+  if (factor >= 0) g_k7_quad = factor;
+  if (min_walk >= 0) g_k7_quad_min = min_walk;
+  return k7_quad() | (k7_quad_min() << 8);
 }
 
 extern "C" int tgs_rasterize_fwd(const TgsCamera* cam, const float* splats,
@@ -1154,9 +1471,19 @@ static int rasterize_bwd_impl(const TgsCamera* cam, const float* splats,
                        (const unsigned long long*)slot_ok);
   } else {
     TGS_CHECK_ARG(stop_pos, "stop_pos (written by tgs_rasterize_fwd) is required");
+    QuadRule qf;
+    qf.factor = band >= 0 ? 0 : k7_quad();   // (a band launch keeps one wave per tile)
+    qf.min_walk = k7_quad_min();
     hipLaunchKernelGGL(k_raster_bwd, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T, splats,
                        group_base, sorted_gid, tile_start, out_rgb, out_depth, final_T, stop_pos,
-                       v_rgb, v_depth, v_alpha, lk, partials, tile_loss, tile_order);
+                       v_rgb, v_depth, v_alpha, lk, partials, tile_loss, tile_order, qf);
+    if (qf.factor > 0) {
+      TGS_CHECK_LAUNCH();
+      // 5 workgroups of 28 KB LDS fit a CU: 1280 resident workgroups walk the schedule
+      hipLaunchKernelGGL(k_raster_bwd_quad, dim3(min(grid, 1280)), dim3(256), 0, (hipStream_t)stream, k, T, splats,
+                         group_base, sorted_gid, tile_start, out_rgb, out_depth, final_T, stop_pos,
+                         v_rgb, v_depth, v_alpha, lk, partials, tile_order, qf, grid);
+    }
   }
   TGS_CHECK_LAUNCH();
   return TGS_OK;

@@ -139,7 +139,7 @@ def bin_sort(cam: Camera, splats, budget: Optional[IntersectBudget] = None):
     G = lib.tgs_num_groups(N)
     cs = cam.c_struct()
     group_base = torch.empty(max(G, 1), dtype=torch.int32, device=dev)
-    tile_start = torch.empty(T + 1, dtype=torch.int32, device=dev)
+    tile_start = torch.empty(T + 1 + 512, dtype=torch.int32, device=dev)[:T + 1]   # + 512 scratch ints of the rasterizer (tgs.h)
     nc = lib.tgs_tile_counter_len(cam.W, cam.H)
     counters = torch.empty(nc + 4, dtype=torch.int32, device=dev)   # per-XCD tile counters + sub-list starts | status[4]
     tile_cursor, status, status4 = counters[:nc], counters[nc:nc + 2], counters[nc:]
@@ -213,7 +213,7 @@ class FrontBuffers:
         self.splats = torch.empty(max(N, 1), SPLAT_FLOATS, dtype=torch.float32, device=dev)[:N]  # non-null even for N = 0
         self.radii = torch.empty(N, dtype=torch.int32, device=dev) if want_radii else None
         self.group_base = torch.empty(max(lib.tgs_num_groups(N), 1), dtype=torch.int32, device=dev)
-        self.tile_start = torch.empty(T + 1, dtype=torch.int32, device=dev)
+        self.tile_start = torch.empty(T + 1 + 512, dtype=torch.int32, device=dev)[:T + 1]   # + 512 scratch ints of the rasterizer (tgs.h)
         nc = lib.tgs_tile_counter_len(cam.W, cam.H)
         counters = torch.empty(nc + 4, dtype=torch.int32, device=dev)   # per-XCD tile counters + sub-list starts | status[4]
         self.tile_cursor, self.status, self.status4 = counters[:nc], counters[nc:nc + 2], counters[nc:]
@@ -366,6 +366,14 @@ def set_raster_variant(k6_blocks: Optional[bool] = None, k7_front_to_back: Optio
     setting alone.  Returns the settings in force (bit 0 = block-form K6, bit 1 = front-to-back K7)."""
     f = lambda v: -1 if v is None else int(bool(v))
     return _lib.load().tgs_set_raster_variant(f(k6_blocks), f(k7_front_to_back))
+
+
+def set_k7_quad(factor: Optional[int] = None, min_walk: Optional[int] = None):
+    """K7's four-waves-per-tile form for the tiles of chain-bound frames (deepest walk > factor / 2 x the balanced
+    per-slot load; tgs_set_k7_quad; defaults factor 8, min_walk 48; factor 0 = one wave per tile always; None leaves
+    a setting).  Returns (factor, min_walk) in effect."""
+    r = _lib.load().tgs_set_k7_quad(-1 if factor is None else int(factor), -1 if min_walk is None else int(min_walk))
+    return r & 255, r >> 8
 
 
 def _stop_pos_of(fT, stop_pos=None):
