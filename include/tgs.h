@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TGS_VERSION 201         /* 0.2.1 -- 201: tile_start buffers are T+513 ints (512 scratch ints behind the starts); adds tgs_set_k7_quad.  200 broke the ABI of 100: tgs_rasterize_fwd / tgs_rasterize_bwd[_band]
+#define TGS_VERSION 201         /* 0.2.1 -- 201: tile_start buffers are T+513 ints (512 scratch ints behind the starts); adds tgs_set_k7_quad, tgs_set_k6_split.  200 broke the ABI of 100: tgs_rasterize_fwd / tgs_rasterize_bwd[_band]
                                    gained stop_pos; earlier (round 3, then unversioned): status is int32[4], the
                                    rasterize calls carry slot_ok, splat slots 0/1 are rect-relative */
 #define TGS_BLOCK 16            /* tile edge in pixels */
@@ -227,6 +227,13 @@ int tgs_set_raster_variant(int k6_blocks_on, int k7_front_to_back);
  * leaves that setting.  Returns factor | min_walk << 8 in effect.  Results of the two forms differ by the rounding
  * of one four-term sum per (tile, Gaussian). */
 int tgs_set_k7_quad(int factor, int min_walk);
+
+/* The forward's counterpart for tiles with LONG lists: a tile whose list is longer than max(256, factor * I / 4096) --
+ * factor (default 4, environment TGS_K6_SPLIT) times the per-slot load of an even spread -- among the first 512 entries
+ * of the tile_order schedule is composited by FOUR blocks of the same launch, one 8x8 quadrant each (pixels are
+ * independent: nothing to exchange; same images, final_T and stop positions bit for bit).  Block-form forward with a
+ * tile_order only.  factor 0 = never; negative leaves it.  Returns the factor in effect. */
+int tgs_set_k6_split(int factor);
 
 /* K7  compositing backward with the tactile depth/uncertainty loss fused in  (stands behind
  *     gsplat `rasterize_gaussians` bwd; spec App. B.7).

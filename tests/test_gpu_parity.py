@@ -394,6 +394,45 @@ def test_k6_block_form_is_bit_identical(dev, monkeypatch, N, W, H, seed, clamp):
     assert bool((stop[stopped] > fidx[stopped]).all()) and bool(stopped.any())
 
 
+@pytest.mark.parametrize("want_idx", [False, True])
+def test_k6_quadrant_split_of_long_tiles_is_bit_identical(dev, want_idx):
+    """The forward composites a tile with a long list with FOUR blocks of the same launch, one 8x8 quadrant each
+    (raster_fwd_quadrant; tgs_set_k6_split): images, depth, final T, stop positions (and the last-contributor index)
+    equal bit for bit to the unsplit launch, on an object-centric scene where the default rule splits the dense centre,
+    with the rule forced onto every tile of the schedule's head (factor 1 at a tiny scene: lists > 256), and on a
+    ragged image (width and height not multiples of 16).  The walk words K7's rule reads stay consistent: same maximum,
+    a sum within the quarter-rounding of the split tiles."""
+    from touch_gs_amd import ops
+    from touch_gs_amd.scene import make_camera, synthetic_gaussians
+    before = ops.set_k6_split()
+    try:
+        for N, W, H, factor in ((60_000, 640, 400, 4), (30_000, 250, 170, 1)):
+            P, intr = synthetic_gaussians(N, W, H, 3, 5, clustered=True)
+            D = {k: v.to(dev).float().contiguous() for k, v in P.items()}
+            cam = make_camera(intr, 1, 8, bg=(0.1, 0.2, 0.3))
+            sp, radii, gb, ts, sg, st = ops.project_bin_sort(cam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], 3)
+            T = cam.num_tiles
+            n = (ts[1:T + 1] - ts[:T]).long()
+            I = int(n.sum())
+            n_split = int((n > max(256, (I * factor) >> 12)).sum())
+            assert 0 < n_split < T, (n_split, T, I, int(n.max()))
+            words = lambda: torch.as_strided(ts, (8, 2), (64, 1), T + 1).clone()     # (max, sum) per XCD behind the tile starts
+            res, ww = [], []
+            for f in (0, factor):
+                ops.set_k6_split(f)
+                torch.as_strided(ts, (8, 2), (64, 1), T + 1).zero_()                  # (the scan zeroes them once per frame)
+                out = ops.rasterize_fwd(cam, sp, sg, ts, want_idx=want_idx)
+                res.append([o for o in out if o is not None] + [out[2].stop_pos])
+                ww.append(words())
+            for a, b in zip(*res):
+                assert torch.equal(a, b), (a.float() - b.float()).abs().max().item()
+            assert int(ww[0][:, 0].max()) == int(ww[1][:, 0].max()) > 0
+            s0, s1 = int(ww[0][:, 1].sum()), int(ww[1][:, 1].sum())
+            assert s0 > 0 and abs(s1 - s0) <= 0.5 * s0, (s0, s1)
+    finally:
+        ops.set_k6_split(before)
+
+
 def test_deterministic_bitwise(dev):
     from touch_gs_amd import ops
     P, cam = scene(5000, 200, 120, 3, 61)

@@ -59,6 +59,7 @@ SIGNATURES = {
     "tgs_rasterize_fwd": (C.c_int, [C.POINTER(TgsCamera), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "tgs_set_raster_variant": (C.c_int, [_I, _I]),
     "tgs_set_k7_quad": (C.c_int, [_I, _I]),
+    "tgs_set_k6_split": (C.c_int, [_I]),
     "tgs_slot_ok_len": (C.c_size_t, [_I, _I, C.c_int64]),
     "tgs_rasterize_bwd": (C.c_int, [C.POINTER(TgsCamera)] + [_P] * 12 + [C.POINTER(TgsLossSpec), _P, _P, _P, _P]),
     "tgs_rasterize_bwd_band": (C.c_int, [C.POINTER(TgsCamera)] + [_P] * 12 + [C.POINTER(TgsLossSpec), _P, _P, _I, _P, _P]),

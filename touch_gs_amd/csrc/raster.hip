@@ -419,14 +419,116 @@ typedef std::conditional<BLK_U == 4, unsigned int, std::conditional<BLK_U == 2, 
 #ifndef TGS_BLK_WAVES
 #define TGS_BLK_WAVES 4    // minimum waves per SIMD asked of the register allocator: 4 (89 VGPRs) and 6 (80) measure the same
 #endif
+// One 8x8 quadrant of a tile, one pixel per lane: the forward's form for tiles with LONG lists.  A tile's pixels are
+// independent of each other, so the four quadrants of such a tile go to four blocks of the SAME launch (the tile's own
+// block takes quadrant 0, three extra blocks at the end of the grid the others) with nothing to exchange: the wave that
+// would walk ~1600 entries for 256 pixels walks the ~half of them that reach its quadrant, for 64, while the rest of the
+// GPU -- idle in an object-centric frame, whose longest tile IS the launch -- hosts the other three.  Same
+// staging, same blend_step on the same bits per pixel: images, final_T and stop positions bit for bit those of the other forms.
+template <bool WANT_IDX>
+__device__ __forceinline__ void raster_fwd_quadrant(
+    const CamK& cam, int T_total, const float* __restrict__ splats, const int32_t* __restrict__ sorted_gid,
+    const int32_t* __restrict__ tile_start, float* __restrict__ out_rgb, float* __restrict__ out_depth,
+    float* __restrict__ final_T, int32_t* __restrict__ final_idx, int32_t* __restrict__ stop_pos,
+    int tile, int k, float4* __restrict__ recs) {
+  const int lane = threadIdx.x;
+  const int ty = tile / cam.TW, tx = tile - ty * cam.TW;
+  const PixConst pc = make_pix_const(lane);
+  const float pu = (k & 1) ? pc.u[1] : pc.u[0], pv = (k >> 1) ? pc.v[1] : pc.v[0];
+  const float puu = (k & 1) ? pc.uu[1] : pc.uu[0], pvv = (k >> 1) ? pc.vv[1] : pc.vv[0];
+  const float puv = k == 0 ? pc.uv[0] : (k == 1 ? pc.uv[1] : (k == 2 ? pc.uv[2] : pc.uv[3]));
+  const int px = tx * TGS_BLOCK + 8 * (k & 1) + (lane & 7);
+  const int py = ty * TGS_BLOCK + 8 * (k >> 1) + (lane >> 3);
+  const bool inb = px < cam.W && py < cam.H;
+  float smax = inb ? LOG2_255 : -3.0e38f;
+  float T = 1.f, Cr = 0.f, Cg = 0.f, Cb = 0.f, D = 0.f;
+  int last = -1;
+  const int start = tile_start[tile], end = tile_start[tile + 1];
+  for (int base = start; base < end; base += 64) {
+    if (__ballot(smax > 0.f) == 0ull) break;
+    __syncthreads();
+    unsigned my_mask = 0u;
+    if (base + lane < end) {
+      const float* r = splats + (size_t)sorted_gid[base + lane] * TGS_SPLAT_FLOATS;
+      const float4 q0 = ld4(r), q1 = ld4(r + 4), q2 = ld4(r + 8);
+      float gx, gy;
+      centre_rel(q0, q2, tx, ty, cam.pix_center, gx, gy);
+      TileRec t = make_tile_rec(q0, q1, q2, gx, gy);
+      t.c.z = stop_code(base - start + lane);
+      recs[lane * 3] = t.a; recs[lane * 3 + 1] = t.b; recs[lane * 3 + 2] = t.c;
+      my_mask = __float_as_uint(t.c.w);
+    }
+    __syncthreads();
+    unsigned long long rem = __ballot((my_mask >> k) & 1u);
+    while (rem) {
+      const int j = __builtin_ctzll(rem);
+      rem &= rem - 1;
+      const float4 qa = recs[j * 3], qb = recs[j * 3 + 1], qc = recs[j * 3 + 2];
+      float s = fmaf(qa.y, pu, qa.x);          // eval_s for slot k
+      s = fmaf(qa.z, pv, s);
+      s = fmaf(qa.w, puu, s);
+      s = fmaf(qb.x, puv, s);
+      s = fmaf(qb.y, pvv, s);
+      float Tn; bool go;
+      unsigned long long okb = 0ull;
+      const float al = blend_step<true, 0>(s, T, smax, Tn, go, okb, qc.z);
+      const float w = al * T;
+      Cr = fmaf(w, qb.w, Cr); Cg = fmaf(w, qc.x, Cg);
+      Cb = fmaf(w, qc.y, Cb); D = fmaf(w, qb.z, D);
+      T = go ? Tn : T;
+      if (WANT_IDX) last = go ? (base - start + j) : last;
+    }
+  }
+  if (inb) {
+    const size_t p = (size_t)py * cam.W + px;
+    out_rgb[3 * p] = Cr + T * cam.bg[0];
+    out_rgb[3 * p + 1] = Cg + T * cam.bg[1];
+    out_rgb[3 * p + 2] = Cb + T * cam.bg[2];
+    out_depth[p] = D;
+    final_T[p] = T;
+    if (WANT_IDX) final_idx[p] = last;
+    if (stop_pos) stop_pos[p] = stop_of(smax);
+  }
+  // the quadrant's walk: the maximum is the tile's once all four have reported; a quarter each into the sum
+  int wl = wave_minmax_i<true>(min(stop_of(smax), end - start));
+  if (lane == 0 && wl > 0) {
+    const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & (TGS_WALK_WORDS - 1));
+    atomicMax(const_cast<int32_t*>(tile_start) + TGS_WALK_AT(T_total, xcc), wl);
+    atomicAdd(const_cast<int32_t*>(tile_start) + TGS_WALKSUM_AT(T_total, xcc), (wl + 3) >> 2);
+  }
+}
+
+// Which tiles the forward splits into quadrant blocks: lists longer than max(256, factor x I / 4096) -- factor (default 4)
+// times what a wave slot would hold if the frame's I intersections were spread evenly -- among the first `heads` entries
+// of the schedule (longest lists first: extra blocks are only launched for those).  cfg3 never qualifies.
+struct SplitRule { int factor, n_slots, heads; };
+__device__ __forceinline__ bool tile_is_split(int n, int I, SplitRule r) {
+  return r.factor > 0 && n > max(256, (int)(((long long)I * r.factor) >> 12));
+}
+
 template <bool WANT_IDX>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TGS_BLK_WAVES, 8))) void k_raster_fwd_blocks(
     CamK cam, int T_total, const float* __restrict__ splats, const int32_t* __restrict__ sorted_gid,
     const int32_t* __restrict__ tile_start, float* __restrict__ out_rgb,
     float* __restrict__ out_depth, float* __restrict__ final_T, int32_t* __restrict__ final_idx,
-    const int32_t* __restrict__ tile_order, int32_t* __restrict__ stop_pos) {
-  const int tile = tile_order ? tile_order[blockIdx.x] : xcd_tile(blockIdx.x, T_total);
+    const int32_t* __restrict__ tile_order, int32_t* __restrict__ stop_pos, SplitRule split) {
+  __shared__ float4 recs[65 * 3];                 // 64 staged Gaussians + the null record (alpha = 0)
+  int slot = blockIdx.x, part = -1;
+  if (slot >= split.n_slots) {                    // extra blocks: quadrants 1..3 of the schedule's first `heads` tiles
+    const int e = slot - split.n_slots;
+    slot = e / 3; part = 1 + (e - 3 * slot);
+  }
+  const int tile = tile_order ? tile_order[slot] : xcd_tile(slot, T_total);
   if (tile >= T_total) return;
+  if (split.factor > 0) {
+    const bool sp = slot < split.heads && tile_is_split(tile_start[tile + 1] - tile_start[tile], tile_start[T_total], split);
+    if (part >= 0 && !sp) return;
+    if (sp) {
+      raster_fwd_quadrant<WANT_IDX>(cam, T_total, splats, sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx,
+                                    stop_pos, tile, part < 0 ? 0 : part, recs);
+      return;
+    }
+  }
   const int lane = threadIdx.x;
   const int ty = tile / cam.TW, tx = tile - ty * cam.TW;
   // lane -> pixel: DPP row g = lane >> 4 owns block (g & 1, g >> 1) of the quadrant, lane & 15 = pixel in it
@@ -451,7 +553,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TGS_BLK_WAVE
   float D[4] = {0.f, 0.f, 0.f, 0.f};
   int last[4] = {-1, -1, -1, -1};
 
-  __shared__ float4 recs[65 * 3];                 // 64 staged Gaussians + the null record (alpha = 0)
   __shared__ unsigned int lists4[16 * 16];        // 16 lists of 64 one-byte indices, padded with 64 = null
   unsigned char* lists = reinterpret_cast<unsigned char*>(lists4);
   if (lane == 0) {
@@ -1376,7 +1477,7 @@ __global__ __launch_bounds__(256) void k_raster_bwd_quad(
 
 // Run-time switches, read from the environment ONCE (first use) and settable through the C ABI afterwards
 // (tgs_rasterize_fwd used to call getenv on every launch).
-static int g_k6_blocks = -1, g_k7_f2b = -1, g_k7_quad = -1, g_k7_quad_min = -1;
+static int g_k6_blocks = -1, g_k7_f2b = -1, g_k7_quad = -1, g_k7_quad_min = -1, g_k6_split = -1;
 static int env_flag(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
@@ -1390,6 +1491,13 @@ extern "C" int tgs_set_raster_variant(int k6_blocks_on, int k7_front_to_back) {
   if (k6_blocks_on >= 0) g_k6_blocks = k6_blocks_on != 0;
   if (k7_front_to_back >= 0) g_k7_f2b = k7_front_to_back != 0;
   return (k6_blocks() ? 1 : 0) | (k7_f2b() ? 2 : 0);
+}
+
+// TGS_K6_SPLIT: tile_is_split()'s factor (default 4: lists beyond 4x the balanced per-slot load, and 256); 0 = never
+static int k6_split() { if (g_k6_split < 0) g_k6_split = max(env_flag("TGS_K6_SPLIT", 4), 0); return g_k6_split; }
+extern "C" int tgs_set_k6_split(int factor) {
+  if (factor >= 0) g_k6_split = factor;
+  return k6_split();
 }
 
 extern "C" int tgs_set_k7_quad(int factor, int min_walk) {
@@ -1416,12 +1524,19 @@ extern "C" int tgs_rasterize_fwd(const TgsCamera* cam, const float* splats,
   // default: the 4x4-block form (-14.5 % at cfg3, bit-identical images); TGS_K6_BLOCKS=0 selects the quadrant
   // form, which also serves the slot_ok bitmaps.  tgs_set_k6_blocks() switches it at run time (tests, A/B).
   if (k6_blocks() && !slot_ok) {   // 4x4-block form (bit-identical images)
+    // tiles with long lists are split into quadrant blocks (raster_fwd_quadrant): three extra blocks for each of the
+    // schedule's first 512 entries (the longest lists of every XCD), which return at once unless their tile is split
+    SplitRule sr;
+    sr.factor = tile_order ? k6_split() : 0;
+    sr.n_slots = grid;
+    sr.heads = sr.factor > 0 ? min(grid, 512) : 0;
+    const int blocks = grid + 3 * sr.heads;
     if (final_idx)
-      hipLaunchKernelGGL(k_raster_fwd_blocks<true>, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T, splats,
-                         sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx, tile_order, stop_pos);
+      hipLaunchKernelGGL(k_raster_fwd_blocks<true>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, k, T, splats,
+                         sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx, tile_order, stop_pos, sr);
     else
-      hipLaunchKernelGGL(k_raster_fwd_blocks<false>, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T, splats,
-                         sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx, tile_order, stop_pos);
+      hipLaunchKernelGGL(k_raster_fwd_blocks<false>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, k, T, splats,
+                         sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx, tile_order, stop_pos, sr);
     TGS_CHECK_LAUNCH();
     return TGS_OK;
   }

@@ -368,6 +368,12 @@ def set_raster_variant(k6_blocks: Optional[bool] = None, k7_front_to_back: Optio
     return _lib.load().tgs_set_raster_variant(f(k6_blocks), f(k7_front_to_back))
 
 
+def set_k6_split(factor: Optional[int] = None) -> int:
+    """The forward splits tiles whose list exceeds max(256, factor x the balanced per-slot load) into four quadrant blocks
+    of the same launch (tgs_set_k6_split; default 4, 0 = never, None = query).  Bit-identical outputs."""
+    return _lib.load().tgs_set_k6_split(-1 if factor is None else int(factor))
+
+
 def set_k7_quad(factor: Optional[int] = None, min_walk: Optional[int] = None):
     """K7's four-waves-per-tile form for the tiles of chain-bound frames (deepest walk > factor / 2 x the balanced
     per-slot load; tgs_set_k7_quad; defaults factor 8, min_walk 48; factor 0 = one wave per tile always; None leaves
