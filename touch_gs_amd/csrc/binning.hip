@@ -409,7 +409,10 @@ __global__ __launch_bounds__(TGS_WAVE * 4) void k_sort_tiles_wg4(
     const int n = tile_start[tile + 1] - s;
     if (n <= 1024 || n > 4096) continue;
     __syncthreads();
-    sort_tile_regs<16, 4>(pairs, sorted_gid, s, n, threadIdx.x, wg_keys);
+    // (1024, 2048]: 8 keys per lane -- half the network per thread; in an object-centric frame this launch lasts as long
+    // as one tile's sort (a few hundred long lists, every workgroup resident at once)
+    if (n <= 2048) sort_tile_regs<8, 4>(pairs, sorted_gid, s, n, threadIdx.x, wg_keys);
+    else sort_tile_regs<16, 4>(pairs, sorted_gid, s, n, threadIdx.x, wg_keys);
   }
 }
 
