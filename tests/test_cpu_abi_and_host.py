@@ -467,3 +467,16 @@ def test_xcd_schedule_sizes_and_bands_host():
             nxt = t1.value if t1.value > t0.value else nxt
         assert nxt == T
         assert lib.tgs_band_tiles(W, H, nb, C.byref(t0), C.byref(t1)) != 0
+
+
+def test_tile_start_copies_are_refused():
+    """TGS_VERSION 201: the rasterizer owns 512 scratch ints behind the tile starts; the Python ops refuse a tensor that
+    has lost them (a clone of the T + 1 view) before any kernel could write out of bounds."""
+    from touch_gs_amd import ops
+    T = 40
+    buf = torch.zeros(T + 1 + 512, dtype=torch.int32)
+    ops._check_tile_start(buf[:T + 1], T)
+    with pytest.raises(ValueError):
+        ops._check_tile_start(buf[:T + 1].clone(), T)
+    with pytest.raises(ValueError):
+        ops._check_tile_start(buf[8:T + 9], T)

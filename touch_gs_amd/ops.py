@@ -306,11 +306,21 @@ def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_d
     return splats, radii, group_base, tile_start, sorted_gid, status
 
 
+def _check_tile_start(tile_start, T: int) -> None:
+    """The rasterizer keeps 512 scratch ints behind the T + 1 tile starts (tgs.h, TGS_VERSION 201): a tensor that was
+    copied out of the buffer ``bin_sort`` / ``FrontBuffers`` allocated (clone, contiguous, .to) has lost them."""
+    have = tile_start.untyped_storage().nbytes() // 4 - tile_start.storage_offset()
+    if have < T + 1 + 512:
+        raise ValueError(f"tile_start must be (a view of) a buffer of T + 513 = {T + 513} int32 (got room for {have}): "
+                         "pass the tensor ops.bin_sort / ops.project_bin_sort returned, not a copy")
+
+
 def rasterize_fwd(cam: Camera, splats, sorted_gid, tile_start, want_idx: bool = False):
     """K6 -> (rgb [H,W,3], depth_acc [H,W], final_T [H,W], final_idx [H,W] or None).  (tgs_rasterize_fwd)"""
     lib = _lib.load()
     dev = splats.device
     H, W = cam.H, cam.W
+    _check_tile_start(tile_start, cam.num_tiles)
     rgb = torch.empty(H, W, 3, dtype=torch.float32, device=dev)
     depth = torch.empty(H, W, dtype=torch.float32, device=dev)
     fT = torch.empty(H, W, dtype=torch.float32, device=dev)
@@ -342,6 +352,7 @@ def rasterize_bwd(cam: Camera, splats, group_base, sorted_gid, tile_start, rgb, 
     """
     lib = _lib.load()
     dev = splats.device
+    _check_tile_start(tile_start, cam.num_tiles)
     if partials is None:     # (a caller may hand in the buffer, e.g. pre-filled to detect reads of unwritten records)
         partials = torch.empty(sorted_gid.shape[0], PARTIAL_FLOATS, dtype=torch.float32, device=dev)
     tile_loss = torch.empty(cam.num_tiles, 2, dtype=torch.float32, device=dev) if want_tile_loss else None
