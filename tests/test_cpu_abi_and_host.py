@@ -328,8 +328,25 @@ def test_densify_screen_size_rules_cpu():
     # (c) past stop_screen_size_at: the screen radius no longer matters
     gp, opt = population()
     dc = DensityController(cfg, N, "cpu"); stats(dc)
-    _, _, info = dc.refine(gp, opt, 150)
+    _, _, info = dc.refine(gp, opt, 140)
     assert info["culled"] == 2 and info["cloned"] == 3 and info["split"] == 0      # culled: 7, 6; clones: 0, 1, 2
+    # (d) Splatfacto's pause after an opacity reset: at step % reset_interval == refine_every the opacities are reset and
+    # nothing is split or culled until num_train_data + refine_every steps have passed (every image seen again)
+    gp, opt = population()
+    dc = DensityController(cfg, N, "cpu"); stats(dc)
+    new, _, info = dc.refine(gp, opt, 130)          # 130 % 30 == 10
+    assert info["opacity_reset"] and info["culled"] == info["cloned"] == info["split"] == 0 and info["after"] == N
+    assert float(torch.sigmoid(new.opac_logit).max()) <= 2 * cfg.cull_alpha_thresh + 1e-6
+    import dataclasses as _dc
+    dc = DensityController(_dc.replace(cfg, num_train_data=15), N, "cpu"); stats(dc)
+    gp, opt = population()
+    _, _, info = dc.refine(gp, opt, 140)            # 140 % 30 = 20 <= 15 + 10: still paused
+    assert not info["opacity_reset"] and info["culled"] == info["cloned"] == info["split"] == 0
+    # (e) after stop_split_at: culls only (continue_cull_post_densification), and no more opacity resets
+    dc = DensityController(_dc.replace(cfg, stop_split_at=100), N, "cpu"); stats(dc)
+    gp, opt = population()
+    _, _, info = dc.refine(gp, opt, 130)
+    assert not info["opacity_reset"] and info["culled"] == 2 and info["cloned"] == info["split"] == 0
 
 
 def test_refine_places_children_behind_their_parents_cpu():

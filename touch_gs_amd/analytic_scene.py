@@ -1,0 +1,427 @@
+"""A known-geometry, object-centric capture in the reference's RAW on-disk layout -- the input of the whole
+``scripts/train_bunny_real.sh`` sequence -- so that the pipeline can be run end to end without the (absent)
+``touch-gs-data`` submodule (reference .gitmodules:1-3) and its results compared with ground truth.
+
+The scene is analytic (ray-cast, nothing here is a Gaussian): a "bunny" made of a union of ellipsoids standing on
+a textured table plane, lit by one directional light (view-independent shading), photographed from orbit views
+with the reference's training-camera intrinsics (utils/read_realsense_depth.py:13: 1297, 1304, 620.91, 238.28 at
+1280 x 720).  ``write_raw_capture`` leaves behind exactly what the reference's steps read:
+
+  imgs/<n>.png                       colour images                        (utils/read_touch_depths.py:24)
+  transforms.json                    fl_x .. h + per-frame OpenGL camera->world  (utils/transforms_utils.py:40-49)
+  realsense_depth/<n>.npy            the depth sensor's image in millimetres at the sensor's own intrinsics
+                                     (360, 360, 243, 137.8; utils/read_realsense_depth.py:13,113-139) + sensor noise
+  gpis_depth/Image<n>.npy, gpis_var/Image<n>.npy    GPIS of the touch readings rendered into every view, NaN where the
+                                     rays meet no touched surface (utils/read_touch_depths.py:41-49) -- touch_gs_amd.gpis
+  zoe_depth/<n>.png                  a stand-in for the monocular network (ZoeDepth needs pretrained weights):
+                                     ground truth x unknown per-image scale + shift, a smooth multiplicative
+                                     distortion and pixel noise -- the error model affine alignment is meant for
+  gt_depth/<n>.npy, gt_object_mask/<n>.npy     exact depth / object mask (evaluation only; not read by the pipeline)
+
+``touch_gs_amd.prepare`` then runs the reference's steps on that directory and ``touch_gs_amd.train`` trains on it.
+Test / measurement infrastructure for SURVEY section 8 rows a10-a14, f3, f4: no kernel of the hot path is involved.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+TRAIN_INTRINSICS = (1297.0, 1304.0, 620.91, 238.28)   # reference utils/read_realsense_depth.py:13 (new_intrinsics)
+SENSOR_INTRINSICS = (360.0, 360.0, 243.0, 137.8)      # same line (old_intrinsics)
+SENSOR_SIZE = (480, 270)
+
+
+def _rot(axis: str, deg: float) -> np.ndarray:
+    a = math.radians(deg)
+    c, s = math.cos(a), math.sin(a)
+    return {"x": np.array([[1, 0, 0], [0, c, -s], [0, s, c]]), "y": np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]]),
+            "z": np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])}[axis].astype(np.float64)
+
+
+# (centre, radii, rotation world<-local, base albedo): world z is up, metres; the table is the plane z = 0
+BUNNY = [
+    ((0.000, 0.000, 0.050), (0.062, 0.045, 0.050), _rot("z", 0), (0.82, 0.74, 0.62)),          # body
+    ((0.055, 0.000, 0.105), (0.034, 0.030, 0.032), _rot("y", -15), (0.85, 0.78, 0.66)),        # head
+    ((0.050, 0.016, 0.160), (0.010, 0.007, 0.038), _rot("x", -12) @ _rot("y", 14), (0.88, 0.62, 0.60)),   # ear
+    ((0.050, -0.016, 0.160), (0.010, 0.007, 0.038), _rot("x", 12) @ _rot("y", 14), (0.88, 0.62, 0.60)),   # ear
+    ((-0.064, 0.000, 0.045), (0.016, 0.016, 0.016), _rot("z", 0), (0.95, 0.95, 0.92)),         # tail
+    ((0.040, 0.030, 0.014), (0.024, 0.012, 0.014), _rot("z", 20), (0.78, 0.70, 0.58)),         # paw
+    ((0.040, -0.030, 0.014), (0.024, 0.012, 0.014), _rot("z", -20), (0.78, 0.70, 0.58)),       # paw
+]
+LIGHT = np.array([0.35, 0.25, 0.90]) / np.linalg.norm([0.35, 0.25, 0.90])
+OBJECT_CENTRE = np.array([0.0, 0.0, 0.075])
+
+
+class AnalyticScene:
+    """Ray caster for the ellipsoid union + table plane (torch; any device)."""
+
+    def __init__(self, device="cpu", dtype=torch.float64):
+        self.device, self.dtype = torch.device(device), dtype
+        t = lambda a: torch.as_tensor(np.asarray(a), dtype=dtype, device=self.device)
+        self.c = t([e[0] for e in BUNNY])            # [E,3]
+        self.r = t([e[1] for e in BUNNY])            # [E,3]
+        self.R = t(np.stack([e[2] for e in BUNNY]))  # [E,3,3]
+        self.albedo = t([e[3] for e in BUNNY])       # [E,3]
+        self.light = t(LIGHT)
+
+    # ---- geometry -------------------------------------------------------------------------------------------
+    def intersect(self, o: torch.Tensor, d: torch.Tensor, table: bool = True):
+        """Nearest hit of rays o + t d (d need not be unit).  -> (t [M] (inf = miss), prim [M] (-1 miss, E = table),
+        normal [M,3])."""
+        E = self.c.shape[0]
+        ol = torch.einsum("eji,mej->mei", self.R, o[:, None, :] - self.c[None]) / self.r[None]   # R^T (o - c) / r
+        dl = torch.einsum("eji,mj->mei", self.R, d) / self.r[None]
+        A = (dl * dl).sum(-1)
+        B = (ol * dl).sum(-1)
+        C = (ol * ol).sum(-1) - 1.0
+        disc = B * B - A * C
+        sq = torch.sqrt(disc.clamp_min(0))
+        t0 = (-B - sq) / A
+        inf = torch.full_like(t0, float("inf"))
+        t0 = torch.where((disc > 0) & (t0 > 1e-9), t0, inf)
+        t_obj, prim = t0.min(dim=1)
+        hit_obj = torch.isfinite(t_obj)
+        pl = torch.gather(ol + t_obj.nan_to_num(posinf=0.0)[:, None, None] * dl, 1,
+                          prim[:, None, None].expand(-1, 1, 3))[:, 0]               # local unit-sphere point
+        n_l = pl / self.r[prim]                                                      # gradient of the quadric
+        n = torch.einsum("mij,mj->mi", self.R[prim], n_l)
+        n = n / n.norm(dim=-1, keepdim=True).clamp_min(1e-30)
+        t_hit, prim = t_obj, torch.where(hit_obj, prim, torch.full_like(prim, -1))
+        if table:
+            tz = -o[:, 2] / torch.where(d[:, 2].abs() > 1e-30, d[:, 2], torch.full_like(d[:, 2], 1e-30))
+            on_table = (tz > 1e-9) & (tz < t_hit)
+            t_hit = torch.where(on_table, tz, t_hit)
+            prim = torch.where(on_table, torch.full_like(prim, E), prim)
+            up = torch.zeros_like(n)
+            up[:, 2] = 1.0
+            n = torch.where(on_table[:, None], up, n)
+        return t_hit, prim, n
+
+    def shade(self, p: torch.Tensor, prim: torch.Tensor, n: torch.Tensor) -> torch.Tensor:
+        """View-independent colour of surface points: procedural albedo x (ambient + Lambert)."""
+        E = self.c.shape[0]
+        two_pi = 2 * math.pi
+        # object: base albedo modulated by a smooth 3-D pattern (period ~3 cm)
+        w = 0.5 + 0.5 * torch.sin(two_pi * p[:, 0] / 0.031) * torch.sin(two_pi * p[:, 1] / 0.027 + 1.0) \
+            * torch.sin(two_pi * p[:, 2] / 0.035 + 2.0)
+        obj = self.albedo[prim.clamp(0, E - 1)] * (0.72 + 0.28 * w[:, None])
+        # table: soft two-tone checker (period 8 cm) over a slow colour gradient
+        s = torch.sin(two_pi * p[:, 0] / 0.16) * torch.sin(two_pi * p[:, 1] / 0.16)
+        k = torch.sigmoid(s * 12.0)[:, None]
+        ca = torch.stack([0.36 + 0.10 * torch.sin(p[:, 0] * 2.1), 0.42 + 0.08 * torch.cos(p[:, 1] * 1.7),
+                          0.50 + 0.0 * p[:, 0]], -1)
+        cb = torch.stack([0.70 + 0.0 * p[:, 0], 0.64 + 0.08 * torch.sin(p[:, 1] * 2.3), 0.52 + 0.10 * torch.cos(p[:, 0] * 1.9)], -1)
+        tab = ca * (1 - k) + cb * k
+        alb = torch.where((prim == E)[:, None], tab, obj)
+        lam = (n * self.light).sum(-1).clamp_min(0)
+        # a cheap contact shadow: the table darkens under the object's footprint
+        r2 = (p[:, 0] / 0.085) ** 2 + (p[:, 1] / 0.065) ** 2
+        shadow = torch.where(prim == E, 1.0 - 0.35 * torch.exp(-r2 * 1.5), torch.ones_like(r2))
+        col = alb * (0.42 + 0.58 * lam)[:, None] * shadow[:, None]
+        return torch.where((prim >= 0)[:, None], col, torch.zeros_like(col)).clamp(0, 1)
+
+    # ---- cameras ---------------------------------------------------------------------------------------------
+    def render(self, c2w_opengl: np.ndarray, intr: Sequence[float], W: int, H: int, ssaa: int = 2,
+               want_rgb: bool = True) -> Dict[str, np.ndarray]:
+        """-> rgb [H,W,3] float32 (box-filtered ssaa x ssaa samples), depth [H,W] float64 (camera z of the ray
+        through the pixel centre x + 0.5, y + 0.5 -- the convention of plumbing.get_point_cloud_from_depth_and_color
+        up to its half-pixel), object [H,W] bool."""
+        fx, fy, cx, cy = intr
+        c2w = torch.as_tensor(np.asarray(c2w_opengl, dtype=np.float64), dtype=self.dtype, device=self.device)
+        Rcv = c2w[:3, :3] @ torch.diag(torch.tensor([1.0, -1.0, -1.0], dtype=self.dtype, device=self.device))
+        o = c2w[:3, 3]
+        ar = lambda n: torch.arange(n, dtype=self.dtype, device=self.device)
+
+        def cast(us, vs):
+            dc = torch.stack([(us - cx) / fx, (vs - cy) / fy, torch.ones_like(us)], -1).reshape(-1, 3)
+            dw = dc @ Rcv.T
+            t, prim, n = self.intersect(o[None].expand(dw.shape[0], 3), dw)
+            return t, prim, n, dw
+
+        vs, us = torch.meshgrid(ar(H) + 0.5, ar(W) + 0.5, indexing="ij")
+        t, prim, n, dw = cast(us, vs)
+        depth = torch.where(torch.isfinite(t), t, torch.zeros_like(t)).reshape(H, W)      # d_cam z = 1 => z = t
+        E = self.c.shape[0]
+        out = {"depth": depth.cpu().numpy(), "object": ((prim >= 0) & (prim < E)).reshape(H, W).cpu().numpy()}
+        if want_rgb:
+            acc = torch.zeros(H * W, 3, dtype=self.dtype, device=self.device)
+            for j in range(ssaa):
+                for i in range(ssaa):
+                    du, dv = (i + 0.5) / ssaa - 0.5, (j + 0.5) / ssaa - 0.5
+                    t, prim, n, dw = cast(us + du, vs + dv)
+                    p = o[None] + t.nan_to_num(posinf=0.0)[:, None] * dw
+                    acc += self.shade(p, prim, n)
+            out["rgb"] = (acc / (ssaa * ssaa)).reshape(H, W, 3).float().cpu().numpy()
+        return out
+
+
+def orbit_cameras(n_views: int, radius: float = 0.46, seed: int = 0) -> List[np.ndarray]:
+    """OpenGL camera->world matrices on an orbit around the object: azimuth 2 pi k / n, elevation swinging between
+    ~22 and ~52 degrees, radius +-8 %; the optical axis is aimed so that the OBJECT lands in the middle of the
+    image although the principal point of the reference's calibration sits at y = 238 of 720."""
+    rng = np.random.default_rng(seed)
+    tilt = math.atan((360.0 - TRAIN_INTRINSICS[3]) / TRAIN_INTRINSICS[1])   # image centre below the optical axis
+    cams = []
+    for k in range(n_views):
+        az = 2 * math.pi * k / n_views
+        el = math.radians(37.0 + 15.0 * math.sin(2 * math.pi * (k * 7 % n_views) / n_views))
+        r = radius * (1.0 + 0.08 * (2 * rng.random() - 1))
+        eye = OBJECT_CENTRE + r * np.array([math.cos(el) * math.cos(az), math.cos(el) * math.sin(az), math.sin(el)])
+        fwd = OBJECT_CENTRE - eye
+        fwd /= np.linalg.norm(fwd)
+        right = np.cross(fwd, [0.0, 0.0, 1.0])
+        right /= np.linalg.norm(right)
+        up = np.cross(right, fwd)
+        # tilt the optical axis UP by `tilt` so that the object appears `tilt` below it = at the image centre
+        fwd_t = math.cos(tilt) * fwd + math.sin(tilt) * up
+        up_t = np.cross(right, fwd_t)
+        M = np.eye(4)
+        M[:3, 0], M[:3, 1], M[:3, 2], M[:3, 3] = right, up_t, -fwd_t, eye
+        cams.append(M)
+    return cams
+
+
+def touch_readings(scene: AnalyticScene, n_touches: int = 50, grid: int = 6, half: float = 0.008,
+                   noise: float = 2e-4, seed: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+    """``n_touches`` readings of a finger-tip sensor pressed against the object: every reading is a grid x grid patch
+    of surface points (~16 mm square, the footprint of a DenseTact-class sensor) measured along the sensor's axis,
+    with Gaussian noise.  -> (points [M,3], sensor positions [M,3] -- each point's sensor, 3 cm off the surface)."""
+    rng = np.random.default_rng(seed)
+    T = lambda a: torch.as_tensor(a, dtype=scene.dtype, device=scene.device)
+    pts, sens = [], []
+    tries = 0
+    while len(pts) < n_touches and tries < 50 * n_touches:
+        tries += 1
+        d = rng.normal(size=3)
+        d[2] = abs(d[2]) * 0.8 + 0.05
+        d /= np.linalg.norm(d)
+        target = OBJECT_CENTRE + rng.normal(size=3) * np.array([0.03, 0.02, 0.035])
+        o = target + 0.4 * d
+        t, prim, n = scene.intersect(T(o[None]), T(-d[None]), table=False)
+        if not bool(torch.isfinite(t[0])):
+            continue
+        p = o - float(t[0]) * d
+        nrm = n[0].cpu().numpy()
+        s = p + 0.03 * nrm
+        a = np.cross(nrm, [0.0, 0.0, 1.0] if abs(nrm[2]) < 0.9 else [1.0, 0.0, 0.0])
+        a /= np.linalg.norm(a)
+        b = np.cross(nrm, a)
+        g = (np.arange(grid) + 0.5) / grid * 2 * half - half
+        gu, gv = np.meshgrid(g, g)
+        oo = s[None] + gu.reshape(-1, 1) * a[None] + gv.reshape(-1, 1) * b[None]
+        dd = np.repeat(-nrm[None], len(oo), 0)
+        t2, prim2, _ = scene.intersect(T(oo), T(dd), table=False)
+        ok = (torch.isfinite(t2) & (t2 < 0.06)).cpu().numpy()
+        if ok.sum() < grid * grid // 2:
+            continue
+        hit = oo[ok] + t2.cpu().numpy()[ok, None] * dd[ok] + rng.normal(size=(int(ok.sum()), 3)) * noise
+        pts.append(hit)
+        sens.append(np.repeat(s[None], len(hit), 0))
+    return np.concatenate(pts), np.concatenate(sens)
+
+
+def fake_monocular_depth(gt: np.ndarray, rng: np.random.Generator) -> np.ndarray:
+    """What a monocular depth network gives for a frame whose true depth is ``gt``: right up to an unknown affine map
+    (scale 0.55 .. 0.9, shift 0.05 .. 0.25 m -- inside the bounds the reference's alignment searches,
+    utils/fuse_touch_vision.py:283-315), a smooth +-4 % distortion across the image and 1.5 mm pixel noise."""
+    H, W = gt.shape
+    s, o = rng.uniform(0.55, 0.9), rng.uniform(0.05, 0.25)
+    yy, xx = np.mgrid[0:H, 0:W]
+    ph = rng.uniform(0, 2 * math.pi, 4)
+    field = 0.5 * np.sin(2 * math.pi * xx / W * 1.3 + ph[0]) * np.cos(2 * math.pi * yy / H * 0.9 + ph[1]) \
+        + 0.5 * np.sin(2 * math.pi * (xx / W * 0.7 + yy / H * 1.1) + ph[2])
+    v = (gt * s + o) * (1.0 + 0.04 * field) + rng.normal(size=gt.shape) * 0.0015
+    return np.where(gt > 0, np.clip(v, 0.0, None), 0.0)
+
+
+def write_raw_capture(root: str, n_views: int = 100, n_touches: int = 50, W: int = 1280, H: int = 720,
+                      device="cpu", seed: int = 0, gpis_stride: int = 2, gpis_length_scale: float = 0.02, gpis_max_var: float = 0.1,
+                      sensor_noise_mm: float = 1.0, verbose: bool = False) -> dict:
+    """Writes the raw capture described in the module docstring.  ``W, H`` scale the reference's 1280 x 720 camera
+    (intrinsics scale along).  Returns a summary (touch point count, GPIS error against the analytic surface)."""
+    from PIL import Image
+    from .gpis import GPIS, estimate_outward_normals
+    from .plumbing import write_png16, to_uint16_mm
+    rng = np.random.default_rng(seed)
+    sc = AnalyticScene(device)
+    k = W / 1280.0
+    intr = tuple(v * k for v in TRAIN_INTRINSICS)
+    s_intr = tuple(v * k for v in SENSOR_INTRINSICS)
+    sW, sH = int(round(SENSOR_SIZE[0] * k)), int(round(SENSOR_SIZE[1] * k))
+    for d in ("imgs", "realsense_depth", "gpis_depth", "gpis_var", "zoe_depth", "gt_depth", "gt_object_mask"):
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+    cams = orbit_cameras(n_views, seed=seed)
+    pts, sens = touch_readings(sc, n_touches, seed=seed)
+    normals = estimate_outward_normals(pts, sens)
+    gp = GPIS(length_scale=gpis_length_scale, offset=0.005, noise_var=1e-5).fit(pts, normals, max_points=1800, rng=rng)
+    gp.device = device
+    frames, err, cover = [], [], []
+    import time
+    tm = {"render": 0.0, "sensor": 0.0, "gpis": 0.0, "io": 0.0}
+    clock = time.perf_counter
+    for i, c2w in enumerate(cams):
+        t0 = clock()
+        r = sc.render(c2w, intr, W, H)
+        tm["render"] += clock() - t0
+        t0 = clock()
+        Image.fromarray((np.clip(r["rgb"], 0, 1) * 255 + 0.5).astype(np.uint8)).save(os.path.join(root, "imgs", f"{i}.png"))
+        np.save(os.path.join(root, "gt_depth", f"{i}.npy"), r["depth"].astype(np.float32))
+        np.save(os.path.join(root, "gt_object_mask", f"{i}.npy"), r["object"])
+        # the depth sensor: its own intrinsics and resolution, millimetres, noise growing with range
+        rs = sc.render(c2w, s_intr, sW, sH, want_rgb=False)["depth"]
+        rs_mm = rs * 1000.0 + rng.normal(size=rs.shape) * sensor_noise_mm * (rs / 0.5) ** 2
+        np.save(os.path.join(root, "realsense_depth", f"{i}.npy"), np.where(rs > 0, rs_mm, 0.0))
+        tm["io"] += clock() - t0
+        t0 = clock()
+        gd, gv = gp.render_depth(c2w, *intr, W, H, near=0.05, far=1.5, stride=gpis_stride, n_steps=48, max_var=gpis_max_var,
+                                  var_floor=1e-3, roi_margin_px=max(int(24 * k), 4))
+        if gpis_stride > 1:   # rendered on a coarser grid: fill the skipped pixels from the nearest rendered one
+            gd, gv = _fill_stride(gd, gpis_stride), _fill_stride(gv, gpis_stride)
+        tm["gpis"] += clock() - t0
+        t0 = clock()
+        np.save(os.path.join(root, "gpis_depth", f"Image{i}.npy"), gd)
+        np.save(os.path.join(root, "gpis_var", f"Image{i}.npy"), gv)
+        write_png16(os.path.join(root, "zoe_depth", f"{i}.png"), to_uint16_mm(fake_monocular_depth(r["depth"], rng)))
+        m = np.isfinite(gd) & r["object"]
+        if m.any():
+            err.append(float(np.sqrt(np.mean((gd[m] - r["depth"][m]) ** 2))))
+            cover.append(float(m.sum() / max(r["object"].sum(), 1)))
+        frames.append({"file_path": f"imgs/{i}.png", "transform_matrix": c2w.tolist()})
+        tm["io"] += clock() - t0
+        if verbose:
+            print(f"view {i}: seconds so far {({k: round(v, 2) for k, v in tm.items()})} gpis rmse {err[-1] if err else float('nan'):.4f} m, cover {cover[-1] if cover else 0:.2f}", flush=True)
+    meta = {"fl_x": intr[0], "fl_y": intr[1], "cx": intr[2], "cy": intr[3], "w": W, "h": H, "frames": frames}
+    with open(os.path.join(root, "transforms.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    np.save(os.path.join(root, "touch_points_raw.npy"), pts)
+    return dict(n_views=n_views, n_touch_points=int(len(pts)), n_touches=n_touches,
+                gpis_rmse_m=float(np.mean(err)) if err else None, gpis_object_cover=float(np.mean(cover)) if cover else 0.0,
+                intrinsics=intr, sensor_intrinsics=s_intr, sensor_size=(sW, sH),
+                seconds={k: round(v, 1) for k, v in tm.items()})
+
+
+def _fill_stride(a: np.ndarray, stride: int) -> np.ndarray:
+    """Values rendered at pixels (stride * j, stride * i) of a region -> every pixel of the block takes its block's
+    rendered value (NaN stays NaN)."""
+    H, W = a.shape
+    out = a.copy()
+    ys, xs = np.nonzero(np.isfinite(a))
+    for dy in range(stride):
+        for dx in range(stride):
+            if dy == 0 and dx == 0:
+                continue
+            y, x = np.minimum(ys + dy, H - 1), np.minimum(xs + dx, W - 1)
+            free = ~np.isfinite(out[y, x])
+            out[y[free], x[free]] = a[ys[free], xs[free]]
+    return out
+
+
+def prepare_capture(root: str, train_split: float, seed: int = 0, is_sim: bool = False) -> dict:
+    """The reference's preparation sequence (scripts/train_bunny_real.sh:10-48) on a raw capture, step for step
+    through ``touch_gs_amd.prepare``.  -> counts per step."""
+    from . import prepare as PR
+    out = {}
+    if not is_sim:
+        out["realsense"] = PR.read_realsense_depth(root, *_scaled_intrinsics(root))
+    out["touch"] = PR.read_touch_depths(root)
+    out["fused"] = PR.fuse_touch_vision(root, "realsense_depths", "touch_depth", "zoe_depth", "vision", "fused_output_dir",
+                                        "touch_var", use_uncertainty=True, is_sim=is_sim, seed=seed)
+    PR.add_depth_file_path_to_transforms(root, "transforms.json", "fused_output_dir", "fused_output_dir_uncertainty")
+    pts, _ = PR.create_point_cloud_from_touches(root, "imgs", "touch_depth", "touch_var", "transforms.json", train_split,
+                                                seed=seed)
+    out["seed_points"] = int(len(pts))
+    return out
+
+
+def _scaled_intrinsics(root: str):
+    with open(os.path.join(root, "transforms.json")) as f:
+        m = json.load(f)
+    k = m["w"] / 1280.0
+    return tuple(v * k for v in SENSOR_INTRINSICS), tuple(v * k for v in TRAIN_INTRINSICS), (m["w"], m["h"])
+
+
+# reference flag sets: scripts/train_bunny_real.sh:48,52 and scripts/train_block_data.sh:46,50
+FLAG_SETS = {
+    "bunny_real": dict(split=0.08, percent_take=100.0, depth_loss_mult=0.005, depth_loss_type="DEPTH_UNCERTAINTY_WEIGHTED_LOSS",
+                       uncertainty_weight=0.01),
+    "block": dict(split=0.8, percent_take=10.0, depth_loss_mult=0.2, depth_loss_type="DEPTH_UNCERTAINTY_WEIGHTED_LOSS",
+                  uncertainty_weight=1.0),
+}
+
+
+def train_and_eval(root: str, flags: str, with_depth: bool, iters: int = 30000, out_dir: Optional[str] = None,
+                   num_gaussians: int = 100000, extra_args: Sequence[str] = (), seed: int = 0, device="cuda") -> dict:
+    """``ns-train depth-gaussian-splatting`` + ``run_eval`` of one reference flag set on a prepared capture:
+    seeds for the flag set's split (create_point_cloud_from_touches), ``touch_gs_amd.train`` for ``iters`` iterations
+    with or without the depth term, ``touch_gs_amd.run_eval`` under IS_REAL_WORLD (scripts/train_bunny_real.sh:54), and
+    -- because this scene's geometry is known exactly -- the same two depth errors against the analytic depth.
+    -> the eval.json ``results`` + wall seconds; depths in metres (the trainer works in the dataparser's scaled frame)."""
+    import time
+    from . import prepare as PR, train
+    from .run_eval import eval_run
+    from .dataset import Scene
+    fs = FLAG_SETS[flags]
+    PR.create_point_cloud_from_touches(root, "imgs", "touch_depth", "touch_var", "transforms.json", fs["split"],
+                                       percent_take=fs["percent_take"], seed=seed)
+    out_dir = out_dir or os.path.join(root, "outputs")
+    argv = ["--data", root, "--train-split-fraction", str(fs["split"]), "--max-num-iterations", str(iters),
+            "--depth-loss-mult", str(fs["depth_loss_mult"] if with_depth else 0.0), "--depth-loss-type", fs["depth_loss_type"],
+            "--uncertainty-weight", str(fs["uncertainty_weight"]), "--num-gaussians", str(num_gaussians),
+            "--steps-per-save", str(iters), "--steps-per-eval", str(max(iters // 10, 1)), "--output-dir", out_dir,
+            "--seed", str(seed), *extra_args]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_dir = train.main(argv)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    was = os.environ.get("IS_REAL_WORLD")
+    os.environ["IS_REAL_WORLD"] = "True"
+    try:
+        res = eval_run(run_dir, os.path.join(run_dir, "run_eval.json"), device=device)
+    finally:
+        if was is None:
+            del os.environ["IS_REAL_WORLD"]
+        else:
+            os.environ["IS_REAL_WORLD"] = was
+    # exact geometry: render the held-out views again and compare with the analytic depth
+    res.update(exact_depth_errors(run_dir, root, fs["split"], device))
+    with open(os.path.join(run_dir, "config.json")) as f:
+        scale = json.load(f)["scene"]["dataparser_scale"]
+    for k in list(res):
+        if k.endswith("depth_mse"):           # scaled-frame units^2 -> metres^2
+            res[k + "_m2"] = res[k] / (scale * scale)
+    res.update(train_wall_s=round(wall, 2), iters=iters, iters_per_s_wall=round(iters / wall, 1), flags=flags,
+               with_depth=bool(with_depth), run_dir=run_dir)
+    return res
+
+
+@torch.no_grad()
+def exact_depth_errors(run_dir: str, root: str, split: float, device="cuda") -> dict:
+    """MSE (scaled-frame units, like the other depth metrics) of the rendered depth of the held-out views against the
+    ANALYTIC depth, over the whole image and over the object's true silhouette."""
+    import glob
+    from .dataset import Scene
+    from .model import DepthGaussianSplattingModel, ModelConfig
+    from .optim import GaussianParams
+    with open(os.path.join(run_dir, "config.json")) as f:
+        cfg = json.load(f)
+    sd = torch.load(sorted(glob.glob(os.path.join(run_dir, "step-*.ckpt")))[-1], map_location=device)
+    mc = {k: v for k, v in cfg["model"].items() if k in ModelConfig.__dataclass_fields__}
+    mc["background_color"] = tuple(mc.get("background_color", (0.0, 0.0, 0.0)))
+    model = DepthGaussianSplattingModel(ModelConfig(**mc), GaussianParams.allocate(sd["N"], sd["K"], device))
+    model.load_state_dict(sd)
+    scene = Scene(root, split, device)
+    e_all, e_obj = [], []
+    for i in scene.i_eval:
+        stem = os.path.splitext(os.path.basename(scene.names[i]))[0]
+        gt = torch.from_numpy(np.load(os.path.join(root, "gt_depth", stem + ".npy"))).to(device).float() * scene.scale
+        ob = torch.from_numpy(np.load(os.path.join(root, "gt_object_mask", stem + ".npy"))).to(device)
+        d = model.get_outputs(scene.views[i].cam, sh_degree=model.active_sh_degree())["depth"][..., 0]
+        e_all.append(float(((d - gt) ** 2).mean()))
+        e_obj.append(float(((d - gt)[ob] ** 2).mean()))
+    return dict(exact_depth_mse=float(np.mean(e_all)), exact_object_depth_mse=float(np.mean(e_obj)))

@@ -68,7 +68,30 @@ class GPIS:
         self.prior = d
         return self
 
+    def _predict_torch(self, Q: np.ndarray, want_var: bool):
+        """Same arithmetic as the NumPy form, in fp64 torch on ``self.device`` (the kernel matrix of a ray-marching
+        step is ~1e8 exponentials: minutes per view in single-threaded NumPy, a fraction of a second threaded / on a GPU)."""
+        import torch
+        dev = torch.device(self.device)
+        if getattr(self, "_t", None) is None or self._t_key != str(self.device):
+            self._t_key = str(self.device)   # (not tensor.device == dev: "cuda" and "cuda:0" compare unequal)
+            T = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+            # K^-1 once on the host (the device BLAS's triangular solve wants a workspace per right-hand side block)
+            self._t = (T(self.X), T(self.alpha), T(cho_solve(self.chol, np.eye(len(self.X)))))
+        X, alpha, Kinv = self._t
+        q = torch.as_tensor(np.ascontiguousarray(Q), dtype=torch.float64, device=dev)
+        d2 = (q * q).sum(1)[:, None] + (X * X).sum(1)[None, :] - 2.0 * q @ X.T
+        Kq = self.sf2 * torch.exp(-0.5 * d2.clamp_min(0.0) / (self.l * self.l))
+        support = (Kq.max(dim=1).values / self.sf2).clamp(0.0, 1.0)
+        mean = Kq @ alpha + self.prior * (1.0 - support)
+        if not want_var:
+            return mean.cpu().numpy(), None
+        var = self.sf2 - ((Kq @ Kinv) * Kq).sum(1)
+        return mean.cpu().numpy(), var.clamp_min(0.0).cpu().numpy()
+
     def predict(self, Q: np.ndarray, want_var: bool = True) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+        if getattr(self, "device", None) is not None:
+            return self._predict_torch(Q, want_var)
         Kq = self._k(np.asarray(Q, dtype=np.float64), self.X)
         # blend towards the positive ("outside") prior where the GP has no support -- a zero-mean GP
         # would otherwise report f = 0 (a surface) everywhere far from the touches
@@ -82,9 +105,17 @@ class GPIS:
 
     def render_depth(self, c2w_opengl: np.ndarray, fx: float, fy: float, cx: float, cy: float, W: int, H: int,
                      near: float = 0.02, far: float = 2.0, n_steps: int = 96, stride: int = 1,
-                     roi_margin_px: int = 24, chunk: int = 20000):
+                     roi_margin_px: int = 24, chunk: int = 20000, max_var: Optional[float] = None,
+                     var_floor: float = 0.0):
         """-> (depth [H,W] metres, var [H,W]); NaN where the ray meets no surface.  ``c2w_opengl`` is
-        the transforms.json camera (x right, y up, -z forward)."""
+        the transforms.json camera (x right, y up, -z forward).
+
+        ``max_var``: crossings whose posterior variance exceeds it are reported as "no surface seen" (NaN): far from
+        every touch the posterior mean is the prior and a zero crossing there carries no information -- without the
+        cut, the inverse-variance fusion downstream (variance ~ signal_var = 1 against the vision prior's >= 5,
+        utils/fuse_touch_vision.py:76-202, :310) would let such a crossing outvote the monocular depth.
+        ``var_floor``: lower bound of the reported variance; the pipeline stores the map as uint16 x 1000
+        (utils/read_touch_depths.py:52-53), so a variance below 1e-3 would be truncated to 0 = "no touch here"."""
         c2w = np.asarray(c2w_opengl, dtype=np.float64)
         R = c2w[:3, :3] @ np.diag([1.0, -1.0, -1.0])  # OpenCV camera axes in the world
         t = c2w[:3, 3]
@@ -134,6 +165,9 @@ class GPIS:
                 lo = np.where(inside, lo, mid)
             zhit = 0.5 * (lo + hi)
             _, vv = self.predict(t + zhit[:, None] * dw[idx], want_var=True)
+            if max_var is not None:
+                sure = vv <= max_var
+                idx, zhit, vv = idx[sure], zhit[sure], vv[sure]
             depth[vs[s:s + chunk][idx], us[s:s + chunk][idx]] = zhit
-            var[vs[s:s + chunk][idx], us[s:s + chunk][idx]] = vv
+            var[vs[s:s + chunk][idx], us[s:s + chunk][idx]] = np.maximum(vv, var_floor)
         return depth, var

@@ -31,14 +31,27 @@ from .optim import GaussianParams
 SH_C0 = 0.28209479177387814
 
 
-def init_params(n: int, K: int, device, seed_points=None, extent: float = 1.0, seed: int = 0) -> GaussianParams:
-    """Seed Gaussians from the touch point cloud (+ random fill), Splatfacto-style: scales from the
-    mean distance to the 3 nearest neighbours, identity-ish rotations, opacity 0.1."""
+def init_params(n: int, K: int, device, seed_points=None, extent: float = 1.0, seed: int = 0,
+                seed_fraction: float = 0.5) -> GaussianParams:
+    """``n`` initial Gaussians: the touch point cloud (points_touch.npy -- the object's touched surface,
+    utils/create_point_cloud_from_touches.py:243-244) + a uniform random fill of the cube [-extent, extent]^3 for
+    everything the fingers never reached (table, background), Splatfacto-style: scales from the mean distance to the
+    3 nearest neighbours, random rotations, opacity 0.1, SH dc from the point colour.
+
+    A touch cloud can hold far more points than ``n`` (every touch-depth pixel of every training view): it is then
+    SUBSAMPLED uniformly at random to ``seed_fraction * n`` points, so that all views contribute and the rest of the
+    scene still gets its random fill.  (Rounds 1-4 kept the first ``n`` points in file order -- the first views'
+    touches only -- and dropped the fill whenever the cloud was larger than ``n``.)"""
     g = torch.Generator().manual_seed(seed)
     pts, cols = [], []
-    if seed_points is not None:
-        pts.append(seed_points[0])
-        cols.append(seed_points[1] / 255.0)
+    if seed_points is not None and len(seed_points[0]):
+        sp, sc = seed_points[0].float(), seed_points[1].float() / 255.0
+        cap = max(int(n * seed_fraction), 1)
+        if len(sp) > cap:
+            sel = torch.randperm(len(sp), generator=g)[:cap]
+            sp, sc = sp[sel], sc[sel]
+        pts.append(sp)
+        cols.append(sc)
     n_rand = max(n - sum(len(p) for p in pts), 0)
     if n_rand:
         pts.append((torch.rand(n_rand, 3, generator=g) - 0.5) * 2 * extent)
@@ -46,11 +59,14 @@ def init_params(n: int, K: int, device, seed_points=None, extent: float = 1.0, s
     means = torch.cat(pts)[:n].float()
     colors = torch.cat(cols)[:n].float()
     N = means.shape[0]
-    sub = means[torch.randperm(N, generator=g)[:min(N, 20000)]]
-    d = torch.cdist(means[:min(N, 200000)], sub)
-    knn = d.topk(4, largest=False).values[:, 1:].mean(1).clamp_min(1e-4)
-    scale = torch.full((N,), float(knn.median()))
-    scale[:knn.numel()] = knn
+    # mean distance to the 3 nearest neighbours, exact, in blocks (the cloud mixes a dense object with a sparse fill:
+    # a subsampled estimate would give the object's points the fill's spacing)
+    knn = torch.empty(N)
+    md = means.to(device)
+    for b in range(0, N, 4096):
+        d = torch.cdist(md[b:b + 4096], md)
+        knn[b:b + 4096] = d.topk(4, largest=False).values[:, 1:].mean(1).clamp_min(1e-5).cpu()
+    scale = knn
     sh = torch.zeros(N, K, 3)
     sh[:, 0] = (colors - 0.5) / SH_C0
     quats = torch.nn.functional.normalize(torch.randn(N, 4, generator=g), dim=1)
@@ -101,6 +117,12 @@ def main(argv=None):
     ap.add_argument("--steps-per-save", type=int, default=2000)
     ap.add_argument("--steps-per-eval", type=int, default=500)
     ap.add_argument("--num-gaussians", type=int, default=100000)
+    ap.add_argument("--random-extent", type=float, default=1.0,
+                    help="half side of the cube the random fill of the initial Gaussians is drawn from (scaled scene units)")
+    ap.add_argument("--seed-fraction", type=float, default=0.5,
+                    help="largest share of the initial Gaussians taken from the touch point cloud")
+    ap.add_argument("--eval-views-during-training", type=int, default=0,
+                    help="at every --steps-per-eval also print held-out PSNR / depth MSE over this many eval views")
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--sync-budget", action="store_true",
                     help="read the intersection count back every step instead of the sync-free speculative budget")
@@ -119,6 +141,7 @@ def main(argv=None):
     ap.add_argument("--resolution-schedule", type=int, default=250, help="double the resolution every this many steps")
     ap.add_argument("--refine-every", type=int, default=100)
     ap.add_argument("--warmup-length", type=int, default=500)
+    ap.add_argument("--densify-grad-thresh", type=float, default=0.0002)
     args = ap.parse_args(argv)
 
     dp = parallel.init_from_env()
@@ -137,7 +160,8 @@ def main(argv=None):
         from .dataset import Scene
         scene = Scene(args.data, args.train_split_fraction, dev, uncertainty_scaling=args.uncertainty_scaling)
         views, i_train, i_eval = scene.views, list(scene.i_train), list(scene.i_eval)
-        params = init_params(args.num_gaussians, K, dev, scene.seed_points(), seed=args.seed)
+        params = init_params(args.num_gaussians, K, dev, scene.seed_points(), extent=args.random_extent, seed=args.seed,
+                             seed_fraction=args.seed_fraction)
         scene_name = os.path.basename(os.path.normpath(args.data))
     cfg = ModelConfig(sh_degree=args.sh_degree, depth_loss_mult=args.depth_loss_mult,
                       depth_loss_type=args.depth_loss_type, uncertainty_weight=args.uncertainty_weight,
@@ -148,7 +172,8 @@ def main(argv=None):
         model.spatial_sort()
     if args.densify:
         from .densify import DensifyConfig
-        model.enable_densification(DensifyConfig(refine_every=args.refine_every, warmup_length=args.warmup_length))
+        model.enable_densification(DensifyConfig(refine_every=args.refine_every, warmup_length=args.warmup_length,
+                                                 num_train_data=len(i_train), densify_grad_thresh=args.densify_grad_thresh))
     trainer_state = dict(uncertainty_scaling=args.uncertainty_scaling, densify=bool(args.densify),
                          num_downscales=args.num_downscales)
     if args.load_checkpoint:
@@ -198,7 +223,11 @@ def main(argv=None):
         if dp.rank == 0 and at_eval:
             loss = model.loss_from(model.last["tile_loss"], model.last["ssim_sum"], model.last["view"])
             print(f"step {step + 1}: " + " ".join(f"{k}={float(v):.5f}" for k, v in loss.items()) +
-                  f"  {(step + 1 - 0) / (time.time() - t0):.1f} it/s", flush=True)
+                  f"  N={model.params.N}  {(step + 1 - 0) / (time.time() - t0):.1f} it/s", flush=True)
+            if args.eval_views_during_training > 0:
+                k = max(len(eval_views) // args.eval_views_during_training, 1)
+                r = evaluate(model, eval_views[::k][:args.eval_views_during_training])
+                print(f"   held-out: " + " ".join(f"{a}={b:.5g}" for a, b in r.items()), flush=True)
         if dp.rank == 0 and at_save:
             torch.save(dict(model.state_dict(), trainer=trainer_state), os.path.join(run_dir, f"step-{step + 1:09d}.ckpt"))
     model.flush()
