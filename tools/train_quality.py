@@ -20,6 +20,7 @@ ap.add_argument("--iters", type=int, default=30000)
 ap.add_argument("--runs", default="bunny_real:1,bunny_real:0,block:1,block:0")
 ap.add_argument("--num-gaussians", type=int, default=100000)
 ap.add_argument("--out", default="gpurun_out/train_quality.json")
+ap.add_argument("--images", default=None, help="directory for [truth | render] pictures of two held-out views per run")
 ap.add_argument("extra", nargs="*", help="extra trainer flags after --")
 args = ap.parse_args()
 root = args.root or tempfile.mkdtemp(prefix="tq_")
@@ -39,6 +40,36 @@ for spec in args.runs.split(","):
     flags, wd = spec.split(":")
     r = A.train_and_eval(root, flags, wd == "1", iters=args.iters, num_gaussians=args.num_gaussians, extra_args=args.extra)
     out["runs"][spec] = r
+    if args.images:   # held-out view 0: [truth | render] colour and depth, half size, for a look
+        import glob, numpy as np
+        from PIL import Image
+        from touch_gs_amd.dataset import Scene
+        from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
+        from touch_gs_amd.optim import GaussianParams
+        cfg = json.load(open(os.path.join(r["run_dir"], "config.json")))
+        sd = torch.load(sorted(glob.glob(os.path.join(r["run_dir"], "step-*.ckpt")))[-1], map_location="cuda")
+        mc = {k: v for k, v in cfg["model"].items() if k in ModelConfig.__dataclass_fields__}
+        mc["background_color"] = tuple(mc["background_color"])
+        m = DepthGaussianSplattingModel(ModelConfig(**mc), GaussianParams.allocate(sd["N"], sd["K"], "cuda"))
+        m.load_state_dict(sd)
+        scene = Scene(root, A.FLAG_SETS[flags]["split"], "cuda")
+        os.makedirs(args.images, exist_ok=True)
+        if os.environ.get("TQ_SAVE_MODEL"):
+            torch.save(dict(flat=sd["flat"].cpu(), N=sd["N"], K=sd["K"], step=sd["step"], model=mc,
+                            cams=[dict(viewmat=v.cam.viewmat.tolist(), fx=v.cam.fx, fy=v.cam.fy, cx=v.cam.cx, cy=v.cam.cy,
+                                       W=v.cam.W, H=v.cam.H) for v in scene.views], i_eval=[int(i) for i in scene.i_eval]),
+                       os.path.join(args.images, f"model_{spec.replace(':', '_')}.pt"))
+        for j in list(scene.i_eval)[:: max(len(scene.i_eval) // 2, 1)][:2]:
+            v = scene.views[j]
+            o = m.get_outputs(v.cam, sh_degree=m.active_sh_degree())
+            stem = os.path.splitext(os.path.basename(scene.names[j]))[0]
+            gt = torch.from_numpy(np.load(os.path.join(root, "gt_depth", stem + ".npy"))).cuda().float() * scene.scale
+            rgb = torch.cat([v.rgb, o["rgb"].clamp(0, 1)], 1)
+            dep = (torch.cat([gt, o["depth"][..., 0], v.depth], 1) / 4.0).clamp(0, 1)[..., None].expand(-1, -1, 3)
+            img = torch.cat([rgb, dep[:, :rgb.shape[1]]], 0)
+            Image.fromarray((img * 255).to(torch.uint8).cpu().numpy()).resize((img.shape[1] // 2, img.shape[0] // 2)).save(
+                os.path.join(args.images, f"{spec.replace(':', '_')}_{stem}.jpg"), quality=85)
+        del m
     print(spec, json.dumps(r), flush=True)
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     json.dump(out, open(args.out, "w"), indent=1)

@@ -240,8 +240,8 @@ def fake_monocular_depth(gt: np.ndarray, rng: np.random.Generator) -> np.ndarray
 
 
 def write_raw_capture(root: str, n_views: int = 100, n_touches: int = 50, W: int = 1280, H: int = 720,
-                      device="cpu", seed: int = 0, gpis_stride: int = 2, gpis_length_scale: float = 0.02, gpis_max_var: float = 0.1,
-                      sensor_noise_mm: float = 1.0, verbose: bool = False) -> dict:
+                      device="cpu", seed: int = 0, gpis_stride: int = 2, gpis_length_scale: float = 0.02, gpis_max_var: float = 0.01,
+                      sensor_noise_mm: float = 1.0, verbose: bool = False, with_gpis: bool = True) -> dict:
     """Writes the raw capture described in the module docstring.  ``W, H`` scale the reference's 1280 x 720 camera
     (intrinsics scale along).  Returns a summary (touch point count, GPIS error against the analytic surface)."""
     from PIL import Image
@@ -258,7 +258,7 @@ def write_raw_capture(root: str, n_views: int = 100, n_touches: int = 50, W: int
     cams = orbit_cameras(n_views, seed=seed)
     pts, sens = touch_readings(sc, n_touches, seed=seed)
     normals = estimate_outward_normals(pts, sens)
-    gp = GPIS(length_scale=gpis_length_scale, offset=0.005, noise_var=1e-5).fit(pts, normals, max_points=1800, rng=rng)
+    gp = GPIS(length_scale=gpis_length_scale, offset=0.005, noise_var=1e-5).fit(pts, normals, max_points=1300, rng=rng)
     gp.device = device
     frames, err, cover = [], [], []
     import time
@@ -278,8 +278,11 @@ def write_raw_capture(root: str, n_views: int = 100, n_touches: int = 50, W: int
         np.save(os.path.join(root, "realsense_depth", f"{i}.npy"), np.where(rs > 0, rs_mm, 0.0))
         tm["io"] += clock() - t0
         t0 = clock()
-        gd, gv = gp.render_depth(c2w, *intr, W, H, near=0.05, far=1.5, stride=gpis_stride, n_steps=48, max_var=gpis_max_var,
-                                  var_floor=1e-3, roi_margin_px=max(int(24 * k), 4))
+        if with_gpis:
+            gd, gv = gp.render_depth(c2w, *intr, W, H, near=0.05, far=1.5, stride=gpis_stride, max_var=gpis_max_var,
+                                      var_floor=1e-3, roi_margin_px=max(int(24 * k), 4))
+        else:
+            gd = gv = np.full((H, W), np.nan)
         if gpis_stride > 1:   # rendered on a coarser grid: fill the skipped pixels from the nearest rendered one
             gd, gv = _fill_stride(gd, gpis_stride), _fill_stride(gv, gpis_stride)
         tm["gpis"] += clock() - t0
@@ -416,7 +419,7 @@ def exact_depth_errors(run_dir: str, root: str, split: float, device="cuda") -> 
     model = DepthGaussianSplattingModel(ModelConfig(**mc), GaussianParams.allocate(sd["N"], sd["K"], device))
     model.load_state_dict(sd)
     scene = Scene(root, split, device)
-    e_all, e_obj = [], []
+    e_all, e_obj, a_all, a_obj = [], [], [], []
     for i in scene.i_eval:
         stem = os.path.splitext(os.path.basename(scene.names[i]))[0]
         gt = torch.from_numpy(np.load(os.path.join(root, "gt_depth", stem + ".npy"))).to(device).float() * scene.scale
@@ -424,4 +427,7 @@ def exact_depth_errors(run_dir: str, root: str, split: float, device="cuda") -> 
         d = model.get_outputs(scene.views[i].cam, sh_degree=model.active_sh_degree())["depth"][..., 0]
         e_all.append(float(((d - gt) ** 2).mean()))
         e_obj.append(float(((d - gt)[ob] ** 2).mean()))
-    return dict(exact_depth_mse=float(np.mean(e_all)), exact_object_depth_mse=float(np.mean(e_obj)))
+        a_all.append(float((d - gt).abs().median()) / scene.scale)
+        a_obj.append(float((d - gt)[ob].abs().median()) / scene.scale)
+    return dict(exact_depth_mse=float(np.mean(e_all)), exact_object_depth_mse=float(np.mean(e_obj)),
+                exact_depth_median_abs_m=float(np.mean(a_all)), exact_object_depth_median_abs_m=float(np.mean(a_obj)))

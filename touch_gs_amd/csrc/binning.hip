@@ -94,7 +94,8 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int T, int NB, int32_t* __r
       for (int w = 1; w < 16; w++) mg = max(mg, wave_mg[w]);
       const int32_t* xa = tile_count + TGS_ALLOC_OFF(T);
       long long n = 0;
-      for (int x = 0; x < TGS_XCC; x++) n += (long long)xa[x * TGS_ALLOC_STRIDE] + xa[x * TGS_ALLOC_STRIDE + 1];
+      for (int x = 0; x < TGS_XCC; x++)   // allocated (+ overshoot of failed attempts, word 2) + pairs that found no room
+        n += (long long)xa[x * TGS_ALLOC_STRIDE] - xa[x * TGS_ALLOC_STRIDE + 2] + xa[x * TGS_ALLOC_STRIDE + 1];
       const long long need = n + (long long)TGS_XCC * mg;
       status[0] = (int32_t)min(status[1] != 0 ? need : n, 0x7fffffffll);
       status[2] = (int32_t)min(need, 0x7fffffffll);
@@ -165,6 +166,9 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int T, int NB, int32_t* __r
   // 16 of the 512 scratch ints behind the tile starts collect the frame's deepest walk and the sum of its walks (K6,
   // raster.hip publish_walk: a pair of words per XCD, 256 B apart) for K7
   if (b == NB - 1 && tid >= 1 && tid <= 16) tile_start[T + 1 + 64 * ((tid - 1) >> 1) + ((tid - 1) & 1)] = 0;
+  // ... and the 8 slot counters of K7's four-wave launch (TGS_SLOTCTR_AT): k_raster_bwd clears them again before every
+  // backward, but a buffer that comes out of torch.empty must not depend on that launch having reached the store
+  if (b == NB - 1 && tid >= 17 && tid <= 24) tile_start[T + 1 + 64 * (tid - 17) + 32] = 0;
 }
 
 // K3b: scatter (gid, depth bits) into the tile bins.  slot = tile_start + arrival rank.

@@ -205,7 +205,8 @@ __device__ __forceinline__ void publish_walk(const int32_t* __restrict__ tile_st
                                              int n, int lane) {
   int wl = 0;
 #pragma unroll
-  for (int k = 0; k < 4; k++) wl = max(wl, min(stop_of(smax[k]), n));
+  for (int k = 0; k < 4; k++)   // a pixel outside the image (smax = the -3e38 sentinel, never a stop code) walks nothing
+    wl = max(wl, smax[k] == -3.0e38f ? 0 : min(stop_of(smax[k]), n));
   wl = wave_minmax_i<true>(wl);
   if (lane == 0 && wl > 0) {
     const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & (TGS_WALK_WORDS - 1));
@@ -490,7 +491,7 @@ __device__ __forceinline__ void raster_fwd_quadrant(
     if (stop_pos) stop_pos[p] = stop_of(smax);
   }
   // the quadrant's walk: the maximum is the tile's once all four have reported; a quarter each into the sum
-  int wl = wave_minmax_i<true>(min(stop_of(smax), end - start));
+  int wl = wave_minmax_i<true>(inb ? min(stop_of(smax), end - start) : 0);
   if (lane == 0 && wl > 0) {
     const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & (TGS_WALK_WORDS - 1));
     atomicMax(const_cast<int32_t*>(tile_start) + TGS_WALK_AT(T_total, xcc), wl);
@@ -987,6 +988,10 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
     const float* __restrict__ v_depth, const float* __restrict__ v_alpha, LossK loss,
     float* __restrict__ partials, float* __restrict__ tile_loss,
     const int32_t* __restrict__ tile_order, QuadRule quad) {
+  // the slot counters of the four-wave launch that follows in the stream (8 words behind the walk words): cleared by
+  // block 0 BEFORE any early return -- block 0's tile is empty in most object-centric frames
+  if (blockIdx.x == 0 && threadIdx.x < TGS_WALK_WORDS && quad.factor > 0)
+    const_cast<int32_t*>(tile_start)[TGS_SLOTCTR_AT(T_total, threadIdx.x)] = 0;
   const int tile = tile_order ? tile_order[blockIdx.x] : xcd_tile(blockIdx.x, T_total);
   if (tile >= T_total) return;
   const int lane = threadIdx.x;
@@ -1055,9 +1060,6 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
 #pragma unroll
   for (int k = 0; k < 4; k++) qlim[k] = wave_minmax_i<true>(lim[k]);
   const int tmax = max(max(qlim[0], qlim[1]), max(qlim[2], qlim[3]));
-  // (the slot counters of the four-wave launch that follows in the stream: 8 words behind the walk words)
-  if (blockIdx.x == 0 && lane < TGS_WALK_WORDS && quad.factor > 0)
-    const_cast<int32_t*>(tile_start)[TGS_SLOTCTR_AT(T_total, lane)] = 0;
   // in a chain-bound frame every tile with a walk worth splitting is k_raster_bwd_quad's (four waves); its losses were
   // written above
   if (tmax > quad.min_walk && frame_is_chain_bound(tile_start, T_total, quad)) return;

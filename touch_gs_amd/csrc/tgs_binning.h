@@ -31,7 +31,7 @@ int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* gro
 // counter buffer layout: count[8][T] | sub_start[8][T] | scan aggregates[64] | longest list[1] (+pad)
 #define TGS_XCC 8
 #define TGS_SCAN_WGS 64
-// ... | pair allocators: one 128-B line per XCD holding {allocated pairs, pairs that found no room}.  The pair index space [0, capacity) is cut into one region per XCD and a
+// ... | pair allocators: one 128-B line per XCD holding {allocated pairs + overshoot, pairs that found no room, overshoot of failed attempts}.  The pair index space [0, capacity) is cut into one region per XCD and a
 // group takes its contiguous pair range from the region of the XCD it runs on; if that region is
 // full (which XCD runs which workgroup is not deterministic, and with few groups the shares are very
 // uneven) it takes the range from the first other region with room.  An allocation can therefore
@@ -218,12 +218,24 @@ __device__ __forceinline__ void group_count_tiles(GroupScan& S, int TW, int T, i
     long long loc = local;
     bool fits = loc + total <= region;
     if (!fits) {   // rare: this XCD's region is full -- take the range from another region with room
-      atomicSub(&alloc[x * TGS_ALLOC_STRIDE], total);
+      // A failed attempt is NOT given back (round 5).  Rounds 3-4 subtracted the total again, which lets a third
+      // group's add return an offset INSIDE a range a second group took in between (A: add t1 -> doesn't fit; B: add
+      // t2 -> [A + t1, A + t1 + t2) fits; A: sub t1; C: add t3 -> [A + t2, ..) overlaps B's range): two groups then
+      // write the same pair slots, the tile counters count both, and the lost pairs leave unwritten entries in the
+      // sorted lists -- garbage Gaussian ids, a memory fault in K6 (seen on a held-out view of an 8-view model at
+      // 89 % of the capacity).  Instead the overshoot stays on the counter, which CLOSES the region (every later add
+      // returns a value beyond it), and word 2 of the line remembers it so that the frame's pair count stays exact.
+      // The bound holds as before: a region is closed or refuses a group only when its real fill exceeds
+      // region - (largest group total), so every allocation succeeds while #pairs + 8 x largest <= capacity.
+      atomicAdd(&alloc[x * TGS_ALLOC_STRIDE + 2], total);
       for (int t = 1; t < TGS_XCC && !fits; t++) {
         xr = (x + t) & (TGS_XCC - 1);
+        // closed or too full already (a racy look: only saves the add; the add's own result decides)
+        if ((long long)__hip_atomic_load(&alloc[xr * TGS_ALLOC_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + total > region)
+          continue;
         loc = atomicAdd(&alloc[xr * TGS_ALLOC_STRIDE], total);
         fits = loc + total <= region;
-        if (!fits) atomicSub(&alloc[xr * TGS_ALLOC_STRIDE], total);
+        if (!fits) atomicAdd(&alloc[xr * TGS_ALLOC_STRIDE + 2], total);
       }
       if (!fits) atomicAdd(&alloc[x * TGS_ALLOC_STRIDE + 1], total);   // still part of the frame's pair count
     }

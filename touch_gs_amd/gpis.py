@@ -58,8 +58,22 @@ class GPIS:
             sel = (rng or np.random.default_rng(0)).choice(len(P), max_points, replace=False)
             P, Nn = P[sel], Nn[sel]
         d = self.offset
-        self.X = np.concatenate([P, P + d * Nn, P - d * Nn])
-        y = np.concatenate([np.zeros(len(P)), np.full(len(P), d), np.full(len(P), -d)])
+        # signed-distance targets along the normal: +d outside, -d and -2d inside (the second inside layer makes the
+        # negative shell behind a touched patch thick enough for a ray march to find).  An offset point that lies
+        # closer to ANOTHER part of the touched surface than its own offset says (a thin part: the inside point of
+        # one face comes out of the opposite face) would contradict that part's own observations: dropped.
+        self.P, self.N = P, Nn
+        cand = [(P + d * Nn, d), (P - d * Nn, -d), (P - 2 * d * Nn, -2 * d)]
+        Xs, ys = [P], [np.zeros(len(P))]
+        from scipy.spatial import cKDTree
+        tree = cKDTree(P)
+        for Q, val in cand:
+            near, _ = tree.query(Q)
+            ok = near >= 0.9 * abs(val)
+            Xs.append(Q[ok])
+            ys.append(np.full(int(ok.sum()), val))
+        self.X = np.concatenate(Xs)
+        y = np.concatenate(ys)
         K = self._k(self.X, self.X)
         K[np.diag_indices_from(K)] += self.sn2
         self.chol = cho_factor(K, lower=True)
@@ -89,6 +103,12 @@ class GPIS:
         var = self.sf2 - ((Kq @ Kinv) * Kq).sum(1)
         return mean.cpu().numpy(), var.clamp_min(0.0).cpu().numpy()
 
+    def _tree(self):
+        if getattr(self, "_kd", None) is None:
+            from scipy.spatial import cKDTree
+            self._kd = cKDTree(self.P)
+        return self._kd
+
     def predict(self, Q: np.ndarray, want_var: bool = True) -> Tuple[np.ndarray, Optional[np.ndarray]]:
         if getattr(self, "device", None) is not None:
             return self._predict_torch(Q, want_var)
@@ -104,12 +124,17 @@ class GPIS:
         return mean, np.maximum(var, 0.0)
 
     def render_depth(self, c2w_opengl: np.ndarray, fx: float, fy: float, cx: float, cy: float, W: int, H: int,
-                     near: float = 0.02, far: float = 2.0, n_steps: int = 96, stride: int = 1,
+                     near: float = 0.02, far: float = 2.0, n_steps: Optional[int] = None, stride: int = 1,
                      roi_margin_px: int = 24, chunk: int = 20000, max_var: Optional[float] = None,
                      var_floor: float = 0.0):
         """-> (depth [H,W] metres, var [H,W]); NaN where the ray meets no surface.  ``c2w_opengl`` is
         the transforms.json camera (x right, y up, -z forward).
 
+        ``n_steps``: samples of the march between the nearest and the farthest touched point (+- 3 length scales);
+        default: one every 0.6 x offset, so that the negative shell behind a touched patch (~2 offsets thick) cannot be
+        stepped over.  A crossing is kept only if the touched point that dominates it FACES the camera (its outward
+        normal against the ray): a ray that comes from an untouched side and enters the inside shell of a far-side
+        patch from behind crosses from the positive prior to negative values as well, but no surface is seen there.
         ``max_var``: crossings whose posterior variance exceeds it are reported as "no surface seen" (NaN): far from
         every touch the posterior mean is the prior and a zero crossing there carries no information -- without the
         cut, the inverse-variance fusion downstream (variance ~ signal_var = 1 against the vision prior's >= 5,
@@ -122,7 +147,7 @@ class GPIS:
         depth = np.full((H, W), np.nan)
         var = np.full((H, W), np.nan)
         # region of interest: pixels near the projection of the observed surface points
-        Pc = (self.X[: len(self.X) // 3] - t) @ R
+        Pc = (self.P - t) @ R
         front = Pc[:, 2] > near
         if not front.any():
             return depth, var
@@ -137,6 +162,8 @@ class GPIS:
         us, vs = np.meshgrid(np.arange(u0, u1 + 1, stride), np.arange(v0, v1 + 1, stride))
         us, vs = us.ravel(), vs.ravel()
         dirs_c = np.stack([(us + 0.5 - cx) / fx, (vs + 0.5 - cy) / fy, np.ones_like(us, dtype=np.float64)], 1)
+        if n_steps is None:
+            n_steps = int(np.clip(np.ceil((zs_hi - zs_lo) / (0.6 * self.offset)), 16, 512))
         zgrid = np.linspace(zs_lo, zs_hi, n_steps)
         for s in range(0, len(us), chunk):
             dc = dirs_c[s:s + chunk]
@@ -165,9 +192,13 @@ class GPIS:
                 lo = np.where(inside, lo, mid)
             zhit = 0.5 * (lo + hi)
             _, vv = self.predict(t + zhit[:, None] * dw[idx], want_var=True)
+            # facing test: outward normal of the touched point nearest to the crossing against the ray
+            ph = t + zhit[:, None] * dw[idx]
+            _, nn = self._tree().query(ph)
+            sure = np.einsum("ij,ij->i", self.N[nn], dw[idx] / np.linalg.norm(dw[idx], axis=1, keepdims=True)) < -0.05
             if max_var is not None:
-                sure = vv <= max_var
-                idx, zhit, vv = idx[sure], zhit[sure], vv[sure]
+                sure &= vv <= max_var
+            idx, zhit, vv = idx[sure], zhit[sure], vv[sure]
             depth[vs[s:s + chunk][idx], us[s:s + chunk][idx]] = zhit
             var[vs[s:s + chunk][idx], us[s:s + chunk][idx]] = np.maximum(vv, var_floor)
         return depth, var
