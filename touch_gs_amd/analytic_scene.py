@@ -261,6 +261,9 @@ def write_raw_capture(root: str, n_views: int = 100, n_touches: int = 50, W: int
     gp = GPIS(length_scale=gpis_length_scale, offset=0.005, noise_var=1e-5).fit(pts, normals, max_points=1300, rng=rng)
     gp.device = device
     frames, err, cover = [], [], []
+    # zero-padded names: the split rule picks every k-th file of the SORTED name list
+    # (utils/create_point_cloud_from_touches.py:174-198), and "10" sorts before "2"
+    stem = lambda i: f"{i:03d}"
     import time
     tm = {"render": 0.0, "sensor": 0.0, "gpis": 0.0, "io": 0.0}
     clock = time.perf_counter
@@ -269,13 +272,13 @@ def write_raw_capture(root: str, n_views: int = 100, n_touches: int = 50, W: int
         r = sc.render(c2w, intr, W, H)
         tm["render"] += clock() - t0
         t0 = clock()
-        Image.fromarray((np.clip(r["rgb"], 0, 1) * 255 + 0.5).astype(np.uint8)).save(os.path.join(root, "imgs", f"{i}.png"))
-        np.save(os.path.join(root, "gt_depth", f"{i}.npy"), r["depth"].astype(np.float32))
-        np.save(os.path.join(root, "gt_object_mask", f"{i}.npy"), r["object"])
+        Image.fromarray((np.clip(r["rgb"], 0, 1) * 255 + 0.5).astype(np.uint8)).save(os.path.join(root, "imgs", f"{stem(i)}.png"))
+        np.save(os.path.join(root, "gt_depth", f"{stem(i)}.npy"), r["depth"].astype(np.float32))
+        np.save(os.path.join(root, "gt_object_mask", f"{stem(i)}.npy"), r["object"])
         # the depth sensor: its own intrinsics and resolution, millimetres, noise growing with range
         rs = sc.render(c2w, s_intr, sW, sH, want_rgb=False)["depth"]
         rs_mm = rs * 1000.0 + rng.normal(size=rs.shape) * sensor_noise_mm * (rs / 0.5) ** 2
-        np.save(os.path.join(root, "realsense_depth", f"{i}.npy"), np.where(rs > 0, rs_mm, 0.0))
+        np.save(os.path.join(root, "realsense_depth", f"{stem(i)}.npy"), np.where(rs > 0, rs_mm, 0.0))
         tm["io"] += clock() - t0
         t0 = clock()
         if with_gpis:
@@ -287,14 +290,14 @@ def write_raw_capture(root: str, n_views: int = 100, n_touches: int = 50, W: int
             gd, gv = _fill_stride(gd, gpis_stride), _fill_stride(gv, gpis_stride)
         tm["gpis"] += clock() - t0
         t0 = clock()
-        np.save(os.path.join(root, "gpis_depth", f"Image{i}.npy"), gd)
-        np.save(os.path.join(root, "gpis_var", f"Image{i}.npy"), gv)
-        write_png16(os.path.join(root, "zoe_depth", f"{i}.png"), to_uint16_mm(fake_monocular_depth(r["depth"], rng)))
+        np.save(os.path.join(root, "gpis_depth", f"Image{stem(i)}.npy"), gd)
+        np.save(os.path.join(root, "gpis_var", f"Image{stem(i)}.npy"), gv)
+        write_png16(os.path.join(root, "zoe_depth", f"{stem(i)}.png"), to_uint16_mm(fake_monocular_depth(r["depth"], rng)))
         m = np.isfinite(gd) & r["object"]
         if m.any():
             err.append(float(np.sqrt(np.mean((gd[m] - r["depth"][m]) ** 2))))
             cover.append(float(m.sum() / max(r["object"].sum(), 1)))
-        frames.append({"file_path": f"imgs/{i}.png", "transform_matrix": c2w.tolist()})
+        frames.append({"file_path": f"imgs/{stem(i)}.png", "transform_matrix": c2w.tolist()})
         tm["io"] += clock() - t0
         if verbose:
             print(f"view {i}: seconds so far {({k: round(v, 2) for k, v in tm.items()})} gpis rmse {err[-1] if err else float('nan'):.4f} m, cover {cover[-1] if cover else 0:.2f}", flush=True)

@@ -19,6 +19,13 @@ encoding).  ``uncertainty_scaling`` chooses what happens to the decoded map:
   "variance" the square of that factor (the map is a variance of a depth in metres,
              utils/fuse_touch_vision.py:76-202; dimensionally consistent with residual^2 / U);
   "none"     the decoded metres^2 values as stored.
+``uncertainty_floor`` (default 0 = off) is a lower bound applied to the decoded map, in the map's own units, before
+the scaling: a GPIS touch variance of 0.001 - 0.01 next to the vision prior's >= 5 (utils/fuse_touch_vision.py:310)
+gives a touched pixel 500 - 5000 x the weight of any other in the uncertainty-weighted loss -- its residual keeps the
+screen-space gradients of the Gaussians it sees above the densification threshold however well they fit (the GP surface
+is accurate to millimetres at best, and is rendered into every view), and the refinement piles several 10^5 Gaussians
+onto the touched object (56 000 in one tile of a 720p frame: 130 iterations/s instead of 900).  A floor of 0.05 bounds
+the ratio at 100.
 The choice is recorded by the trainer in config.json (``Scene.describe()``) and used identically by
 the nerfstudio plugin's dataparser (nerfstudio_plugin.py).  ``ModelConfig.depth_eps`` is in the
 units of the scaled map.
@@ -63,11 +70,12 @@ class Scene:
     def __init__(self, root: str, train_split_fraction: float = 0.9, device="cuda", scale_poses: bool = True,
                  depth_unit_scale_factor: float = 1e-3, real_world: Optional[bool] = None,
                  gt_depth_dir: str = "realsense_depths", object_mask_dir: str = "touch_depth",
-                 uncertainty_scaling: str = "linear"):
+                 uncertainty_scaling: str = "linear", uncertainty_floor: float = 0.0):
         self.root = root
         if uncertainty_scaling not in UNCERTAINTY_SCALINGS:
             raise ValueError(f"uncertainty_scaling must be one of {UNCERTAINTY_SCALINGS}")
         self.uncertainty_scaling = uncertainty_scaling
+        self.uncertainty_floor = float(uncertainty_floor)
         self.depth_unit_scale_factor = depth_unit_scale_factor
         if real_world is None:
             real_world = os.environ.get("IS_REAL_WORLD", "").lower() in ("1", "true", "yes")
@@ -93,9 +101,11 @@ class Scene:
                 depth = torch.from_numpy(from_uint16_mm(read_png16(os.path.join(root, fr["depth_file_path"])))
                                          .astype(np.float32) * (depth_unit_scale_factor * 1e3) * self.scale)
             if "uncertainty_file_path" in fr:
-                unc = torch.from_numpy(from_uint16_mm(read_png16(os.path.join(root, fr["uncertainty_file_path"])))
-                                       .astype(np.float32) *
-                                       uncertainty_factor(uncertainty_scaling, depth_unit_scale_factor, self.scale))
+                unc_m = from_uint16_mm(read_png16(os.path.join(root, fr["uncertainty_file_path"]))).astype(np.float32)
+                if self.uncertainty_floor > 0:     # in the map's own units, before any scaling (module docstring)
+                    unc_m = np.maximum(unc_m, np.float32(self.uncertainty_floor))
+                unc = torch.from_numpy(unc_m * np.float32(uncertainty_factor(uncertainty_scaling, depth_unit_scale_factor,
+                                                                             self.scale)))
             view = View(cam=cam, rgb=torch.from_numpy(rgb).to(device).contiguous(),
                         depth=None if depth is None else depth.to(device).contiguous(),
                         uncertainty=None if unc is None else unc.to(device).contiguous())
@@ -121,7 +131,7 @@ class Scene:
     def describe(self) -> dict:
         """What the trainer records in config.json about the units of the supervision maps."""
         return dict(dataparser_scale=self.scale, depth_unit_scale_factor=self.depth_unit_scale_factor,
-                    uncertainty_scaling=self.uncertainty_scaling,
+                    uncertainty_scaling=self.uncertainty_scaling, uncertainty_floor=self.uncertainty_floor,
                     uncertainty_factor=uncertainty_factor(self.uncertainty_scaling, self.depth_unit_scale_factor,
                                                           self.scale))
 

@@ -50,6 +50,13 @@ class DensifyConfig:
     # removes Gaussians the scene needs.  The trainer sets this to its number of training views.
     num_train_data: int = 0
     continue_cull_post_densification: bool = True
+    # Cull Gaussians that NO training view has had in its frustum during a whole refinement window (applied only when
+    # the window covers every training view at least once: refine_every >= num_train_data > 0).  Not in Splatfacto,
+    # whose seeds are SfM points the cameras see by construction: here the seeds are a touch cloud + a random fill of
+    # the scene cube, and in the reference's few-view regime (8 - 13 views) a large part of that fill lies in space
+    # no training camera covers -- it can never be supervised or culled by opacity (it keeps its initial 0.1), and
+    # shows up as haze right in front of the held-out cameras.
+    cull_unseen: bool = True
 
 
 def quat_to_rotmat(q: torch.Tensor) -> torch.Tensor:
@@ -130,6 +137,8 @@ class DensityController:
             cull = cull | too_big
         if not do_cull:
             cull &= False
+        if c.cull_unseen and c.num_train_data > 0 and c.refine_every >= c.num_train_data:
+            cull = cull | (self.vis_count == 0)
         keep = ~cull & ~split  # split parents are replaced by their samples
         clone = clone & ~cull
         split = split & ~cull

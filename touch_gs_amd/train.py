@@ -113,6 +113,9 @@ def main(argv=None):
     ap.add_argument("--train-split-fraction", type=float, default=0.9)
     ap.add_argument("--uncertainty-scaling", type=str, default="linear", choices=("linear", "variance", "none"),
                     help="units of the uncertainty map in the scaled scene (dataset.py docstring; UNVERIFIED-PRIOR)")
+    ap.add_argument("--uncertainty-floor", type=float, default=0.05,
+                    help="lower bound of the uncertainty map, in the map's own units (dataset.py docstring: without it "
+                         "the touched pixels pile the refinement onto the object); 0 = off")
     ap.add_argument("--max-num-iterations", type=int, default=30000)
     ap.add_argument("--steps-per-save", type=int, default=2000)
     ap.add_argument("--steps-per-eval", type=int, default=500)
@@ -158,7 +161,8 @@ def main(argv=None):
         scene_name = f"synthetic_{N}_{W}x{H}"
     else:
         from .dataset import Scene
-        scene = Scene(args.data, args.train_split_fraction, dev, uncertainty_scaling=args.uncertainty_scaling)
+        scene = Scene(args.data, args.train_split_fraction, dev, uncertainty_scaling=args.uncertainty_scaling,
+                      uncertainty_floor=args.uncertainty_floor)
         views, i_train, i_eval = scene.views, list(scene.i_train), list(scene.i_eval)
         params = init_params(args.num_gaussians, K, dev, scene.seed_points(), extent=args.random_extent, seed=args.seed,
                              seed_fraction=args.seed_fraction)
@@ -174,7 +178,7 @@ def main(argv=None):
         from .densify import DensifyConfig
         model.enable_densification(DensifyConfig(refine_every=args.refine_every, warmup_length=args.warmup_length,
                                                  num_train_data=len(i_train), densify_grad_thresh=args.densify_grad_thresh))
-    trainer_state = dict(uncertainty_scaling=args.uncertainty_scaling, densify=bool(args.densify),
+    trainer_state = dict(uncertainty_scaling=args.uncertainty_scaling, uncertainty_floor=args.uncertainty_floor, densify=bool(args.densify),
                          num_downscales=args.num_downscales)
     if args.load_checkpoint:
         sd = torch.load(args.load_checkpoint, map_location=dev)
