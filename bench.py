@@ -159,6 +159,62 @@ def cpu_baseline(N, W, H, deg, seed, frac=None, clustered=False):
                              project_bwd=t5 - t4))
 
 
+def cpu_baseline_torch(cfg_name="cfg2"):
+    """north_star: "the reference's pure-PyTorch CPU rasterizer timed on the same box's host cores".  The reference's
+    rasterizer source is absent (empty submodule), so this is the build's vectorised PyTorch restatement of the published
+    algorithm (oracle/torch_oracle.py, fp32 here; its autograd is the backward) -- forward + backward of configs[1] IN FULL
+    (BASELINE.md section 2), one view, on torch's intra-op thread pool."""
+    from oracle import torch_oracle as O
+    c = CONFIGS[cfg_name]
+    N, W, H, deg = c["gaussians"], c["width"], c["height"], 3
+    P, intr = O.synthetic_scene(N, W, H, deg, c["seed"], dtype=torch.float32)
+    cam = O.Camera(viewmat=O.orbit_viewmat(0, 8, dtype=torch.float32), **intr)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    t0 = time.perf_counter()
+    out, _, _, _ = O.render(Pg["means"], Pg["log_scales"], Pg["quats"], Pg["opac_logit"], Pg["sh"], cam, deg)
+    t1 = time.perf_counter()
+    (out["rgb"].sum() + out["depth_acc"].sum()).backward()
+    t2 = time.perf_counter()
+    return dict(value=round(1.0 / (t2 - t0), 5), unit="train iters/s (fwd+bwd, no SSIM/Adam)", cores=torch.get_num_threads(),
+                kind="port", config=c["label"],
+                sample=f"build's PyTorch-CPU oracle (oracle/torch_oracle.py, fp32, autograd backward), {c['label']} in full, "
+                       f"one view: forward {t1 - t0:.1f} s + backward {t2 - t1:.1f} s",
+                seconds=dict(forward=round(t1 - t0, 2), backward=round(t2 - t1, 2)))
+
+
+def train_quality_run(full: bool = False):
+    """Does the step the headline times TRAIN?  The whole scripts/train_bunny_real.sh sequence on the known-geometry
+    capture (touch_gs_amd/analytic_scene.py): raw capture -> prepare -> touch_gs_amd.train -> run_eval, held-out views
+    only.  Default: reduced size (24 views at 640 x 360, 4000 iterations per run; what tests/test_gpu_train_quality.py
+    asserts on).  ``full``: 100 views at 1280 x 720, 30 000 iterations, the reference's two flag sets with and without the
+    depth term (tools/train_quality.py; ~6 min; committed results: profiles/r5_train_quality.json)."""
+    import tempfile
+    from touch_gs_amd import analytic_scene as A
+    root = tempfile.mkdtemp(prefix="tq_")
+    keys = ("psnr", "ssim", "depth_mse", "gt_depth_mse", "gt_object_depth_mse", "exact_depth_mse", "exact_object_depth_mse",
+            "exact_object_depth_median_abs_m", "gaussian_count", "iters", "split", "train_wall_s", "iters_per_s_wall")
+    if full:
+        t0 = time.perf_counter()
+        cap = A.write_raw_capture(root, n_views=100, device="cuda")
+        A.prepare_capture(root, 0.08)
+        runs = {f"{f}:{d}": A.train_and_eval(root, f, d == 1, iters=30000) for f in ("bunny_real", "block") for d in (1, 0)}
+        r = dict(capture=cap, runs=runs, total_s=round(time.perf_counter() - t0, 1))
+    else:
+        r = A.quick_quality(root)
+    import shutil
+    shutil.rmtree(root, ignore_errors=True)
+    out = {"size": "100 views 1280x720, 30000 iterations" if full else "24 views 640x360, 4000 iterations (reduced)",
+           "total_s": r["total_s"], "gpis_rmse_m": r["capture"]["gpis_rmse_m"], "held_out_views_only": True,
+           "runs": {k: {m: (round(v[m], 5) if isinstance(v[m], float) else v[m]) for m in keys if m in v}
+                    for k, v in r["runs"].items()},
+           "key": "flag set (scripts/train_block_data.sh:50 at 0.8 split | scripts/train_bunny_real.sh:52 few views) : "
+                  "1 = with the depth term, 0 = RGB only; depth errors in the dataparser's scaled frame"}
+    few, rgb = r["runs"].get("bunny_real:1"), r["runs"].get("bunny_real:0")
+    if few and rgb:
+        out["few_view_depth_mse_with_over_without"] = round(few["depth_mse"] / rgb["depth_mse"], 3)
+    return out
+
+
 def densify_run(N, W, H, deg, seed, dev, views, steps=600, clustered=False):
     """The workload the reference's method actually runs for the first half of its 30 000 iterations
     (a densifying Splatfacto), next to the steady state the headline value is quoted on:
@@ -224,7 +280,7 @@ def touch_scene_run(dev, steps=3000, target=300_000, seeds=5000, W=1280, H=720, 
     pick = torch.randperm(target, generator=g)[:seeds].to(dev)
     pts = D["means"][pick].float().cpu()
     cols = ((D["sh"][pick, 0].float() * 0.28209479177387814 + 0.5).clamp(0, 1) * 255).cpu()
-    params = train.init_params(seeds, (deg + 1) ** 2, dev, (pts, cols), seed=0)
+    params = train.init_params(seeds, (deg + 1) ** 2, dev, (pts, cols), seed=0, seed_fraction=1.0)
     cfg = ModelConfig(sh_degree=deg, depth_loss_mult=0.2, depth_loss_type="DEPTH_UNCERTAINTY_WEIGHTED_LOSS",
                       uncertainty_weight=1.0, spatial_sort=True, num_downscales=2, resolution_schedule=250)
     m = DepthGaussianSplattingModel(cfg, params)
@@ -309,6 +365,11 @@ def main():
                          "sum(average x calls per step) reproduces ms_per_step (profiles/r4_*_reconcile.json)")
     ap.add_argument("--no-densify-run", action="store_true",
                     help="skip the densifying-training measurement reported as `train_densify` (N = 1 only)")
+    ap.add_argument("--train-quality", choices=("reduced", "full", "off"), default="reduced",
+                    help="end-to-end training quality on the known-geometry capture, reported as `train_quality` (N = 1): "
+                         "reduced = 24 views at 640x360, ~30 s; full = 100 views at 720p, 30 000 iterations x 4 runs, ~6 min")
+    ap.add_argument("--touch-scene-run", action="store_true",
+                    help="also run rounds 3-4's growing-scene throughput measurement (`train_touch_scene`: machinery, not quality)")
     ap.add_argument("--ssim-pipeline", action="store_true",
                     help="SSIM on a second stream pipelined by image bands behind K7 (measured slower; off by default)")
     ap.add_argument("--no-color-prefetch", action="store_true",
@@ -539,7 +600,12 @@ def main():
         dom = max(kern_ms, key=kern_ms.get)
         achieved = sb[dom] / (kern_ms[dom] * 1e-3) / 1e9
         achieved_layout = ab[dom] / (kern_ms[dom] * 1e-3) / 1e9
-        step_bytes = sum(ab.values())
+        # bytes of the kernels the TIMED LOOP runs: single process = K8 and Adam fused (the gradient never reaches HBM:
+        # no A N write by K8, no A N read by Adam); data parallel = the unfused layout
+        A_bytes = 44 + 12 * K
+        fused_loop = not dp.active and model.optimizer.can_fuse_with_backward(deg)
+        step_bytes = sum(ab.values()) - (2 * A_bytes * N if fused_loop else 0)
+        survey_step_bytes = sum(v for k_, v in sb.items() if k_ != "ssim")   # B_fwd + B_bwd + B_adam
         traffic, traffic_src = measured_traffic(dom, N, W, H, deg) if args.config == "cfg3" and not custom else (None, None)
         fwd_bwd_ms = sum(kern_ms[k] for k in names[:5] if k != "ssim")
         fwd_bwd_bytes = sum(sb[k] for k in names[:5] if k != "ssim")
@@ -578,6 +644,10 @@ def main():
                          "achieved_layout": round(achieved_layout, 1), "frac_layout": round(achieved_layout / HBM_PEAK_GBS, 4),
                          "layout_bytes": ab[dom]},
             "step_roofline": {"algorithmic_bytes": step_bytes,
+                              "bytes_model": "this build's layout, kernels of the timed loop"
+                                             + (" (K8 + Adam fused: no gradient round trip)" if fused_loop else ""),
+                              "survey_bytes_fwd_bwd_adam": survey_step_bytes,
+                              "survey_frac_of_hbm_peak": round(survey_step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                               "achieved_GBs": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                               "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                               "fwd_bwd_ms": round(fwd_bwd_ms, 4),
@@ -604,11 +674,18 @@ def main():
                                                    steps=min(600, max(args.steps * 3, 150)))
             except Exception as ex:  # noqa: BLE001 -- a secondary measurement never fails the headline line
                 out["train_densify"] = {"value": None, "error": repr(ex)}
-            try:   # the reference's regime: a 720p scene that starts from touch seeds and grows
-                torch.cuda.empty_cache()
-                out["train_touch_scene"] = touch_scene_run(dev)[0]
-            except Exception as ex:  # noqa: BLE001
-                out["train_touch_scene"] = {"value": None, "error": repr(ex)}
+            if args.touch_scene_run:
+                try:   # a 720p scene of random Gaussians that starts from touch seeds and grows (throughput of the machinery)
+                    torch.cuda.empty_cache()
+                    out["train_touch_scene"] = touch_scene_run(dev)[0]
+                except Exception as ex:  # noqa: BLE001
+                    out["train_touch_scene"] = {"value": None, "error": repr(ex)}
+            if args.train_quality != "off":
+                try:   # the reference's regime end to end: does the trainer reach a usable image / better depth with touch?
+                    torch.cuda.empty_cache()
+                    out["train_quality"] = train_quality_run(full=args.train_quality == "full")
+                except Exception as ex:  # noqa: BLE001
+                    out["train_quality"] = {"value": None, "error": repr(ex)}
         if dp.world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(N, W, H, deg, args.seed, clustered=clustered)
@@ -617,6 +694,10 @@ def main():
                                                         "unit": out["cpu_baseline"]["unit"]}
             except Exception as ex:  # the oracle is test infrastructure; never fail the bench on it
                 out["cpu_baseline"] = {"value": None, "error": repr(ex)}
+            try:
+                out["cpu_baseline"]["torch"] = cpu_baseline_torch("cfg2")
+            except Exception as ex:  # noqa: BLE001
+                out["cpu_baseline"]["torch"] = {"value": None, "error": repr(ex)}
     dp.barrier()
     if dp.peer is not None:      # peer transport: unmap the other ranks' buffers before the group goes away
         dp.check_transport()

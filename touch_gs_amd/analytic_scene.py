@@ -241,7 +241,8 @@ def fake_monocular_depth(gt: np.ndarray, rng: np.random.Generator) -> np.ndarray
 
 def write_raw_capture(root: str, n_views: int = 100, n_touches: int = 50, W: int = 1280, H: int = 720,
                       device="cpu", seed: int = 0, gpis_stride: int = 2, gpis_length_scale: float = 0.02, gpis_max_var: float = 0.01,
-                      sensor_noise_mm: float = 1.0, verbose: bool = False, with_gpis: bool = True) -> dict:
+                      sensor_noise_mm: float = 1.0, verbose: bool = False, with_gpis: bool = True,
+                      gpis_max_points: int = 1300) -> dict:
     """Writes the raw capture described in the module docstring.  ``W, H`` scale the reference's 1280 x 720 camera
     (intrinsics scale along).  Returns a summary (touch point count, GPIS error against the analytic surface)."""
     from PIL import Image
@@ -258,7 +259,7 @@ def write_raw_capture(root: str, n_views: int = 100, n_touches: int = 50, W: int
     cams = orbit_cameras(n_views, seed=seed)
     pts, sens = touch_readings(sc, n_touches, seed=seed)
     normals = estimate_outward_normals(pts, sens)
-    gp = GPIS(length_scale=gpis_length_scale, offset=0.005, noise_var=1e-5).fit(pts, normals, max_points=1300, rng=rng)
+    gp = GPIS(length_scale=gpis_length_scale, offset=0.005, noise_var=1e-5).fit(pts, normals, max_points=gpis_max_points, rng=rng)
     gp.device = device
     frames, err, cover = [], [], []
     # zero-padded names: the split rule picks every k-th file of the SORTED name list
@@ -361,7 +362,8 @@ FLAG_SETS = {
 
 
 def train_and_eval(root: str, flags: str, with_depth: bool, iters: int = 30000, out_dir: Optional[str] = None,
-                   num_gaussians: int = 100000, extra_args: Sequence[str] = (), seed: int = 0, device="cuda") -> dict:
+                   num_gaussians: int = 100000, extra_args: Sequence[str] = (), seed: int = 0, device="cuda",
+                   split: Optional[float] = None, percent_take: Optional[float] = None) -> dict:
     """``ns-train depth-gaussian-splatting`` + ``run_eval`` of one reference flag set on a prepared capture:
     seeds for the flag set's split (create_point_cloud_from_touches), ``touch_gs_amd.train`` for ``iters`` iterations
     with or without the depth term, ``touch_gs_amd.run_eval`` under IS_REAL_WORLD (scripts/train_bunny_real.sh:54), and
@@ -371,7 +373,11 @@ def train_and_eval(root: str, flags: str, with_depth: bool, iters: int = 30000, 
     from . import prepare as PR, train
     from .run_eval import eval_run
     from .dataset import Scene
-    fs = FLAG_SETS[flags]
+    fs = dict(FLAG_SETS[flags])
+    if split is not None:          # (reduced-size runs: fewer views, so the few-view split is a larger fraction)
+        fs["split"] = split
+    if percent_take is not None:
+        fs["percent_take"] = percent_take
     PR.create_point_cloud_from_touches(root, "imgs", "touch_depth", "touch_var", "transforms.json", fs["split"],
                                        percent_take=fs["percent_take"], seed=seed)
     out_dir = out_dir or os.path.join(root, "outputs")
@@ -402,8 +408,29 @@ def train_and_eval(root: str, flags: str, with_depth: bool, iters: int = 30000, 
         if k.endswith("depth_mse"):           # scaled-frame units^2 -> metres^2
             res[k + "_m2"] = res[k] / (scale * scale)
     res.update(train_wall_s=round(wall, 2), iters=iters, iters_per_s_wall=round(iters / wall, 1), flags=flags,
-               with_depth=bool(with_depth), run_dir=run_dir)
+               with_depth=bool(with_depth), run_dir=run_dir, split=fs["split"])
     return res
+
+
+def quick_quality(root: str, n_views: int = 24, W: int = 640, iters: int = 4000, few_view_split: float = 0.25,
+                  device="cuda", runs: Sequence[str] = ("block:1", "bunny_real:1", "bunny_real:0")) -> dict:
+    """The end-to-end pipeline at reduced size (``n_views`` views at ``W`` x 9/16 W, ``iters`` iterations per run): raw
+    capture -> prepare -> train -> run_eval.  ``block`` keeps its 0.8 split; the few-view runs use ``few_view_split``
+    (0.08 of 24 views would be two).  What the -m gpu test asserts on and what bench.py reports as ``train_quality``."""
+    import time
+    t0 = time.perf_counter()
+    cap = write_raw_capture(root, n_views=n_views, W=W, H=W * 9 // 16, device=device, gpis_stride=2, gpis_max_points=700)
+    t1 = time.perf_counter()
+    prep = prepare_capture(root, few_view_split)
+    t2 = time.perf_counter()
+    out = dict(capture=cap, prepare=prep, capture_s=round(t1 - t0, 1), prepare_s=round(t2 - t1, 1), runs={})
+    for spec in runs:
+        flags, wd = spec.split(":")
+        out["runs"][spec] = train_and_eval(root, flags, wd == "1", iters=iters, device=device, num_gaussians=50000,
+                                           split=None if flags == "block" else few_view_split,
+                                           extra_args=["--steps-per-eval", str(iters)])
+    out["total_s"] = round(time.perf_counter() - t0, 1)
+    return out
 
 
 @torch.no_grad()
