@@ -1189,6 +1189,7 @@ def test_nerfstudio_plugin_shell_executes_against_a_stub(dev):
         mc.depth_loss_mult, mc.uncertainty_weight = 0.005, 0.01          # scripts/train_bunny_real.sh:52
         assert (mc.num_downscales, mc.resolution_schedule) == (2, 250)   # Splatfacto's defaults
         mc.num_downscales = 0                                            # (the schedule is exercised by the on-disk test below)
+        mc.random_fill = 0                                               # this test starts from exactly its seed points
         model = mc.setup(scene_box=None, num_train_data=1, seed_points=(P["means"], torch.rand(N, 3) * 255))
         groups = model.get_param_groups()
         assert set(groups) == set(plug.PARAM_GROUP_LRS)
@@ -1270,8 +1271,14 @@ def test_nerfstudio_plugin_trains_with_touch_supervision_from_disk(dev, tmp_path
         assert md["points3D_xyz"].shape == (200, 3) and md["points3D_rgb"].dtype == torch.uint8
         assert torch.allclose(md["points3D_xyz"], (seeds - centre) * sc, atol=1e-5)
         assert torch.equal(md["points3D_rgb"], torch.from_numpy(np.load(root / "points_colors.npy")).float().clamp(0, 255).to(torch.uint8))
+        assert (mc.random_fill, mc.max_seed_points) == (50000, 50000)   # defaults: touch cloud (subsampled) + random fill of the cube
+        filled = mc.setup(scene_box=None, num_train_data=5, seed_points=(md["points3D_xyz"], md["points3D_rgb"]))
+        assert filled.gaussians.num_points == 200 + 50000
+        assert torch.allclose(filled.gaussians.params["xyz"].detach().cpu()[:200], md["points3D_xyz"], atol=1e-6)
+        del filled
+        mc.random_fill = 0
         model = mc.setup(scene_box=None, num_train_data=5, seed_points=(md["points3D_xyz"], md["points3D_rgb"]))
-        assert model.gaussians.num_points == 200          # the model starts from exactly the touch points
+        assert model.gaussians.num_points == 200          # random_fill = 0: the model starts from exactly the touch points
         assert torch.allclose(model.gaussians.params["xyz"].detach().cpu(), md["points3D_xyz"], atol=1e-6)
         dc = model.gaussians.params["features_dc"].detach().cpu()[:, 0] * 0.28209479177387814 + 0.5
         assert torch.allclose(dc, md["points3D_rgb"].float() / 255.0, atol=1e-5)
@@ -1668,8 +1675,11 @@ if stats is not None: print("DPFULL " + json.dumps(stats), flush=True)
 '''
 
 
-@pytest.mark.parametrize("transport", ["rccl", "ipc"])
-@pytest.mark.parametrize("world,N,W,H,seed", [(4, 1_000_000, 1920, 1080, 1236), (8, 5_000_000, 3840, 2160, 1238)])
+# (the 8 x 5 M instance runs for the peer transport only: the collective form is covered at 4 x 1 M, and the pair
+# costs a minute of the driver's GPU-test budget -- VERDICT r4 item 8)
+@pytest.mark.parametrize("world,N,W,H,seed,transport", [(4, 1_000_000, 1920, 1080, 1236, "rccl"),
+                                                        (4, 1_000_000, 1920, 1080, 1236, "ipc"),
+                                                        (8, 5_000_000, 3840, 2160, 1238, "ipc")])
 def test_data_parallel_fullsize(dev, tmp_path, world, N, W, H, seed, transport):
     """BASELINE configs[3] (a batch of 4 views of the 1 M / 1080p scene on 4 ranks) and the data-parallel part of
     configs[4] (5 M Gaussians, SH 3, 4K, 8 ranks) at FULL size: the ranks share the one GPU of the test box over gloo

@@ -245,7 +245,11 @@ __device__ __forceinline__ float blend_step(float s, float& T, float& smax, floa
   const bool above = Tnew > T_STOP;
   if constexpr (WANT_OK == 2) okb = __builtin_amdgcn_ballot_w64(ok) & __builtin_amdgcn_ballot_w64(above);
   go = ok & above;
+#ifdef TGS_AB_LITERAL_STOP
+  smax = (ok != go) ? -3.0e38f : smax;
+#else
   smax = (ok != go) ? stopv : smax;  // stop (ok and not go; go implies ok): T' <= 1e-4, this Gaussian excluded
+#endif
   return go ? al : 0.f;
 }
 
@@ -349,10 +353,14 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
       out_depth[p] = D[k];
       final_T[p] = T[k];
       if (WANT_IDX) final_idx[p] = last[k];
+#ifndef TGS_AB_NO_STOPSTORE
       if (stop_pos) stop_pos[p] = stop_of(smax[k]);
+#endif
     }
   }
+#ifndef TGS_AB_NO_PUBLISH   // (A/B switch, tools/abn.py: what the walk statistics cost K6)
   publish_walk(tile_start, T_total, smax, end - start, lane);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -650,10 +658,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TGS_BLK_WAVE
       out_depth[p] = D[k];
       final_T[p] = T[k];
       if (WANT_IDX) final_idx[p] = last[k];
+#ifndef TGS_AB_NO_STOPSTORE
       if (stop_pos) stop_pos[p] = stop_of(smax[k]);
+#endif
     }
   }
+#ifndef TGS_AB_NO_PUBLISH   // (A/B switch, tools/abn.py: what the walk statistics cost K6)
   publish_walk(tile_start, T_total, smax, end - start, lane);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -81,14 +81,16 @@ def _resize_nearest(a, H: int, W: int):
 
 
 def load_supervision_maps(depth_path, uncertainty_path, H: int, W: int, depth_unit_scale_factor: float = 1e-3,
-                          dataparser_scale: float = 1.0, uncertainty_scaling: str = "linear"):
+                          dataparser_scale: float = 1.0, uncertainty_scaling: str = "linear",
+                          uncertainty_floor: float = 0.0):
     """One frame's tactile supervision as float32 arrays [H,W,1] (None where the frame has no file).
 
     depth       = uint16 PNG value x depth_unit_scale_factor x dataparser_scale  (0 = unsupervised),
                   the nerfstudio DepthDataset convention the in-tree dataparser feeds
                   (legacy/dataparser_tactile.py:65-66,301-312; config_tactile.py:33 wires DepthDataset);
     uncertainty = the same decoding x dataset.uncertainty_factor(uncertainty_scaling, ..) -- see
-                  touch_gs_amd/dataset.py on the (UNVERIFIED-PRIOR) choice of units; both trainers share it."""
+                  touch_gs_amd/dataset.py on the (UNVERIFIED-PRIOR) choice of units; both trainers share it.
+                  ``uncertainty_floor``: lower bound in the map's own units, applied before the scaling (dataset.py)."""
     import numpy as np
     from .dataset import uncertainty_factor
     from .plumbing import from_uint16_mm, read_png16
@@ -99,6 +101,8 @@ def load_supervision_maps(depth_path, uncertainty_path, H: int, W: int, depth_un
             out.append(None)
             continue
         a = _resize_nearest(from_uint16_mm(read_png16(path)), H, W)
+        if path is uncertainty_path and uncertainty_floor > 0:
+            a = np.maximum(a, uncertainty_floor)
         out.append((a * factor).astype(np.float32)[..., None])
     return out[0], out[1]
 
@@ -340,6 +344,7 @@ if available:  # pragma: no cover
         ``uncertainty_file_path`` in the same (split-filtered) order."""
         _target: Type = field(default_factory=lambda: TactileDataParser)
         uncertainty_scaling: str = "linear"
+        uncertainty_floor: float = 0.05    # dataset.py: bounds the touch : vision weight ratio of the depth loss at 100
 
     class TactileDataParser(Nerfstudio):
         config: TactileDataParserConfig
@@ -355,6 +360,7 @@ if available:  # pragma: no cover
             md["uncertainty_filenames"] = [r[1] for r in rows] if any(r[1] for r in rows) else None
             md.setdefault("depth_unit_scale_factor", self.config.depth_unit_scale_factor)
             md["uncertainty_scaling"] = self.config.uncertainty_scaling
+            md["uncertainty_floor"] = self.config.uncertainty_floor
             # the touch point cloud is what seeds the model (the Touch-GS scenes have no COLMAP ply for
             # load_3D_points to find): nerfstudio hands metadata["points3D_xyz"/"points3D_rgb"] to the model as
             # `seed_points`
@@ -380,6 +386,7 @@ if available:  # pragma: no cover
             self.uncertainty_filenames = md.get("uncertainty_filenames")
             self.depth_unit_scale_factor = md.get("depth_unit_scale_factor", 1e-3)
             self.uncertainty_scaling = md.get("uncertainty_scaling", "linear")
+            self.uncertainty_floor = md.get("uncertainty_floor", 0.0)
 
         def get_metadata(self, data):
             import torch
@@ -391,7 +398,7 @@ if available:  # pragma: no cover
             H, W = int(self._dataparser_outputs.cameras.height[i]), int(self._dataparser_outputs.cameras.width[i])
             d, u = load_supervision_maps(None if dpath is None else str(dpath), None if upath is None else str(upath), H, W,
                                          self.depth_unit_scale_factor, self._dataparser_outputs.dataparser_scale,
-                                         self.uncertainty_scaling)
+                                         self.uncertainty_scaling, self.uncertainty_floor)
             out = {}
             if d is not None:
                 out["depth_image"] = torch.from_numpy(d)
@@ -409,7 +416,11 @@ if available:  # pragma: no cover
         sh_degree: int = 3
         sh_degree_interval: int = 1000
         ssim_lambda: float = 0.2
-        num_random: int = 50000
+        num_random: int = 50000            # Gaussians drawn uniformly from the scene cube when there are no seed points ...
+        # ... and, WITH a touch seed cloud, the random fill added next to it: the cloud only covers the touched object,
+        # table and background have to come from somewhere (train.init_params does the same).  0 = seeds only
+        random_fill: int = 50000
+        max_seed_points: int = 50000       # a larger cloud (every touch-depth pixel of every training view) is subsampled; 0 = keep all
         num_downscales: int = 2            # Splatfacto's coarse-to-fine schedule
         resolution_schedule: int = 250
         # refinement (Splatfacto defaults)
@@ -434,6 +445,13 @@ if available:  # pragma: no cover
             seed = self.kwargs.get("seed_points")
             if seed is not None:
                 means, cols = seed[0].float(), seed[1].float() / 255.0
+                g = torch.Generator().manual_seed(0)
+                if self.config.max_seed_points > 0 and len(means) > self.config.max_seed_points:
+                    sel = torch.randperm(len(means), generator=g)[:self.config.max_seed_points]
+                    means, cols = means[sel], cols[sel]
+                if self.config.random_fill > 0:
+                    means = torch.cat([means, ((torch.rand(self.config.random_fill, 3, generator=g) - 0.5) * 2).to(means)])
+                    cols = torch.cat([cols, torch.rand(self.config.random_fill, 3, generator=g).to(cols)])
             else:
                 means = (torch.rand(self.config.num_random, 3) - 0.5) * 2
                 cols = torch.rand(self.config.num_random, 3)
@@ -446,7 +464,7 @@ if available:  # pragma: no cover
                     warmup_length=c.warmup_length, refine_every=c.refine_every, densify_grad_thresh=c.densify_grad_thresh,
                     densify_size_thresh=c.densify_size_thresh, cull_alpha_thresh=c.cull_alpha_thresh,
                     cull_scale_thresh=c.cull_scale_thresh, reset_alpha_every=c.reset_alpha_every,
-                    stop_split_at=c.stop_split_at))
+                    stop_split_at=c.stop_split_at, num_train_data=int(getattr(self, "num_train_data", 0) or 0)))
                 self.refiner.on_replace = lambda name, p: self.gauss_params.__setitem__(name, p)
 
         def get_param_groups(self):
