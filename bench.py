@@ -580,7 +580,7 @@ def main():
         for _ in range(rr):
             sp, _, gb, ts, sg, _ = ops.project_bin_sort(view.cam, p.means, p.log_scales, p.quats, p.opac_logit,
                                                         p.sh, deg, model.budget)
-            ops.rasterize_fwd(view.cam, sp, sg, ts)
+            ops.rasterize_fwd(view.cam, sp, sg, ts, want_stop=False)   # render only: no backward, no stop positions
         torch.cuda.synchronize()
         render_ms = (time.perf_counter() - r0) / rr * 1e3
         # ... and cycling through all the views of the timed loop (view 0 above is the fullest one)
@@ -588,7 +588,7 @@ def main():
         for i in range(3 * len(views)):
             v = views[i % len(views)]
             spv, _, _, tsv, sgv, _ = ops.project_bin_sort(v.cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, model.budget)
-            ops.rasterize_fwd(v.cam, spv, sgv, tsv)
+            ops.rasterize_fwd(v.cam, spv, sgv, tsv, want_stop=False)
         torch.cuda.synchronize()
         render_mean_ms = (time.perf_counter() - r0) / (3 * len(views)) * 1e3
         del spv, tsv, sgv
@@ -663,6 +663,8 @@ def main():
                                   "dense_all_reduce_bytes": int(model.params.grad.numel() * 4)}
             out["dp_exchange"]["replicas_identical"] = replicas_identical
             out["dp_exchange"]["transport"] = dp.transport
+            if dp.peer is not None:   # which kind of device memory the receive slots live in (tgs_peer_alloc never downgrades silently)
+                out["dp_exchange"]["memory_kind"] = dp.peer.memory_kind
             if comm:
                 out["dp_exchange"].update(comm)
             out["dp_exchange"]["busbw_sweep"] = busbw

@@ -25,8 +25,11 @@
 extern "C" {
 #endif
 
-#define TGS_VERSION 201         /* 0.2.1 -- 201: tile_start buffers are T+513 ints (512 scratch ints behind the starts); adds tgs_set_k7_quad, tgs_set_k6_split.  200 broke the ABI of 100: tgs_rasterize_fwd / tgs_rasterize_bwd[_band]
-                                   gained stop_pos; earlier (round 3, then unversioned): status is int32[4], the
+#define TGS_VERSION 300         /* 0.3.0 -- 300: every entry point that takes `tile_start` takes its length next to it (validated against
+                                   tgs_tile_start_len: the rasterizer keeps 512 scratch ints behind the starts) and the rasterize calls declare it
+                                   non-const (they write that scratch); tgs_rasterize_fwd / _bwd / _bwd_band take a per-call TgsRasterOpts.
+                                   201: tile_start buffers are T+513 ints; adds tgs_set_k7_quad, tgs_set_k6_split.  200 broke the ABI of 100:
+                                   tgs_rasterize_fwd / tgs_rasterize_bwd[_band] gained stop_pos; earlier (round 3, then unversioned): status is int32[4], the
                                    rasterize calls carry slot_ok, splat slots 0/1 are rect-relative */
 #define TGS_BLOCK 16            /* tile edge in pixels */
 #define TGS_SPLAT_FLOATS 12     /* floats per projected-splat record */
@@ -92,6 +95,9 @@ int tgs_num_bands(int W, int H);           /* image bands of tgs_rasterize_bwd_b
 int tgs_band_tiles(int W, int H, int band, int* tile0, int* tile1);   /* row-major tile range of a band */
 int tgs_tile_order_len(int W, int H);      /* 8 * 8 * ceil(ceil(tiles / 8) / 8) (one entry per K6/K7 block) */
 int tgs_tile_counter_len(int W, int H);    /* int32 entries of the tile_cursor scratch: per-XCD counter rows + sub-list starts */
+int64_t tgs_tile_start_len(int W, int H);  /* int32 entries of a tile_start buffer: tiles + 1 + the rasterizer's 512 scratch ints.  Every call that
+                                              takes `tile_start` takes `tile_start_len` = the entries the caller allocated and fails with TGS_E_ARG
+                                              if that is less (the kernels write the scratch: a T + 1 allocation would be written out of bounds) */
 /* Bytes of scratch tgs_bin_sort needs for a given intersection capacity. */
 size_t tgs_sort_scratch_bytes(int64_t capacity);
 
@@ -126,7 +132,7 @@ int tgs_sh_bwd(int N, int sh_deg, int sh_stride, const float* dirs, const float*
  * in : splats[N,12] (slot 11 is overwritten with the in-group intersection offset)
  * out: group_base[G]    start of each 256-Gaussian group's contiguous range in the pair index
  *                       space (G = tgs_num_groups; ranges are disjoint, their order is arbitrary)
- *      tile_start[T+513] [start,end) of every tile's list; tile_start[T] = #intersections; the 512 ints behind it are
+ *      tile_start[tgs_tile_start_len] [start,end) of every tile's list; tile_start[T] = #intersections; the 512 ints behind it are
  *                       scratch of the rasterizer: a pair of words per XCD, 256 B apart, that tgs_rasterize_fwd folds the
  *                       frame's deepest walk and the sum of its walks into (zeroed here) and tgs_rasterize_bwd reads --
  *                       tgs_set_k7_quad -- and, 128 B behind each pair, a slot counter of tgs_rasterize_bwd.  Since TGS_VERSION 201 the buffer is T+513 ints
@@ -153,7 +159,7 @@ int tgs_sh_bwd(int N, int sh_deg, int sh_stride, const float* dirs, const float*
  *                       until the caller has cleared the word, grown the buffers and replayed.
  * tmp: tile_cursor[tgs_tile_counter_len(W,H)], scratch (tgs_sort_scratch_bytes(capacity)). */
 int tgs_bin_sort(const TgsCamera* cam /*[host]*/, int N, float* splats, int32_t* group_base,
-                 int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
+                 int32_t* tile_start, int64_t tile_start_len, int32_t* tile_cursor, int32_t* sorted_gid,
                  int32_t* tile_order, int64_t capacity, void* scratch, int32_t* status,
                  int32_t* sticky_overflow, void* stream);
 
@@ -164,7 +170,7 @@ int tgs_bin_sort(const TgsCamera* cam /*[host]*/, int N, float* splats, int32_t*
 int tgs_project_bin_sort(const TgsCamera* cam /*[host]*/, int N, const float* means,
                          const float* log_scales, const float* quats, const float* opac_logit,
                          const float* sh, int sh_stride, int sh_deg, float* splats, int32_t* radii,
-                         int32_t* group_base, int32_t* tile_start, int32_t* tile_cursor,
+                         int32_t* group_base, int32_t* tile_start, int64_t tile_start_len, int32_t* tile_cursor,
                          int32_t* sorted_gid, int32_t* tile_order, int64_t capacity, void* scratch,
                          int32_t* status, int32_t* sticky_overflow, void* stream);
 
@@ -182,11 +188,23 @@ int tgs_project_bin_sort(const TgsCamera* cam /*[host]*/, int N, const float* me
 int tgs_project_bin_sort_colors(const TgsCamera* cam /*[host]*/, int N, const float* means,
                                 const float* log_scales, const float* quats, const float* opac_logit,
                                 const float* sh, int sh_stride, int sh_deg, float* splats,
-                                int32_t* radii, int32_t* group_base, int32_t* tile_start,
+                                int32_t* radii, int32_t* group_base, int32_t* tile_start, int64_t tile_start_len,
                                 int32_t* tile_cursor, int32_t* sorted_gid, int32_t* tile_order,
                                 int64_t capacity, void* scratch, int32_t* status,
                                 int32_t* sticky_overflow, const float* colors_in,
                                 const int32_t* color_tag, int32_t tag_expect, void* stream);
+
+/* Per-call choice of the compositing kernels' forms (tgs_rasterize_fwd / _bwd / _bwd_band; NULL = every field -1).
+ * A field < 0 takes the process-wide default: the value of the matching tgs_set_* call, else of the environment
+ * variable (read once), else the built-in one.  A caller that needs re-entrancy passes the struct and never touches
+ * the setters; the setters exist for A/B runs and tests and are process-wide by definition. */
+typedef struct TgsRasterOpts {
+  int32_t k6_blocks;         /* 1 / 0: forward in 4x4-block / quadrant form (bit-identical images)      [TGS_K6_BLOCKS, 1] */
+  int32_t k6_split;          /* tile_is_split factor of the forward, 0 = never (tgs_set_k6_split)        [TGS_K6_SPLIT, 4]  */
+  int32_t k7_front_to_back;  /* 1: backward in the front-to-back form of TGS_VERSION 100                 [TGS_K7_F2B, 0]    */
+  int32_t k7_quad;           /* chain-bound factor of the backward, 0 = one wave per tile (tgs_set_k7_quad) [TGS_K7_QUAD, 8] */
+  int32_t k7_quad_min_walk;  /* walks up to this many entries stay with the one-wave kernel              [TGS_K7_QUAD_MIN, 48] */
+} TgsRasterOpts;
 
 /* K6  per-tile front-to-back compositing of RGB + depth in ONE pass  (stands behind gsplat
  *     `rasterize_gaussians` fwd, called twice by Splatfacto for rgb and depth; spec App. B.6).
@@ -196,10 +214,13 @@ int tgs_project_bin_sort_colors(const TgsCamera* cam /*[host]*/, int N, const fl
  * in : tile_order (may be NULL = spatial order) as produced by tgs_bin_sort: scheduling only, the
  *      results do not depend on it */
 int tgs_rasterize_fwd(const TgsCamera* cam /*[host]*/, const float* splats,
-                      const int32_t* sorted_gid, const int32_t* tile_start,
+                      const int32_t* sorted_gid, int32_t* tile_start, int64_t tile_start_len,
                       const int32_t* tile_order, float* out_rgb, float* out_depth, float* final_T,
                       int32_t* final_idx /*may be NULL*/, int32_t* stop_pos /*may be NULL*/,
-                      uint64_t* slot_ok /*may be NULL*/, void* stream);
+                      uint64_t* slot_ok /*may be NULL*/, const TgsRasterOpts* opts /*[host], may be NULL*/,
+                      void* stream);
+/* tile_start is NOT const: the forward folds the frame's walk statistics into the scratch ints behind the starts and
+ * the backward keeps a slot counter there (tgs_tile_start_len).  The starts themselves are only read. */
 /* stop_pos[H,W] (optional; REQUIRED by tgs_rasterize_bwd*): per pixel the list position (relative to the
  * tile's first entry) of the Gaussian whose T' <= 1e-4 stopped the pixel (App. B.6) -- every earlier position
  * with alpha >= 1/255 contributed, nothing else did -- or 0x7fffffff if the pixel never stopped.  The
@@ -213,7 +234,9 @@ size_t tgs_slot_ok_len(int W, int H, int64_t capacity);
 /* Developer switch (A/B runs, tests): k6_blocks_on 1 / 0 = K6 in 4x4-block / quadrant form,
  * k7_front_to_back 1 / 0 = K7 in the front-to-back form of TGS_VERSION 100 / back to front; -1 leaves a
  * setting as it is.  Defaults: environment TGS_K6_BLOCKS (1), TGS_K7_F2B (0), read once at first use.
- * Returns the settings in force: bit 0 = block-form K6, bit 1 = front-to-back K7. */
+ * Returns the settings in force: bit 0 = block-form K6, bit 1 = front-to-back K7.
+ * PROCESS-WIDE (atomic words; they only set the defaults a NULL / -1 TgsRasterOpts falls back to): a caller that
+ * runs several models in one process passes TgsRasterOpts per call instead.  Same for the two setters below. */
 int tgs_set_raster_variant(int k6_blocks_on, int k7_front_to_back);
 
 /* In a CHAIN-BOUND frame K7 gives every tile that walks more than min_walk list entries to a workgroup of FOUR waves
@@ -246,11 +269,12 @@ int tgs_set_k6_split(int factor);
  *      tile_loss[T,2] (may be NULL) per-tile {sum|C-gt|*l1_weight, depth-term} of the fused loss */
 int tgs_rasterize_bwd(const TgsCamera* cam /*[host]*/, const float* splats,
                       const int32_t* group_base, const int32_t* sorted_gid,
-                      const int32_t* tile_start, const int32_t* tile_order /*may be NULL*/,
+                      int32_t* tile_start, int64_t tile_start_len, const int32_t* tile_order /*may be NULL*/,
                       const float* out_rgb, const float* out_depth, const float* final_T,
                       const int32_t* stop_pos, const float* v_rgb, const float* v_depth, const float* v_alpha,
                       const TgsLossSpec* loss /*[host]*/, float* partials, float* tile_loss,
-                      const uint64_t* slot_ok /*may be NULL*/, void* stream);
+                      const uint64_t* slot_ok /*may be NULL*/, const TgsRasterOpts* opts /*[host], may be NULL*/,
+                      void* stream);
 
 /* K7 for ONE image band: the tiles [tile0, tile1) of tgs_band_tiles(W, H, band, ...) (a contiguous row-major
  *     range; tgs_num_bands(W, H) >= 4 bands cover the image).  Needs the tile_order of tgs_bin_sort.  The
@@ -259,11 +283,12 @@ int tgs_rasterize_bwd(const TgsCamera* cam /*[host]*/, const float* splats,
  *     while earlier bands composite (DepthGaussianSplattingModel: SSIM pipelined behind K7). */
 int tgs_rasterize_bwd_band(const TgsCamera* cam /*[host]*/, const float* splats,
                       const int32_t* group_base, const int32_t* sorted_gid,
-                      const int32_t* tile_start, const int32_t* tile_order /*may be NULL*/,
+                      int32_t* tile_start, int64_t tile_start_len, const int32_t* tile_order /*may be NULL*/,
                       const float* out_rgb, const float* out_depth, const float* final_T,
                       const int32_t* stop_pos, const float* v_rgb, const float* v_depth, const float* v_alpha,
                       const TgsLossSpec* loss /*[host]*/, float* partials, float* tile_loss,
-                      int band, const uint64_t* slot_ok /*may be NULL*/, void* stream);
+                      int band, const uint64_t* slot_ok /*may be NULL*/,
+                      const TgsRasterOpts* opts /*[host], may be NULL*/, void* stream);
 
 /* K8a segmented reduction of the partials to one gradient record per Gaussian
  *     out: v_splats[N,12] = {v_x, v_y, v_depth, v_opacity, v_a, v_b, v_c, v_r, v_g, v_b, 0, 0}. */
@@ -346,7 +371,7 @@ int tgs_adam_geom_project_next(const TgsCamera* next_cam /*[host]*/, int N, int 
 int tgs_project_bin_sort_front(const TgsCamera* cam /*[host]*/, int N, const float* means,
                                const float* log_scales, const float* quats, const float* opac_logit,
                                const float* sh, int sh_stride, int sh_deg, float* splats, int32_t* radii,
-                               int32_t* group_base, int32_t* tile_start, int32_t* tile_cursor,
+                               int32_t* group_base, int32_t* tile_start, int64_t tile_start_len, int32_t* tile_cursor,
                                int32_t* sorted_gid, int32_t* tile_order, int64_t capacity, void* scratch,
                                int32_t* status, int32_t* sticky_overflow, const int32_t* tag_word,
                                int32_t tag_expect,
@@ -439,18 +464,28 @@ int tgs_ssim_fwd_bwd_rows(int W, int H, const float* img, const float* gt, float
  * Peer exchange: the data-parallel gradient exchange by direct stores into IPC-mapped peer memory (all 7 xGMI
  * links of a rank at once, no collective launch) -- the alternative to RCCL that touch_gs_amd.parallel selects
  * with TGS_DP_TRANSPORT=ipc (csrc/peer.hip).  The reference has no counterpart (single GPU).
- * tgs_peer_alloc: `bytes` of zeroed, uncached device memory + its 64-byte IPC handle (send it to the other
- *     processes by any means); tgs_peer_open maps another process's buffer; _close / _free undo them.
+ * tgs_peer_alloc: `bytes` of zeroed device memory of the first kind in `allow_kinds` (a mask of TGS_PEER_MEM_*, tried
+ *     in the order uncached, fine-grained, plain) the driver grants + its 64-byte IPC handle (send it to the other
+ *     processes by any means); *kind_out (may be NULL) = the kind obtained; TGS_E_HIP if none of the allowed kinds
+ *     could be had -- there is no silent downgrade.  The transport's ordering argument (csrc/peer.hip) holds for
+ *     uncached and fine-grained memory only: touch_gs_amd.parallel.PeerExchange asks for exactly those.
+ *     tgs_peer_open maps another process's buffer; _close / _free undo them.
  * Flags are int32 words inside such buffers; `seq` must grow from call to call (compared as seq - flag <= 0);
  * `ticket` = a zeroed device int32 private to each (call site, stream).
  * tgs_peer_push:        src[0, bytes) -> dsts[i][0, bytes) for i < n_dst, then flags[i] = seq (release, system scope)
  * tgs_peer_scatter:     src[q * slice_bytes, ...) -> dsts[q][0, ...) for q < n_dst, then flags
  * tgs_peer_reduce_push: sum over r < world of srcs[r] in rank order -> every dsts[i], then flags
  * tgs_peer_wait:        the stream waits until all n flags (local memory) have reached seq; after timeout_s
- *     seconds (<= 0: 20 s) it gives up and sets *err = 1 + index of the missing flag (check it at a sync point).
+ *     seconds (<= 0: 20 s) it gives up, sets *err = 1 + index of the missing flag and, if given, *poison_a = *poison_b = 1
+ *     (device int32 words, may be NULL): hand it the sticky overflow word and word [1] of the verdict the optimizer
+ *     kernels are guarded by (tgs_dp_agree_overflow ORs the sticky word in) and nothing behind a timed-out wait
+ *     touches the model; the host reads *err with its per-step status copy.
  * All pointer arrays are HOST arrays of device pointers; at most 8 receivers; sizes and pointers are multiples of
  * 16 bytes (tgs_peer_push also takes multiples of 4 bytes, on a slower scalar path). */
-int tgs_peer_alloc(size_t bytes, void** dptr, unsigned char* handle64);
+#define TGS_PEER_MEM_UNCACHED 1     /* hipDeviceMallocUncached: peers' stores land in HBM behind the owner's L2 */
+#define TGS_PEER_MEM_FINEGRAINED 2  /* hipDeviceMallocFinegrained: coherent at system scope */
+#define TGS_PEER_MEM_PLAIN 4        /* hipMalloc: cached; the owner may read stale lines -- not used by PeerExchange */
+int tgs_peer_alloc(size_t bytes, int allow_kinds, void** dptr, unsigned char* handle64, int* kind_out /*may be NULL*/);
 int tgs_peer_open(const unsigned char* handle64, void** dptr);
 int tgs_peer_close(void* dptr);
 int tgs_peer_free(void* dptr);
@@ -463,7 +498,8 @@ int tgs_peer_reduce_push(int world, const void* const* srcs, int n_dst, void* co
  /* tgs_peer_signal: flags[i] = seq (release, system scope) as a launch of its own -- the conservative way to publish
  *     after a push / scatter / reduce_push that was given flags = NULL (the kernel boundary orders the data). */
 int tgs_peer_signal(int n, int32_t* const* flags, int32_t seq, void* stream);
-int tgs_peer_wait(int n, const int32_t* const* flags, int32_t seq, int32_t* err, float timeout_s, void* stream);
+int tgs_peer_wait(int n, const int32_t* const* flags, int32_t seq, int32_t* err, float timeout_s,
+                  int32_t* poison_a /*may be NULL*/, int32_t* poison_b /*may be NULL*/, void* stream);
 
 #ifdef __cplusplus
 }

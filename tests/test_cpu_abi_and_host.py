@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"{s} declared in include/tgs.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in touch_gs_amd/_lib.py"
     assert set(_lib.SIGNATURES) == set(syms)
-    assert lib.tgs_version() == 201
+    assert lib.tgs_version() == 300
 
 
 def _declared_prototypes():
@@ -38,7 +38,7 @@ def _declared_prototypes():
     txt = open(os.path.join(ROOT, "include", "tgs.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\b(?:int|size_t|const char\s*\*|void)\s+(tgs_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
+    for m in re.finditer(r"\b(?:int64_t|int|size_t|const char\s*\*|void)\s+(tgs_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
         name, args = m.group(1), " ".join(m.group(2).split())
         kinds = []
         if args not in ("", "void"):
@@ -85,6 +85,11 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.TgsCamera) == 16 * 4 + 4 * 4 + 2 * 4 + 2 * 4 + 3 * 4 + 4
     assert C.sizeof(_lib.TgsAdamSpec) == 11 * 4 + 4 + 8   # 11 floats, pad, device pointer
     assert C.sizeof(_lib.TgsLossSpec) == 3 * 8 + 4 * 4
+    assert C.sizeof(_lib.TgsRasterOpts) == 5 * 4
+    # field order of the header (a per-call option read from the wrong slot would silently select another kernel form)
+    txt = open(os.path.join(ROOT, "include", "tgs.h")).read()
+    body = re.search(r"typedef struct TgsRasterOpts \{(.*?)\} TgsRasterOpts;", txt, flags=re.S).group(1)
+    assert re.findall(r"int32_t\s+(\w+);", body) == [f[0] for f in _lib.TgsRasterOpts._fields_]
 
 
 def test_argument_validation_without_gpu():
@@ -486,9 +491,61 @@ def test_xcd_schedule_sizes_and_bands_host():
         assert lib.tgs_band_tiles(W, H, nb, C.byref(t0), C.byref(t1)) != 0
 
 
+def test_c_abi_refuses_a_short_tile_start_buffer():
+    """TGS_VERSION 300: every entry point that takes tile_start takes the length the caller allocated and fails with
+    TGS_E_ARG -- before any launch, so this runs without a GPU -- when it is shorter than tgs_tile_start_len(W, H): a
+    C caller that still allocates T + 1 ints (ABI <= 200) gets an error instead of out-of-bounds device writes."""
+    from touch_gs_amd import _lib
+    lib = _lib.load()
+    W, H = 320, 208
+    T = lib.tgs_num_tiles(W, H)
+    need = lib.tgs_tile_start_len(W, H)
+    assert need == T + 1 + 512
+    cam = _lib.TgsCamera()
+    cam.W, cam.H, cam.fx, cam.fy, cam.cx, cam.cy = W, H, 300.0, 300.0, W / 2, H / 2
+    for i in (0, 5, 10, 15):
+        cam.viewmat[i] = 1.0
+    fake = C.c_void_p(0x1000)      # never dereferenced: the length check precedes every launch
+    for short in (T + 1, need - 1):
+        rc = lib.tgs_rasterize_fwd(C.byref(cam), fake, fake, fake, short, None, fake, fake, fake, None, None, None, None, None)
+        assert rc == -1 and b"tgs_tile_start_len" in lib.tgs_last_error(), lib.tgs_last_error()
+        rc = lib.tgs_rasterize_bwd(C.byref(cam), fake, fake, fake, fake, short, None, fake, fake, fake, fake, None, None, None,
+                                   None, fake, None, None, None, None)
+        assert rc == -1 and b"tgs_tile_start_len" in lib.tgs_last_error(), lib.tgs_last_error()
+        rc = lib.tgs_bin_sort(C.byref(cam), 0, None, fake, fake, short, fake, fake, None, 1024, fake, fake, None, None)
+        assert rc == -1 and b"tgs_tile_start_len" in lib.tgs_last_error(), lib.tgs_last_error()
+        rc = lib.tgs_project_bin_sort(C.byref(cam), 0, None, None, None, None, None, 0, -1, None, None, fake, fake, short, fake,
+                                      fake, None, 1024, fake, fake, None, None)
+        assert rc == -1 and b"tgs_tile_start_len" in lib.tgs_last_error(), lib.tgs_last_error()
+        rc = lib.tgs_project_bin_sort_front(C.byref(cam), 256, fake, fake, fake, fake, fake, 16, 3, fake, None, fake, fake, short,
+                                            fake, fake, None, 1024, fake, fake, None, fake, 0, None, None, None, None)
+        assert rc == -1 and b"tgs_tile_start_len" in lib.tgs_last_error(), lib.tgs_last_error()
+
+
+def test_raster_defaults_are_process_wide_and_opts_override_them():
+    """The tgs_set_* calls only move the process-wide DEFAULTS (atomic words); they round-trip, and a TgsRasterOpts with
+    every field -1 is what NULL means."""
+    from touch_gs_amd import _lib, ops
+    lib = _lib.load()
+    before = lib.tgs_set_raster_variant(-1, -1), lib.tgs_set_k6_split(-1), lib.tgs_set_k7_quad(-1, -1)
+    try:
+        assert lib.tgs_set_raster_variant(0, 1) == 2 and lib.tgs_set_raster_variant(-1, -1) == 2
+        assert lib.tgs_set_raster_variant(1, 0) == 1
+        assert lib.tgs_set_k6_split(7) == 7 and lib.tgs_set_k6_split(-1) == 7
+        assert lib.tgs_set_k7_quad(3, 100) == (3 | 100 << 8) and ops.set_k7_quad() == (3, 100)
+    finally:
+        lib.tgs_set_raster_variant(before[0] & 1, (before[0] >> 1) & 1)
+        lib.tgs_set_k6_split(before[1])
+        lib.tgs_set_k7_quad(before[2] & 255, before[2] >> 8)
+    o = ops.raster_opts()
+    assert [getattr(o, f[0]) for f in o._fields_] == [-1] * 5
+    o = ops.raster_opts(k6_blocks=False, k7_quad=0)
+    assert (o.k6_blocks, o.k6_split, o.k7_front_to_back, o.k7_quad, o.k7_quad_min_walk) == (0, -1, -1, 0, -1)
+
+
 def test_tile_start_copies_are_refused():
-    """TGS_VERSION 201: the rasterizer owns 512 scratch ints behind the tile starts; the Python ops refuse a tensor that
-    has lost them (a clone of the T + 1 view) before any kernel could write out of bounds."""
+    """The rasterizer owns 512 scratch ints behind the tile starts; the Python ops refuse a tensor that
+    has lost them (a clone of the T + 1 view) with the reason, before the C ABI's own length check would."""
     from touch_gs_amd import ops
     T = 40
     buf = torch.zeros(T + 1 + 512, dtype=torch.int32)

@@ -28,6 +28,12 @@ class TgsLossSpec(C.Structure):
                 ("uncertainty_weight", C.c_float), ("eps", C.c_float)]
 
 
+class TgsRasterOpts(C.Structure):
+    """Per-call choice of the compositing kernels' forms (tgs.h); -1 = the process-wide default."""
+    _fields_ = [("k6_blocks", C.c_int32), ("k6_split", C.c_int32), ("k7_front_to_back", C.c_int32),
+                ("k7_quad", C.c_int32), ("k7_quad_min_walk", C.c_int32)]
+
+
 class TgsAdamSpec(C.Structure):
     _fields_ = [("lr_means", C.c_float), ("lr_scales", C.c_float), ("lr_quats", C.c_float),
                 ("lr_opac", C.c_float), ("lr_sh_dc", C.c_float), ("lr_sh_rest", C.c_float),
@@ -47,22 +53,23 @@ SIGNATURES = {
     "tgs_num_bands": (C.c_int, [_I, _I]),
     "tgs_band_tiles": (C.c_int, [_I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tgs_tile_counter_len": (C.c_int, [_I, _I]),
+    "tgs_tile_start_len": (C.c_int64, [_I, _I]),
     "tgs_sort_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "tgs_project_fwd": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "tgs_sh_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P]),
     "tgs_sh_bwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P]),
-    "tgs_bin_sort": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _P]),
-    "tgs_project_bin_sort": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P,
+    "tgs_bin_sort": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, C.c_int64, _P, _P, _P, C.c_int64, _P, _P, _P, _P]),
+    "tgs_project_bin_sort": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, C.c_int64, _P, _P,
                                        _P, C.c_int64, _P, _P, _P, _P]),
-    "tgs_project_bin_sort_colors": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P,
+    "tgs_project_bin_sort_colors": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, C.c_int64, _P,
                                               _P, _P, C.c_int64, _P, _P, _P, _P, _P, C.c_int32, _P]),
-    "tgs_rasterize_fwd": (C.c_int, [C.POINTER(TgsCamera), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "tgs_rasterize_fwd": (C.c_int, [C.POINTER(TgsCamera), _P, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, C.POINTER(TgsRasterOpts), _P]),
     "tgs_set_raster_variant": (C.c_int, [_I, _I]),
     "tgs_set_k7_quad": (C.c_int, [_I, _I]),
     "tgs_set_k6_split": (C.c_int, [_I]),
     "tgs_slot_ok_len": (C.c_size_t, [_I, _I, C.c_int64]),
-    "tgs_rasterize_bwd": (C.c_int, [C.POINTER(TgsCamera)] + [_P] * 12 + [C.POINTER(TgsLossSpec), _P, _P, _P, _P]),
-    "tgs_rasterize_bwd_band": (C.c_int, [C.POINTER(TgsCamera)] + [_P] * 12 + [C.POINTER(TgsLossSpec), _P, _P, _I, _P, _P]),
+    "tgs_rasterize_bwd": (C.c_int, [C.POINTER(TgsCamera)] + [_P] * 4 + [C.c_int64] + [_P] * 8 + [C.POINTER(TgsLossSpec), _P, _P, _P, C.POINTER(TgsRasterOpts), _P]),
+    "tgs_rasterize_bwd_band": (C.c_int, [C.POINTER(TgsCamera)] + [_P] * 4 + [C.c_int64] + [_P] * 8 + [C.POINTER(TgsLossSpec), _P, _P, _I, _P, C.POINTER(TgsRasterOpts), _P]),
     "tgs_reduce_partials": (C.c_int, [_I, _P, _P, C.POINTER(TgsCamera), _P, _P, _P]),
     "tgs_project_bwd": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I] + [_P] * 12),
     "tgs_project_bwd_adam": (C.c_int, [C.POINTER(TgsCamera), _I, _I, _I, _P, _P, _P, C.POINTER(TgsAdamSpec), _P, _P, _P, _P, _P, _P]),
@@ -73,7 +80,7 @@ SIGNATURES = {
                                                   _P, _P, _P, _I, _P]),
     "tgs_adam_geom_project_next": (C.c_int, [C.POINTER(TgsCamera), _I, _I, _I, _P, _P, _P, _P, C.POINTER(TgsAdamSpec), C.c_float,
                                              _P, _P, C.c_int32, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _I, _P]),
-    "tgs_project_bin_sort_front": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P,
+    "tgs_project_bin_sort_front": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, C.c_int64, _P,
                                              _P, _P, C.c_int64, _P, _P, _P, _P, C.c_int32, C.POINTER(TgsCamera), _P, _P, _P]),
     "tgs_front_can_clear_next": (C.c_int, [_I, _I, _I]),
     "tgs_project_bwd_color": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I] + [_P] * 11),
@@ -85,7 +92,7 @@ SIGNATURES = {
     "tgs_adam_step": (C.c_int, [_I, _I, _P, _P, _P, _P, C.POINTER(TgsAdamSpec), C.c_float, C.c_int64, C.c_int64, _P, _P]),
     "tgs_ssim_fwd_bwd": (C.c_int, [_I, _I, _P, _P, C.c_float, _P, _P, _P, _P]),
     "tgs_ssim_fwd_bwd_rows": (C.c_int, [_I, _I, _P, _P, C.c_float, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
-    "tgs_peer_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_ubyte)]),
+    "tgs_peer_alloc": (C.c_int, [C.c_size_t, _I, C.POINTER(C.c_void_p), C.POINTER(C.c_ubyte), C.POINTER(C.c_int)]),
     "tgs_peer_open": (C.c_int, [C.POINTER(C.c_ubyte), C.POINTER(C.c_void_p)]),
     "tgs_peer_close": (C.c_int, [_P]),
     "tgs_peer_free": (C.c_int, [_P]),
@@ -94,7 +101,7 @@ SIGNATURES = {
     "tgs_peer_reduce_push": (C.c_int, [_I, C.POINTER(C.c_void_p), _I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t,
                                        C.c_int32, _P, _P]),
     "tgs_peer_signal": (C.c_int, [_I, C.POINTER(C.c_void_p), C.c_int32, _P]),
-    "tgs_peer_wait": (C.c_int, [_I, C.POINTER(C.c_void_p), C.c_int32, _P, C.c_float, _P]),
+    "tgs_peer_wait": (C.c_int, [_I, C.POINTER(C.c_void_p), C.c_int32, _P, C.c_float, _P, _P, _P]),
 }
 
 _lib = None

@@ -165,10 +165,10 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int T, int NB, int32_t* __r
   if (b == NB - 1 && tid == 0) tile_start[T] = s_base + tot;
   // 16 of the 512 scratch ints behind the tile starts collect the frame's deepest walk and the sum of its walks (K6,
   // raster.hip publish_walk: a pair of words per XCD, 256 B apart) for K7
-  if (b == NB - 1 && tid >= 1 && tid <= 16) tile_start[T + 1 + 64 * ((tid - 1) >> 1) + ((tid - 1) & 1)] = 0;
+  if (b == NB - 1 && tid >= 1 && tid <= 16) tile_start[((tid - 1) & 1) ? TGS_WALKSUM_AT(T, (tid - 1) >> 1) : TGS_WALK_AT(T, (tid - 1) >> 1)] = 0;
   // ... and the 8 slot counters of K7's four-wave launch (TGS_SLOTCTR_AT): k_raster_bwd clears them again before every
   // backward, but a buffer that comes out of torch.empty must not depend on that launch having reached the store
-  if (b == NB - 1 && tid >= 17 && tid <= 24) tile_start[T + 1 + 64 * (tid - 17) + 32] = 0;
+  if (b == NB - 1 && tid >= 17 && tid <= 24) tile_start[TGS_SLOTCTR_AT(T, tid - 17)] = 0;
 }
 
 // K3b: scatter (gid, depth bits) into the tile bins.  slot = tile_start + arrival rank.
@@ -478,6 +478,8 @@ extern "C" int tgs_band_tiles(int W, int H, int band, int* tile0, int* tile1) {
   return TGS_OK;
 }
 extern "C" int tgs_tile_counter_len(int W, int H) { return tgs_counter_len(tgs_num_tiles(W, H)); }
+// tile starts [T + 1] + the rasterizer's scratch (walk words, slot counters: raster.hip); k_scan_tiles zeroes them
+extern "C" int64_t tgs_tile_start_len(int W, int H) { return (int64_t)tgs_num_tiles(W, H) + 1 + TGS_TILE_START_SCRATCH; }
 // scratch layout: pairs u64[cap] | fallback u64[2*cap] | rank i32[cap]
 extern "C" size_t tgs_sort_scratch_bytes(int64_t capacity) {
   if (capacity < 0) capacity = 0;
@@ -485,10 +487,12 @@ extern "C" size_t tgs_sort_scratch_bytes(int64_t capacity) {
 }
 
 int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* group_base,
-                   int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
+                   int32_t* tile_start, int64_t tile_start_len, int32_t* tile_cursor, int32_t* sorted_gid,
                    int32_t* tile_order, int64_t capacity, void* scratch, int32_t* status,
                    hipStream_t s) {
   const int T = k.TW * k.TH;
+  TGS_CHECK_ARG(tile_start_len >= (int64_t)T + 1 + TGS_TILE_START_SCRATCH,
+                "tile_start buffer shorter than tgs_tile_start_len(W, H) (the scan zeroes the rasterizer's scratch behind the starts)");
   const int G = tgs_num_groups(N);
   const BinScratch sc = carve_scratch(scratch, capacity);
   const int NB = (T + 1023) / 1024;   // <= 64 (image sides are limited to 255 tiles)
@@ -522,7 +526,7 @@ int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* gro
 }
 
 extern "C" int tgs_bin_sort(const TgsCamera* cam, int N, float* splats, int32_t* group_base,
-                            int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
+                            int32_t* tile_start, int64_t tile_start_len, int32_t* tile_cursor, int32_t* sorted_gid,
                             int32_t* tile_order, int64_t capacity, void* scratch, int32_t* status,
                             int32_t* sticky_overflow, void* stream) {
   TGS_CHECK_ARG(camera_ok(cam), "bad camera");
@@ -533,6 +537,7 @@ extern "C" int tgs_bin_sort(const TgsCamera* cam, int N, float* splats, int32_t*
   TGS_CHECK_ARG(N == 0 || splats, "null splats");
   const CamK k = make_camk(cam);
   const int T = k.TW * k.TH;
+  TGS_CHECK_ARG(tile_start_len >= (int64_t)T + 1 + TGS_TILE_START_SCRATCH, "tile_start buffer shorter than tgs_tile_start_len(W, H)");
   const int G = tgs_num_groups(N);
   hipStream_t s = (hipStream_t)stream;
   const BinScratch sc = carve_scratch(scratch, capacity);
@@ -544,6 +549,6 @@ extern "C" int tgs_bin_sort(const TgsCamera* cam, int N, float* splats, int32_t*
                        tile_cursor, sc.rank, status, (long long)capacity, sticky_overflow);
     TGS_CHECK_LAUNCH();
   }
-  return tgs_bin_finish(k, N, splats, group_base, tile_start, tile_cursor, sorted_gid, tile_order,
+  return tgs_bin_finish(k, N, splats, group_base, tile_start, tile_start_len, tile_cursor, sorted_gid, tile_order,
                         capacity, scratch, status, s);
 }

@@ -262,7 +262,10 @@ static int ssim_impl(int W, int H, const float* img, const float* gt, float weig
   const int sx = (W + SW - 1) / SW;
   int nblk = 4;
   while (nblk > 2 && (long long)sx * ((rows + seg_rows(nblk) - 1) / seg_rows(nblk)) < 3 * 256) nblk--;
-  if (const char* e = getenv("TGS_SSIM_NBLK")) nblk = max(2, min(16, atoi(e)));   // tuning override
+  {   // tuning override, read from the environment ONCE (function-local static: thread-safe initialisation)
+    static const int env_nblk = [] { const char* e = getenv("TGS_SSIM_NBLK"); return e ? max(2, min(16, atoi(e))) : 0; }();
+    if (env_nblk) nblk = env_nblk;
+  }
   // one workgroup sum goes into each of the first entries of block_partials, the rest is zeroed
   while (nblk < 16 && (long long)sx * ((rows + seg_rows(nblk) - 1) / seg_rows(nblk)) > n_partials) nblk++;
   TGS_CHECK_ARG((long long)sx * ((rows + seg_rows(nblk) - 1) / seg_rows(nblk)) <= n_partials, "block_partials too small");

@@ -130,7 +130,12 @@ struct PeerFlags { const int32_t* flag[2 * PEER_MAX]; };
 
 // One wave: lane i polls flag i (system-scope acquire) with a wall-clock bound; a timeout raises *err instead of
 // hanging the queue (the caller checks it at its next sync point).
-__global__ __launch_bounds__(64) void k_peer_wait(PeerFlags f, int n, int32_t seq, int32_t* err, long long timeout_ticks) {
+// On a timeout the wait gives up, records who was missing (*err) and POISONS the step: the two optional words (the
+// caller's sticky overflow word and the agreed verdict word the optimizer kernels are guarded by) are set to 1, so the
+// kernels queued behind this one do not consume the stale receive slots (a timed-out wait used to let the SH
+// and geometry Adam run on them until the host looked at *err).
+__global__ __launch_bounds__(64) void k_peer_wait(PeerFlags f, int n, int32_t seq, int32_t* err, long long timeout_ticks,
+                                                  int32_t* poison_a, int32_t* poison_b) {
   const int i = threadIdx.x;
   if (i < n && f.flag[i]) {
     const long long t0 = (long long)__builtin_readcyclecounter();
@@ -139,6 +144,8 @@ __global__ __launch_bounds__(64) void k_peer_wait(PeerFlags f, int n, int32_t se
       __builtin_amdgcn_s_sleep(16);
       if ((long long)__builtin_readcyclecounter() - t0 > timeout_ticks) {
         if (err) *err = 1 + i;
+        if (poison_a) *poison_a = 1;
+        if (poison_b) *poison_b = 1;
         break;
       }
     }
@@ -158,18 +165,27 @@ int grid_for(size_t n4) { const size_t g = (n4 + 255) / 256; return (int)(g < 20
 
 }  // namespace
 
-extern "C" int tgs_peer_alloc(size_t bytes, void** dptr, unsigned char* handle64) {
+extern "C" int tgs_peer_alloc(size_t bytes, int allow_kinds, void** dptr, unsigned char* handle64, int* kind_out) {
   TGS_CHECK_ARG(dptr && handle64 && bytes > 0, "null pointer / zero size");
+  TGS_CHECK_ARG((allow_kinds & (TGS_PEER_MEM_UNCACHED | TGS_PEER_MEM_FINEGRAINED | TGS_PEER_MEM_PLAIN)) != 0, "no memory kind allowed");
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
   void* p = nullptr;
-  // uncached: a peer's stores arrive in this GPU's HBM behind its L2; fall back to fine-grained, then plain memory
-  if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) {
+  int kind = 0;
+  // uncached: a peer's stores arrive in this GPU's HBM behind its L2 -- what the transport's ordering argument is
+  // written for; fine-grained: coherent at system scope, same argument; plain (cached) memory only on request: the
+  // owner's L2 may then hold stale lines of a slot a peer has written, the caller must publish behind kernel
+  // boundaries AND invalidate before reading.  The kind obtained is reported, never silently downgraded.
+  if ((allow_kinds & TGS_PEER_MEM_UNCACHED) && hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) == hipSuccess) kind = TGS_PEER_MEM_UNCACHED;
+  if (!kind) (void)hipGetLastError();
+  if (!kind && (allow_kinds & TGS_PEER_MEM_FINEGRAINED) && hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) == hipSuccess) kind = TGS_PEER_MEM_FINEGRAINED;
+  if (!kind) (void)hipGetLastError();
+  if (!kind && (allow_kinds & TGS_PEER_MEM_PLAIN) && hipMalloc(&p, bytes) == hipSuccess) kind = TGS_PEER_MEM_PLAIN;
+  if (!kind) {
     (void)hipGetLastError();
-    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
-      (void)hipGetLastError();
-      TGS_HIP(hipMalloc(&p, bytes));
-    }
+    tgs_set_error("tgs_peer_alloc: none of the allowed memory kinds (mask %d) could be allocated (%zu bytes)", allow_kinds, bytes);
+    return TGS_E_HIP;
   }
+  if (kind_out) *kind_out = kind;
   TGS_HIP(hipMemset(p, 0, bytes));
   TGS_HIP(hipDeviceSynchronize());
   hipIpcMemHandle_t h;
@@ -255,14 +271,15 @@ extern "C" int tgs_peer_signal(int n, int32_t* const* flags, int32_t seq, void* 
   return TGS_OK;
 }
 
-extern "C" int tgs_peer_wait(int n, const int32_t* const* flags, int32_t seq, int32_t* err, float timeout_s, void* stream) {
+extern "C" int tgs_peer_wait(int n, const int32_t* const* flags, int32_t seq, int32_t* err, float timeout_s,
+                             int32_t* poison_a, int32_t* poison_b, void* stream) {
   TGS_CHECK_ARG(n >= 0 && n <= 2 * PEER_MAX && (n == 0 || flags), "at most 16 flags");
   if (n == 0) return TGS_OK;
   PeerFlags f;
   for (int i = 0; i < 2 * PEER_MAX; i++) f.flag[i] = i < n ? flags[i] : nullptr;
   // __builtin_readcyclecounter = s_memtime: the shader clock (~2.4 GHz nominal)
   const long long ticks = (long long)((timeout_s > 0 ? timeout_s : 20.0) * 2.0e9);
-  hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, (hipStream_t)stream, f, n, seq, err, ticks);
+  hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, (hipStream_t)stream, f, n, seq, err, ticks, poison_a, poison_b);
   TGS_CHECK_LAUNCH();
   return TGS_OK;
 }

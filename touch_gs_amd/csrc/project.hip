@@ -1349,7 +1349,7 @@ extern "C" int tgs_project_bin_sort_front(const TgsCamera* cam, int N, const flo
                                           const float* log_scales, const float* quats,
                                           const float* opac_logit, const float* sh, int sh_stride,
                                           int sh_deg, float* splats, int32_t* radii, int32_t* group_base,
-                                          int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
+                                          int32_t* tile_start, int64_t tile_start_len, int32_t* tile_cursor, int32_t* sorted_gid,
                                           int32_t* tile_order, int64_t capacity, void* scratch,
                                           int32_t* status, int32_t* sticky_overflow,
                                           const int32_t* tag_word, int32_t tag_expect,
@@ -1369,6 +1369,8 @@ extern "C" int tgs_project_bin_sort_front(const TgsCamera* cam, int N, const flo
   TGS_CHECK_ARG(means && log_scales && quats && opac_logit && sh && splats, "null pointer (the SH rows stay the fallback)");
   TGS_CHECK_ARG(sh_deg >= 0 && sh_deg <= 3 && sh_stride >= (sh_deg + 1) * (sh_deg + 1), "bad SH degree / stride");
   const CamK k = make_camk(cam);
+  // checked BEFORE the first launch (tgs_bin_finish checks again): nothing is enqueued for a short buffer
+  TGS_CHECK_ARG(tile_start_len >= (int64_t)k.TW * k.TH + 1 + TGS_TILE_START_SCRATCH, "tile_start buffer shorter than tgs_tile_start_len(W, H)");
   hipStream_t s = (hipStream_t)stream;
   const BinScratch sc = carve_scratch(scratch, capacity);
   const dim3 grid((N + 255) / 256), block(256);
@@ -1384,7 +1386,7 @@ extern "C" int tgs_project_bin_sort_front(const TgsCamera* cam, int N, const flo
   }
 #undef LAUNCH_U
   TGS_CHECK_LAUNCH();
-  return tgs_bin_finish(k, N, splats, group_base, tile_start, tile_cursor, sorted_gid, tile_order,
+  return tgs_bin_finish(k, N, splats, group_base, tile_start, tile_start_len, tile_cursor, sorted_gid, tile_order,
                         capacity, scratch, status, s);
 }
 
@@ -1393,7 +1395,7 @@ static int project_bin_sort_impl(const TgsCamera* cam, int N, const float* means
                                  const float* log_scales, const float* quats,
                                  const float* opac_logit, const float* sh, int sh_stride,
                                  int sh_deg, float* splats, int32_t* radii, int32_t* group_base,
-                                 int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
+                                 int32_t* tile_start, int64_t tile_start_len, int32_t* tile_cursor, int32_t* sorted_gid,
                                  int32_t* tile_order, int64_t capacity, void* scratch,
                                  int32_t* status, int32_t* sticky_overflow, const float* colors_in,
                                  const int32_t* color_tag, int32_t tag_expect, void* stream) {
@@ -1407,6 +1409,7 @@ static int project_bin_sort_impl(const TgsCamera* cam, int N, const float* means
   TGS_CHECK_ARG(sh_deg < 0 || sh_stride >= (sh_deg + 1) * (sh_deg + 1), "sh_stride too small");
   const CamK k = make_camk(cam);
   const int T = k.TW * k.TH;
+  TGS_CHECK_ARG(tile_start_len >= (int64_t)T + 1 + TGS_TILE_START_SCRATCH, "tile_start buffer shorter than tgs_tile_start_len(W, H)");
   hipStream_t s = (hipStream_t)stream;
   const BinScratch sc = carve_scratch(scratch, capacity);
   hipLaunchKernelGGL(k_clear_counters, dim3((max(TGS_XCC * T, 2) + 255) / 256), dim3(256), 0, s, tile_cursor, T, status,
@@ -1442,7 +1445,7 @@ static int project_bin_sort_impl(const TgsCamera* cam, int N, const float* means
 #undef LAUNCH_PRE
     TGS_CHECK_LAUNCH();
   }
-  return tgs_bin_finish(k, N, splats, group_base, tile_start, tile_cursor, sorted_gid, tile_order,
+  return tgs_bin_finish(k, N, splats, group_base, tile_start, tile_start_len, tile_cursor, sorted_gid, tile_order,
                         capacity, scratch, status, s);
 }
 
@@ -1450,11 +1453,11 @@ extern "C" int tgs_project_bin_sort(const TgsCamera* cam, int N, const float* me
                                     const float* log_scales, const float* quats,
                                     const float* opac_logit, const float* sh, int sh_stride,
                                     int sh_deg, float* splats, int32_t* radii, int32_t* group_base,
-                                    int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
+                                    int32_t* tile_start, int64_t tile_start_len, int32_t* tile_cursor, int32_t* sorted_gid,
                                     int32_t* tile_order, int64_t capacity, void* scratch,
                                     int32_t* status, int32_t* sticky_overflow, void* stream) {
   return project_bin_sort_impl(cam, N, means, log_scales, quats, opac_logit, sh, sh_stride, sh_deg, splats,
-                               radii, group_base, tile_start, tile_cursor, sorted_gid, tile_order, capacity,
+                               radii, group_base, tile_start, tile_start_len, tile_cursor, sorted_gid, tile_order, capacity,
                                scratch, status, sticky_overflow, nullptr, nullptr, 0, stream);
 }
 
@@ -1462,7 +1465,7 @@ extern "C" int tgs_project_bin_sort_colors(const TgsCamera* cam, int N, const fl
                                            const float* log_scales, const float* quats,
                                            const float* opac_logit, const float* sh, int sh_stride,
                                            int sh_deg, float* splats, int32_t* radii,
-                                           int32_t* group_base, int32_t* tile_start,
+                                           int32_t* group_base, int32_t* tile_start, int64_t tile_start_len,
                                            int32_t* tile_cursor, int32_t* sorted_gid,
                                            int32_t* tile_order, int64_t capacity, void* scratch,
                                            int32_t* status, int32_t* sticky_overflow,
@@ -1470,7 +1473,7 @@ extern "C" int tgs_project_bin_sort_colors(const TgsCamera* cam, int N, const fl
                                            int32_t tag_expect, void* stream) {
   TGS_CHECK_ARG(sh && colors_in && color_tag, "null pointer (the SH rows stay the fallback)");
   return project_bin_sort_impl(cam, N, means, log_scales, quats, opac_logit, sh, sh_stride, sh_deg, splats,
-                               radii, group_base, tile_start, tile_cursor, sorted_gid, tile_order, capacity,
+                               radii, group_base, tile_start, tile_start_len, tile_cursor, sorted_gid, tile_order, capacity,
                                scratch, status, sticky_overflow, colors_in, color_tag, tag_expect, stream);
 }
 
@@ -1591,6 +1594,9 @@ static __global__ void k_dp_agree_overflow(int world, size_t blk, const float* _
   int any = 0;
   for (int r = threadIdx.x; r < world; r += TGS_WAVE) any |= v_color_all[r * blk + blk - 1] != 0.f;
   any = __ballot(any) != 0ull;
+  // a sticky word that is already raised voids this step too: by an earlier overflow (then every rank's flag is set
+  // anyway) or by a peer-exchange wait that timed out in front of this launch (tgs_peer_wait's poison word)
+  if (sticky && *sticky) any = 1;
   if (threadIdx.x == 0) {
     status_out[0] = 0;
     status_out[1] = any;

@@ -194,13 +194,10 @@ __device__ __forceinline__ int stop_of(float smax) {
 // chain -- is what decides whether K7 splits its tiles over four waves (frame_is_chain_bound).  Every K6 block folds
 // its tile's walk into two of the words behind the tile starts (maximum and sum, TGS_WALK_AT / TGS_WALKSUM_AT(T, XCC
 // id): one pair per L2, the scan kernel zeroed them); a pixel that never stopped walks the whole list.  Pixels outside the image keep smax > 0.
-#define TGS_WALK_WORDS 8
-// word x of the 512 scratch ints behind the tile starts: one XCD's words sit 256 B from the next one's and its two
-// words 128 B apart -- eight L2s updating neighbouring words of ONE line pass the line around for every atomic
-#define TGS_WALK_AT(T, x) ((T) + 1 + 64 * (x))
-#define TGS_WALKSUM_AT(T, x) ((T) + 1 + 64 * (x) + 1)
-#define TGS_SLOTCTR_AT(T, x) ((T) + 1 + 64 * (x) + 32)
-#define TGS_TILE_START_SCRATCH 512
+// (TGS_WALK_AT / TGS_WALKSUM_AT / TGS_SLOTCTR_AT: layout of the scratch ints behind the tile starts, tgs_common.h)
+// The host entry points take tile_start as a mutable buffer of tgs_tile_start_len ints (tgs.h); the kernels keep a const
+// __restrict__ view of it for the starts (scalar loads) and reach the scratch words behind them through this one cast.
+__device__ __forceinline__ int32_t* frame_scratch(const int32_t* tile_start) { return const_cast<int32_t*>(tile_start); }
 __device__ __forceinline__ void publish_walk(const int32_t* __restrict__ tile_start, int T_total, const float (&smax)[4],
                                              int n, int lane) {
   int wl = 0;
@@ -210,8 +207,8 @@ __device__ __forceinline__ void publish_walk(const int32_t* __restrict__ tile_st
   wl = wave_minmax_i<true>(wl);
   if (lane == 0 && wl > 0) {
     const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & (TGS_WALK_WORDS - 1));
-    atomicMax(const_cast<int32_t*>(tile_start) + TGS_WALK_AT(T_total, xcc), wl);
-    atomicAdd(const_cast<int32_t*>(tile_start) + TGS_WALKSUM_AT(T_total, xcc), wl);   // sum of the walks = K7's work
+    atomicMax(frame_scratch(tile_start) + TGS_WALK_AT(T_total, xcc), wl);
+    atomicAdd(frame_scratch(tile_start) + TGS_WALKSUM_AT(T_total, xcc), wl);   // sum of the walks = K7's work
   }
 }
 
@@ -502,8 +499,8 @@ __device__ __forceinline__ void raster_fwd_quadrant(
   int wl = wave_minmax_i<true>(inb ? min(stop_of(smax), end - start) : 0);
   if (lane == 0 && wl > 0) {
     const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & (TGS_WALK_WORDS - 1));
-    atomicMax(const_cast<int32_t*>(tile_start) + TGS_WALK_AT(T_total, xcc), wl);
-    atomicAdd(const_cast<int32_t*>(tile_start) + TGS_WALKSUM_AT(T_total, xcc), (wl + 3) >> 2);
+    atomicMax(frame_scratch(tile_start) + TGS_WALK_AT(T_total, xcc), wl);
+    atomicAdd(frame_scratch(tile_start) + TGS_WALKSUM_AT(T_total, xcc), (wl + 3) >> 2);
   }
 }
 
@@ -1003,7 +1000,7 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
   // the slot counters of the four-wave launch that follows in the stream (8 words behind the walk words): cleared by
   // block 0 BEFORE any early return -- block 0's tile is empty in most object-centric frames
   if (blockIdx.x == 0 && threadIdx.x < TGS_WALK_WORDS && quad.factor > 0)
-    const_cast<int32_t*>(tile_start)[TGS_SLOTCTR_AT(T_total, threadIdx.x)] = 0;
+    frame_scratch(tile_start)[TGS_SLOTCTR_AT(T_total, threadIdx.x)] = 0;
   const int tile = tile_order ? tile_order[blockIdx.x] : xcd_tile(blockIdx.x, T_total);
   if (tile >= T_total) return;
   const int lane = threadIdx.x;
@@ -1271,7 +1268,7 @@ __global__ __launch_bounds__(256) void k_raster_bwd_quad(
   // the launch before this one) -- longest lists first, every tile on the XCD whose L2 holds its neighbours' records.
   __shared__ int s_slot;
   const int xcc = blockIdx.x & (TGS_XCDS - 1);    // workgroup b runs on XCD b % 8
-  int32_t* ctr = const_cast<int32_t*>(tile_start);
+  int32_t* ctr = frame_scratch(tile_start);
   int turn = 0;     // own XCD first, then the others' leftovers (correct wherever the workgroups were placed)
   for (;;) {
   __syncthreads();                          // (the previous tile's s_slot / s_qlim have been read)
@@ -1489,59 +1486,76 @@ __global__ __launch_bounds__(256) void k_raster_bwd_quad(
 
 }  // namespace
 
-// Run-time switches, read from the environment ONCE (first use) and settable through the C ABI afterwards
-// (tgs_rasterize_fwd used to call getenv on every launch).
-static int g_k6_blocks = -1, g_k7_f2b = -1, g_k7_quad = -1, g_k7_quad_min = -1, g_k6_split = -1;
-static int env_flag(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
-static int k6_blocks() { if (g_k6_blocks < 0) g_k6_blocks = env_flag("TGS_K6_BLOCKS", 1) != 0; return g_k6_blocks; }
-static int k7_f2b() { if (g_k7_f2b < 0) g_k7_f2b = env_flag("TGS_K7_F2B", 0) != 0; return g_k7_f2b; }
+// Process-wide DEFAULTS of the per-call TgsRasterOpts fields: read from the environment once (first use), settable
+// through the tgs_set_* calls afterwards (A/B runs, tests).  Atomic words, relaxed: a setter racing a launch on another
+// thread gives that launch the old or the new default, never a torn one.  Callers that need re-entrancy pass
+// TgsRasterOpts and leave the setters alone (tgs.h).
+#include <atomic>
+struct RasterDefault {
+  const char* env; int builtin; bool as_flag;
+  std::atomic<int> v{-1};
+  int get() {
+    int x = v.load(std::memory_order_relaxed);
+    if (x < 0) {
+      const char* e = getenv(env);
+      x = e ? atoi(e) : builtin;
+      x = as_flag ? (x != 0) : (x < 0 ? 0 : x);
+      int expect = -1;
+      if (!v.compare_exchange_strong(expect, x, std::memory_order_relaxed)) x = expect;   // a setter got there first
+    }
+    return x;
+  }
+  void set(int x) { v.store(as_flag ? (x != 0) : x, std::memory_order_relaxed); }
+};
+static RasterDefault g_k6_blocks{"TGS_K6_BLOCKS", 1, true};
+static RasterDefault g_k7_f2b{"TGS_K7_F2B", 0, true};
 // TGS_K7_QUAD: frame_is_chain_bound()'s factor (default 8: deepest walk beyond 4x the balanced per-slot load); 0 = one wave per tile always
-static int k7_quad() { if (g_k7_quad < 0) g_k7_quad = max(env_flag("TGS_K7_QUAD", 8), 0); return g_k7_quad; }
-static int k7_quad_min() { if (g_k7_quad_min < 0) g_k7_quad_min = max(env_flag("TGS_K7_QUAD_MIN", 48), 0); return g_k7_quad_min; }
-extern "C" int tgs_set_raster_variant(int k6_blocks_on, int k7_front_to_back) {
-  if (k6_blocks_on >= 0) g_k6_blocks = k6_blocks_on != 0;
-  if (k7_front_to_back >= 0) g_k7_f2b = k7_front_to_back != 0;
-  return (k6_blocks() ? 1 : 0) | (k7_f2b() ? 2 : 0);
-}
-
+static RasterDefault g_k7_quad{"TGS_K7_QUAD", 8, false};
+static RasterDefault g_k7_quad_min{"TGS_K7_QUAD_MIN", 48, false};
 // TGS_K6_SPLIT: tile_is_split()'s factor (default 4: lists beyond 4x the balanced per-slot load, and 256); 0 = never
-static int k6_split() { if (g_k6_split < 0) g_k6_split = max(env_flag("TGS_K6_SPLIT", 4), 0); return g_k6_split; }
-extern "C" int tgs_set_k6_split(int factor) {
-  if (factor >= 0) g_k6_split = factor;
-  return k6_split();
+static RasterDefault g_k6_split{"TGS_K6_SPLIT", 4, false};
+static inline int opt_or(const TgsRasterOpts* o, int32_t TgsRasterOpts::*f, RasterDefault& d) {
+  return (o && o->*f >= 0) ? (int)(o->*f) : d.get();
 }
-
+extern "C" int tgs_set_raster_variant(int k6_blocks_on, int k7_front_to_back) {
+  if (k6_blocks_on >= 0) g_k6_blocks.set(k6_blocks_on);
+  if (k7_front_to_back >= 0) g_k7_f2b.set(k7_front_to_back);
+  return (g_k6_blocks.get() ? 1 : 0) | (g_k7_f2b.get() ? 2 : 0);
+}
+extern "C" int tgs_set_k6_split(int factor) {
+  if (factor >= 0) g_k6_split.set(factor);
+  return g_k6_split.get();
+}
 extern "C" int tgs_set_k7_quad(int factor, int min_walk) {
-  if (factor >= 0) g_k7_quad = factor;
-  if (min_walk >= 0) g_k7_quad_min = min_walk;
-  return k7_quad() | (k7_quad_min() << 8);
+  if (factor >= 0) g_k7_quad.set(factor);
+  if (min_walk >= 0) g_k7_quad_min.set(min_walk);
+  return g_k7_quad.get() | (g_k7_quad_min.get() << 8);
 }
 
 extern "C" int tgs_rasterize_fwd(const TgsCamera* cam, const float* splats,
-                                 const int32_t* sorted_gid, const int32_t* tile_start,
+                                 const int32_t* sorted_gid, int32_t* tile_start, int64_t tile_start_len,
                                  const int32_t* tile_order, float* out_rgb, float* out_depth,
                                  float* final_T, int32_t* final_idx, int32_t* stop_pos, uint64_t* slot_ok,
-                                 void* stream) {
+                                 const TgsRasterOpts* opts, void* stream) {
   TGS_CHECK_ARG(camera_ok(cam), "bad camera");
   TGS_CHECK_ARG(splats && sorted_gid && tile_start && out_rgb && out_depth && final_T,
                 "null pointer");
   const CamK k = make_camk(cam);
   const int T = k.TW * k.TH;
+  TGS_CHECK_ARG(tile_start_len >= (int64_t)T + 1 + TGS_TILE_START_SCRATCH,
+                "tile_start buffer shorter than tgs_tile_start_len(W, H) (the forward writes the scratch behind the starts)");
   const int grid = TGS_XCDS * tgs_xcd_slots(T);
 #define TGS_LAUNCH_FWD(IDX, OK)                                                                          \
   hipLaunchKernelGGL((k_raster_fwd<IDX, OK>), dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T, splats, \
                      sorted_gid, tile_start, out_rgb, out_depth, final_T, final_idx, tile_order,          \
                      (unsigned long long*)slot_ok, stop_pos)
   // default: the 4x4-block form (-14.5 % at cfg3, bit-identical images); TGS_K6_BLOCKS=0 selects the quadrant
-  // form, which also serves the slot_ok bitmaps.  tgs_set_k6_blocks() switches it at run time (tests, A/B).
-  if (k6_blocks() && !slot_ok) {   // 4x4-block form (bit-identical images)
+  // form, which also serves the slot_ok bitmaps.  TgsRasterOpts.k6_blocks / tgs_set_raster_variant switch it (tests, A/B).
+  if (opt_or(opts, &TgsRasterOpts::k6_blocks, g_k6_blocks) && !slot_ok) {   // 4x4-block form (bit-identical images)
     // tiles with long lists are split into quadrant blocks (raster_fwd_quadrant): three extra blocks for each of the
     // schedule's first 512 entries (the longest lists of every XCD), which return at once unless their tile is split
     SplitRule sr;
-    sr.factor = tile_order ? k6_split() : 0;
+    sr.factor = tile_order ? opt_or(opts, &TgsRasterOpts::k6_split, g_k6_split) : 0;
     sr.n_slots = grid;
     sr.heads = sr.factor > 0 ? min(grid, 512) : 0;
     const int blocks = grid + 3 * sr.heads;
@@ -1563,12 +1577,12 @@ extern "C" int tgs_rasterize_fwd(const TgsCamera* cam, const float* splats,
 
 static int rasterize_bwd_impl(const TgsCamera* cam, const float* splats,
                                  const int32_t* group_base, const int32_t* sorted_gid,
-                                 const int32_t* tile_start, const int32_t* tile_order,
+                                 int32_t* tile_start, int64_t tile_start_len, const int32_t* tile_order,
                                  const float* out_rgb, const float* out_depth,
                                  const float* final_T, const int32_t* stop_pos, const float* v_rgb,
                                  const float* v_depth, const float* v_alpha,
                                  const TgsLossSpec* loss, float* partials, float* tile_loss,
-                                 int band, const uint64_t* slot_ok, void* stream) {
+                                 int band, const uint64_t* slot_ok, const TgsRasterOpts* opts, void* stream) {
   TGS_CHECK_ARG(camera_ok(cam), "bad camera");
   TGS_CHECK_ARG(splats && group_base && sorted_gid && tile_start && out_rgb && out_depth &&
                 final_T && partials, "null pointer");
@@ -1585,6 +1599,8 @@ static int rasterize_bwd_impl(const TgsCamera* cam, const float* splats,
   }
   const CamK k = make_camk(cam);
   const int T = k.TW * k.TH;
+  TGS_CHECK_ARG(tile_start_len >= (int64_t)T + 1 + TGS_TILE_START_SCRATCH,
+                "tile_start buffer shorter than tgs_tile_start_len(W, H) (the backward keeps slot counters behind the starts)");
   int grid = TGS_XCDS * tgs_xcd_slots(T);
   if (band >= 0) {   // one image band: the blocks of chunk `band` of every XCD's slots
     TGS_CHECK_ARG(tile_order, "a band launch needs the tile_order of tgs_bin_sort");
@@ -1593,7 +1609,7 @@ static int rasterize_bwd_impl(const TgsCamera* cam, const float* splats,
     tile_order += (size_t)s0 * TGS_XCDS;
     grid = (s1 - s0) * TGS_XCDS;
   }
-  if (k7_f2b() || slot_ok) {   // the front-to-back form (round 1-3; kept for A/B and for the slot_ok bitmaps)
+  if (opt_or(opts, &TgsRasterOpts::k7_front_to_back, g_k7_f2b) || slot_ok) {   // the front-to-back form (round 1-3; kept for A/B and for the slot_ok bitmaps)
     hipLaunchKernelGGL(k_raster_bwd_f2b, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T, splats,
                        group_base, sorted_gid, tile_start, out_rgb, out_depth, final_T,
                        v_rgb, v_depth, v_alpha, lk, partials, tile_loss, tile_order,
@@ -1601,8 +1617,8 @@ static int rasterize_bwd_impl(const TgsCamera* cam, const float* splats,
   } else {
     TGS_CHECK_ARG(stop_pos, "stop_pos (written by tgs_rasterize_fwd) is required");
     QuadRule qf;
-    qf.factor = band >= 0 ? 0 : k7_quad();   // (a band launch keeps one wave per tile)
-    qf.min_walk = k7_quad_min();
+    qf.factor = band >= 0 ? 0 : opt_or(opts, &TgsRasterOpts::k7_quad, g_k7_quad);   // (a band launch keeps one wave per tile)
+    qf.min_walk = opt_or(opts, &TgsRasterOpts::k7_quad_min_walk, g_k7_quad_min);
     hipLaunchKernelGGL(k_raster_bwd, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T, splats,
                        group_base, sorted_gid, tile_start, out_rgb, out_depth, final_T, stop_pos,
                        v_rgb, v_depth, v_alpha, lk, partials, tile_loss, tile_order, qf);
@@ -1620,25 +1636,25 @@ static int rasterize_bwd_impl(const TgsCamera* cam, const float* splats,
 
 extern "C" int tgs_rasterize_bwd(const TgsCamera* cam, const float* splats,
                                  const int32_t* group_base, const int32_t* sorted_gid,
-                                 const int32_t* tile_start, const int32_t* tile_order,
+                                 int32_t* tile_start, int64_t tile_start_len, const int32_t* tile_order,
                                  const float* out_rgb, const float* out_depth,
                                  const float* final_T, const int32_t* stop_pos, const float* v_rgb,
                                  const float* v_depth, const float* v_alpha,
                                  const TgsLossSpec* loss, float* partials, float* tile_loss,
-                                 const uint64_t* slot_ok, void* stream) {
-  return rasterize_bwd_impl(cam, splats, group_base, sorted_gid, tile_start, tile_order, out_rgb, out_depth, final_T, stop_pos, v_rgb, v_depth, v_alpha, loss, partials, tile_loss, -1, slot_ok, stream);
+                                 const uint64_t* slot_ok, const TgsRasterOpts* opts, void* stream) {
+  return rasterize_bwd_impl(cam, splats, group_base, sorted_gid, tile_start, tile_start_len, tile_order, out_rgb, out_depth, final_T, stop_pos, v_rgb, v_depth, v_alpha, loss, partials, tile_loss, -1, slot_ok, opts, stream);
 }
 
 extern "C" int tgs_rasterize_bwd_band(const TgsCamera* cam, const float* splats,
                                  const int32_t* group_base, const int32_t* sorted_gid,
-                                 const int32_t* tile_start, const int32_t* tile_order,
+                                 int32_t* tile_start, int64_t tile_start_len, const int32_t* tile_order,
                                  const float* out_rgb, const float* out_depth,
                                  const float* final_T, const int32_t* stop_pos, const float* v_rgb,
                                  const float* v_depth, const float* v_alpha,
                                  const TgsLossSpec* loss, float* partials, float* tile_loss,
-                                 int band, const uint64_t* slot_ok, void* stream) {
+                                 int band, const uint64_t* slot_ok, const TgsRasterOpts* opts, void* stream) {
   TGS_CHECK_ARG(band >= 0, "band < 0");
-  return rasterize_bwd_impl(cam, splats, group_base, sorted_gid, tile_start, tile_order, out_rgb, out_depth, final_T, stop_pos, v_rgb, v_depth, v_alpha, loss, partials, tile_loss, band, slot_ok, stream);
+  return rasterize_bwd_impl(cam, splats, group_base, sorted_gid, tile_start, tile_start_len, tile_order, out_rgb, out_depth, final_T, stop_pos, v_rgb, v_depth, v_alpha, loss, partials, tile_loss, band, slot_ok, opts, stream);
 }
 
 extern "C" size_t tgs_slot_ok_len(int W, int H, int64_t capacity) {

@@ -19,7 +19,7 @@ static inline BinScratch carve_scratch(void* scratch, int64_t capacity) {
 
 // scan + fill + sort (everything after the per-tile counts exist); defined in binning.hip
 int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* group_base,
-                   int32_t* tile_start, int32_t* tile_cursor, int32_t* sorted_gid,
+                   int32_t* tile_start, int64_t tile_start_len, int32_t* tile_cursor, int32_t* sorted_gid,
                    int32_t* tile_order, int64_t capacity, void* scratch, int32_t* status,
                    hipStream_t s);
 

@@ -19,6 +19,15 @@
 #ifndef TGS_XCD_GRANULE
 #define TGS_XCD_GRANULE 8
 #endif
+// The rasterizer's scratch behind the T + 1 tile starts (tgs_tile_start_len = T + 1 + 512 ints): per XCD x the frame's
+// deepest walk and the sum of its walks (K6 publish_walk -> K7 frame_is_chain_bound) and a slot counter of K7's
+// four-wave launch.  One XCD's words sit 256 B from the next one's, walk words and slot counter 128 B apart -- eight
+// L2s updating neighbouring words of ONE line pass the line around for every atomic.  Zeroed by k_scan_tiles.
+#define TGS_WALK_WORDS 8
+#define TGS_WALK_AT(T, x) ((T) + 1 + 64 * (x))
+#define TGS_WALKSUM_AT(T, x) ((T) + 1 + 64 * (x) + 1)
+#define TGS_SLOTCTR_AT(T, x) ((T) + 1 + 64 * (x) + 32)
+#define TGS_TILE_START_SCRATCH 512
 static inline __host__ __device__ int tgs_xcd_slots(int T) {
   const int q = (T + TGS_XCD_GRANULE - 1) / TGS_XCD_GRANULE;
   return ((q + TGS_XCDS - 1) / TGS_XCDS) * TGS_XCD_GRANULE;

@@ -363,11 +363,17 @@ class DepthGaussianSplattingModel:
         self._dp = None
 
     def _speculative_track(self, view: View, distributed: bool = False) -> None:
-        # pinned int32[6]: {#intersections, overflow, sufficient capacity, -} of this rank's frame | the verdict
-        host = self._pinned.pop() if self._pinned else torch.empty(6, dtype=torch.int32).pin_memory()
+        # pinned int32[7]: {#intersections, overflow, sufficient capacity, -} of this rank's frame | the verdict | the
+        # peer transport's error word (a wait that timed out; the device has already voided the step, see tgs_peer_wait)
+        host = self._pinned.pop() if self._pinned else torch.zeros(7, dtype=torch.int32).pin_memory()
         host[:4].copy_(self.budget.last_status4, non_blocking=True)
         # data parallel: the verdict is the agreed flag, not this rank's own
-        host[4:].copy_(self._dp_status if distributed else self.last["status"], non_blocking=True)
+        host[4:6].copy_(self._dp_status if distributed else self.last["status"], non_blocking=True)
+        peer = getattr(self._dp, "peer", None) if distributed else None
+        if peer is not None:
+            host[6:].copy_(peer.err_word, non_blocking=True)
+        else:
+            host[6] = 0
         ev = torch.cuda.Event()
         ev.record()
         self._pending.append((view, host, ev))
@@ -382,6 +388,8 @@ class DepthGaussianSplattingModel:
             view, host, ev = self._pending[0]
             ev.synchronize()
             block = False
+            if int(host[6]) != 0:      # surfaces at most max_in_flight steps after the wait gave up, before any replay
+                self._dp.peer.raise_if(int(host[6]))
             if int(host[5]) == 0:
                 self._pending.popleft()
                 self._seen_need = max(getattr(self, "_seen_need", 0), int(host[2]), int(host[0]))
@@ -541,6 +549,8 @@ class DepthGaussianSplattingModel:
             if self.budget.speculative:   # agree the overflow verdict across ranks before anything touches the model
                 if self._dp_status is None:
                     self._dp_status = torch.zeros(2, dtype=torch.int32, device=self.params.flat.device)
+                    # a peer-exchange wait that times out raises both words: this step and every later one are voided
+                    dp.set_poison_words(self.budget.sticky_word(self.params.flat.device), self._dp_status)
                 dguard = self._dp_status
 
             rows = self._color_rows
@@ -571,6 +581,9 @@ class DepthGaussianSplattingModel:
         self.step += 1
         if self.budget.speculative:
             self._speculative_track(full_view, distributed)
+        elif distributed and getattr(dp, "peer", None) is not None:
+            # synchronous budget: no guard words exist, so the error word is read every step (this mode syncs per step anyway)
+            dp.peer.raise_if(int(dp.peer.err_word.item()))
         if density is not None and density.due(self.step) and getattr(self, "_refined_at", None) != self.step:
             if self.budget.speculative:
                 # barrier: settle every pending overflow verdict first (a drain that finds one replays the

@@ -152,7 +152,7 @@ def bin_sort(cam: Camera, splats, budget: Optional[IntersectBudget] = None):
     while True:
         sorted_gid = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
         scratch = torch.empty(lib.tgs_sort_scratch_bytes(cap), dtype=torch.uint8, device=dev)
-        check(lib.tgs_bin_sort(C.byref(cs), N, ptr(splats), ptr(group_base), ptr(tile_start),
+        check(lib.tgs_bin_sort(C.byref(cs), N, ptr(splats), ptr(group_base), ptr(tile_start), _tile_start_len(tile_start),
                                ptr(tile_cursor), ptr(sorted_gid), ptr(tile_order), cap, ptr(scratch),
                                ptr(status), ptr(budget.sticky_word(dev)), _stream()), "tgs_bin_sort")
         budget.last_status = status
@@ -266,8 +266,8 @@ def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_d
             ncs = nf.cam.c_struct() if nf is not None else None
             check(lib.tgs_project_bin_sort_front(C.byref(cs), N, ptr(means), ptr(log_scales), ptr(quats), ptr(opac_logit),
                                                  ptr(sh), sh_stride, sh_deg, ptr(splats), ptr(radii), ptr(group_base),
-                                                 ptr(tile_start), ptr(tile_cursor), ptr(sorted_gid), ptr(tile_order),
-                                                 cap, ptr(scratch), ptr(status), ptr(budget.sticky_word(dev)),
+                                                 ptr(tile_start), _tile_start_len(tile_start), ptr(tile_cursor), ptr(sorted_gid),
+                                                 ptr(tile_order), cap, ptr(scratch), ptr(status), ptr(budget.sticky_word(dev)),
                                                  ptr(tag_holder.tag_word), tag_holder.tag,
                                                  C.byref(ncs) if nf is not None else None,
                                                  ptr(nf.tile_cursor) if nf is not None else None,
@@ -279,15 +279,15 @@ def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_d
         elif colors is None or sh is None:
             check(lib.tgs_project_bin_sort(C.byref(cs), N, ptr(means), ptr(log_scales), ptr(quats), ptr(opac_logit),
                                            ptr(sh), sh_stride, sh_deg if sh is not None else -1, ptr(splats),
-                                           ptr(radii), ptr(group_base), ptr(tile_start), ptr(tile_cursor),
-                                           ptr(sorted_gid), ptr(tile_order), cap, ptr(scratch), ptr(status),
+                                           ptr(radii), ptr(group_base), ptr(tile_start), _tile_start_len(tile_start),
+                                           ptr(tile_cursor), ptr(sorted_gid), ptr(tile_order), cap, ptr(scratch), ptr(status),
                                            ptr(budget.sticky_word(dev)), _stream()),
                   "tgs_project_bin_sort")
         else:
             check(lib.tgs_project_bin_sort_colors(C.byref(cs), N, ptr(means), ptr(log_scales), ptr(quats),
                                                   ptr(opac_logit), ptr(sh), sh_stride, sh_deg, ptr(splats),
-                                                  ptr(radii), ptr(group_base), ptr(tile_start), ptr(tile_cursor),
-                                                  ptr(sorted_gid), ptr(tile_order), cap, ptr(scratch), ptr(status),
+                                                  ptr(radii), ptr(group_base), ptr(tile_start), _tile_start_len(tile_start),
+                                                  ptr(tile_cursor), ptr(sorted_gid), ptr(tile_order), cap, ptr(scratch), ptr(status),
                                                   ptr(budget.sticky_word(dev)), ptr(colors.colors),
                                                   ptr(colors.tag_word), colors.tag, _stream()),
                   "tgs_project_bin_sort_colors")
@@ -306,17 +306,34 @@ def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_d
     return splats, radii, group_base, tile_start, sorted_gid, status
 
 
+def _tile_start_len(tile_start) -> int:
+    """int32 entries of the allocation from the tensor's first element on: the ``tile_start_len`` the C ABI validates
+    against ``tgs_tile_start_len`` (TGS_VERSION 300)."""
+    return tile_start.untyped_storage().nbytes() // 4 - tile_start.storage_offset()
+
+
+def raster_opts(k6_blocks=None, k6_split=None, k7_front_to_back=None, k7_quad=None, k7_quad_min_walk=None):
+    """Per-call TgsRasterOpts (tgs.h): the forms of the compositing kernels for ONE rasterize_fwd / rasterize_bwd call,
+    independent of the process-wide ``set_raster_variant`` / ``set_k6_split`` / ``set_k7_quad`` defaults.  None = default."""
+    f = lambda v: -1 if v is None else int(v)
+    return _lib.TgsRasterOpts(f(k6_blocks), f(k6_split), f(k7_front_to_back), f(k7_quad), f(k7_quad_min_walk))
+
+
 def _check_tile_start(tile_start, T: int) -> None:
-    """The rasterizer keeps 512 scratch ints behind the T + 1 tile starts (tgs.h, TGS_VERSION 201): a tensor that was
-    copied out of the buffer ``bin_sort`` / ``FrontBuffers`` allocated (clone, contiguous, .to) has lost them."""
-    have = tile_start.untyped_storage().nbytes() // 4 - tile_start.storage_offset()
+    """The rasterizer keeps 512 scratch ints behind the T + 1 tile starts (tgs.h, tgs_tile_start_len): a tensor that was
+    copied out of the buffer ``bin_sort`` / ``FrontBuffers`` allocated (clone, contiguous, .to) has lost them.  (The C
+    ABI checks the same length; this gives the Python caller the reason.)"""
+    have = _tile_start_len(tile_start)
     if have < T + 1 + 512:
         raise ValueError(f"tile_start must be (a view of) a buffer of T + 513 = {T + 513} int32 (got room for {have}): "
                          "pass the tensor ops.bin_sort / ops.project_bin_sort returned, not a copy")
 
 
-def rasterize_fwd(cam: Camera, splats, sorted_gid, tile_start, want_idx: bool = False):
-    """K6 -> (rgb [H,W,3], depth_acc [H,W], final_T [H,W], final_idx [H,W] or None).  (tgs_rasterize_fwd)"""
+def rasterize_fwd(cam: Camera, splats, sorted_gid, tile_start, want_idx: bool = False, want_stop: bool = True, opts=None):
+    """K6 -> (rgb [H,W,3], depth_acc [H,W], final_T [H,W], final_idx [H,W] or None).  (tgs_rasterize_fwd)
+
+    ``want_stop=False`` (render only: evaluation, ``get_outputs``) skips the per-pixel stop positions the backward needs
+    (4 B per pixel not allocated, not written); ``opts`` = ``raster_opts(...)`` for this call only."""
     lib = _lib.load()
     dev = splats.device
     H, W = cam.H, cam.W
@@ -327,7 +344,7 @@ def rasterize_fwd(cam: Camera, splats, sorted_gid, tile_start, want_idx: bool = 
     fidx = torch.empty(H, W, dtype=torch.int32, device=dev) if want_idx else None
     # per pixel: list position of the Gaussian that stopped it -- where the backward (back to front) starts.
     # It travels with final_T (fT.stop_pos), like tile_order / slot_ok travel with tile_start.
-    stop = torch.empty(H, W, dtype=torch.int32, device=dev)
+    stop = torch.empty(H, W, dtype=torch.int32, device=dev) if want_stop else None
     fT.stop_pos = stop
     cs = cam.c_struct()
     slot_ok = None
@@ -336,15 +353,16 @@ def rasterize_fwd(cam: Camera, splats, sorted_gid, tile_start, want_idx: bool = 
         # backward over the same lists (rasterize_bwd*) skips the rest.  Results are unaffected.
         slot_ok = torch.empty(4 * lib.tgs_slot_ok_len(W, H, sorted_gid.shape[0]), dtype=torch.int64, device=dev)
         tile_start.slot_ok = slot_ok
-    check(lib.tgs_rasterize_fwd(C.byref(cs), ptr(splats), ptr(sorted_gid), ptr(tile_start),
+    check(lib.tgs_rasterize_fwd(C.byref(cs), ptr(splats), ptr(sorted_gid), ptr(tile_start), _tile_start_len(tile_start),
                                 ptr(getattr(tile_start, "tile_order", None)), ptr(rgb),
-                                ptr(depth), ptr(fT), ptr(fidx), ptr(stop), ptr(slot_ok), _stream()), "tgs_rasterize_fwd")
+                                ptr(depth), ptr(fT), ptr(fidx), ptr(stop), ptr(slot_ok),
+                                C.byref(opts) if opts is not None else None, _stream()), "tgs_rasterize_fwd")
     return rgb, depth, fT, fidx
 
 
 def rasterize_bwd(cam: Camera, splats, group_base, sorted_gid, tile_start, rgb, depth, fT,
                   v_rgb=None, v_depth=None, v_alpha=None, loss: Optional[dict] = None,
-                  want_tile_loss: bool = False, stop_pos=None, partials=None):
+                  want_tile_loss: bool = False, stop_pos=None, partials=None, opts=None):
     """K7 -> (partials [cap,12], tile_loss [T,2] or None).  (tgs_rasterize_bwd)
 
     ``loss`` = dict(gt_rgb, gt_depth, uncertainty, l1_weight, depth_weight, uncertainty_weight, eps).
@@ -363,11 +381,12 @@ def rasterize_bwd(cam: Camera, splats, group_base, sorted_gid, tile_start, rgb, 
         ls = _loss_spec_struct(loss, keep)
     v_rgb, v_depth, v_alpha = _f32c(v_rgb), _f32c(v_depth), _f32c(v_alpha)
     check(lib.tgs_rasterize_bwd(C.byref(cs), ptr(splats), ptr(group_base), ptr(sorted_gid),
-                                ptr(tile_start), ptr(getattr(tile_start, "tile_order", None)),
+                                ptr(tile_start), _tile_start_len(tile_start), ptr(getattr(tile_start, "tile_order", None)),
                                 ptr(rgb), ptr(depth), ptr(fT), ptr(_stop_pos_of(fT, stop_pos)),
                                 ptr(v_rgb), ptr(v_depth), ptr(v_alpha),
                                 C.byref(ls) if ls is not None else None, ptr(partials),
-                                ptr(tile_loss), ptr(getattr(tile_start, "slot_ok", None)), _stream()), "tgs_rasterize_bwd")
+                                ptr(tile_loss), ptr(getattr(tile_start, "slot_ok", None)),
+                                C.byref(opts) if opts is not None else None, _stream()), "tgs_rasterize_bwd")
     return partials, tile_loss
 
 
@@ -474,9 +493,10 @@ def rasterize_bwd_ssim_pipelined(cam: Camera, splats, group_base, sorted_gid, ti
     for (b, *_), ev in zip(bands, done):
         main.wait_event(ev)
         check(lib.tgs_rasterize_bwd_band(C.byref(cs), ptr(splats), ptr(group_base), ptr(sorted_gid), ptr(tile_start),
-                                         ptr(order), ptr(rgb), ptr(depth), ptr(fT), ptr(_stop_pos_of(fT)), ptr(v_img), None, None,
+                                         _tile_start_len(tile_start), ptr(order), ptr(rgb), ptr(depth), ptr(fT),
+                                         ptr(_stop_pos_of(fT)), ptr(v_img), None, None,
                                          C.byref(ls) if ls is not None else None, ptr(partials), ptr(tile_loss),
-                                         b, ptr(getattr(tile_start, "slot_ok", None)), _stream()), "tgs_rasterize_bwd_band")
+                                         b, ptr(getattr(tile_start, "slot_ok", None)), None, _stream()), "tgs_rasterize_bwd_band")
     return partials, tile_loss, bp
 
 
@@ -556,11 +576,14 @@ class _Render(torch.autograd.Function):
         means, log_scales, quats, opac_logit, sh = map(_f32c, (means, log_scales, quats, opac_logit, sh))
         splats, radii, group_base, tile_start, sorted_gid, _ = project_bin_sort(
             cam, means, log_scales, quats, opac_logit, sh, sh_deg, budget, want_radii=True)
-        rgb, depth, fT, fidx = rasterize_fwd(cam, splats, sorted_gid, tile_start)
+        # render only (evaluation, get_outputs under no_grad): no backward will ask for the stop positions
+        need_bwd = torch.is_grad_enabled() and any(ctx.needs_input_grad)
+        rgb, depth, fT, fidx = rasterize_fwd(cam, splats, sorted_gid, tile_start, want_stop=need_bwd)
         ctx.cam, ctx.sh_deg = cam, sh_deg
         ctx.want_xy = means2d is not None
-        ctx.save_for_backward(means, log_scales, quats, opac_logit, sh, splats, group_base,
-                              tile_start, sorted_gid, rgb, depth, fT, fT.stop_pos)
+        if need_bwd:
+            ctx.save_for_backward(means, log_scales, quats, opac_logit, sh, splats, group_base,
+                                  tile_start, sorted_gid, rgb, depth, fT, fT.stop_pos)
         alpha = 1.0 - fT
         ctx.mark_non_differentiable(radii)
         return rgb, depth, alpha, radii

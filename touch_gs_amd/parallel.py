@@ -95,7 +95,12 @@ class PeerExchange:
         self.n_int = -(-(self.f_ticket + self.C + 2) // 4) * 4
         nbytes = 4 * (self.n_float + self.n_int)
         base, handle = C.c_void_p(), (C.c_ubyte * 64)()
-        _lib.check(lib.tgs_peer_alloc(nbytes, C.byref(base), handle), "tgs_peer_alloc")
+        # uncached or fine-grained memory only (TGS_PEER_MEM_UNCACHED | _FINEGRAINED): with plain cached memory the
+        # owner's L2 may hold stale lines of a slot a peer has written and the premise of the transport is void --
+        # the call fails instead of downgrading; the kind obtained goes into the bench line (dp_exchange.memory_kind)
+        kind = C.c_int(0)
+        _lib.check(lib.tgs_peer_alloc(nbytes, 1 | 2, C.byref(base), handle, C.byref(kind)), "tgs_peer_alloc")
+        self.memory_kind = {1: "uncached", 2: "fine-grained"}[kind.value]
         self._own = base.value
         handles = [None] * W
         dist.all_gather_object(handles, bytes(handle))
@@ -109,6 +114,11 @@ class PeerExchange:
                 self.base.append(p.value)
         self.seq = 0
         self.bytes_pushed = 0
+        # device words a timed-out wait sets to 1 (tgs_peer_wait): the sticky overflow word and word [1] of the agreed
+        # verdict the optimizer kernels are guarded by -- the kernels behind the wait then skip instead of consuming
+        # stale receive slots (GradSync.set_poison_words; None = no guard words exist, e.g. a synchronous budget)
+        self.poison = (None, None)
+        self.timeout_s = float(os.environ.get("TGS_PEER_TIMEOUT_S", "0") or 0)    # <= 0: the library's 20 s
         # default: the data kernels publish nothing, a separate one-wave launch raises the flags behind the kernel
         # boundary -- ordered by the stream alone.  TGS_PEER_SAFE_FLAGS=0: the last workgroup of the data kernel
         # raises them itself (one launch less per transfer); that form assumes that a completed store to uncached
@@ -181,7 +191,8 @@ class PeerExchange:
 
     def _wait(self, flags) -> None:
         from . import _lib
-        _lib.check(self.lib.tgs_peer_wait(len(flags), flags, self.seq, self._i(self.r, self.f_err), 0.0,
+        _lib.check(self.lib.tgs_peer_wait(len(flags), flags, self.seq, self._i(self.r, self.f_err), self.timeout_s,
+                                          self.poison[0], self.poison[1],
                                           torch.cuda.current_stream().cuda_stream), "tgs_peer_wait")
 
     def all_reduce_geom(self, geom_grad: torch.Tensor) -> None:
@@ -207,9 +218,17 @@ class PeerExchange:
     def check(self) -> None:
         """Raises if a wait timed out (a peer never delivered): synchronises the device."""
         torch.cuda.synchronize(self.dev)
-        e = int(self._err_view.item())
+        self.raise_if(int(self._err_view.item()))
+
+    def raise_if(self, e: int) -> None:
+        """``e`` = a host copy of the error word (``err_word`` rides in the trainer's per-step status copy)."""
         if e:
-            raise RuntimeError(f"peer exchange: rank {self.r} timed out waiting for the flag of rank {e - 1}")
+            raise RuntimeError(f"peer exchange: rank {self.r} timed out waiting for the flag of rank {e - 1}; the steps "
+                               "behind the timed-out wait were voided on the device (poison words), nothing stale was applied")
+
+    @property
+    def err_word(self) -> torch.Tensor:
+        return self._err_view
 
     def close(self) -> None:
         from . import _lib
@@ -462,6 +481,7 @@ class GradSync:
             if self.peer is not None:
                 self.peer.close()
             self.peer = PeerExchange(self, geom_grad.device, sizes, geom_grad.numel())
+            self.peer.poison = getattr(self, "_poison", (None, None))
         peer, C_ = self.peer, len(blocks)
         if self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(device=geom_grad.device)
@@ -499,6 +519,16 @@ class GradSync:
         """Raises if a peer-exchange wait timed out (synchronises); no-op for the collective transport."""
         if self.peer is not None:
             self.peer.check()
+
+    def set_poison_words(self, sticky, verdict) -> None:
+        """The device words a timed-out peer wait raises (``tgs_peer_wait``): the budget's sticky overflow word and the
+        agreed verdict ``int32[2]`` whose word [1] guards the optimizer kernels.  Kept on the GradSync so that a
+        PeerExchange built later (first step) picks them up."""
+        from . import _lib
+        self._poison = (_lib.ptr(sticky) if sticky is not None else None,
+                        (_lib.ptr(verdict) + 4) if verdict is not None else None)
+        if self.peer is not None:
+            self.peer.poison = self._poison
 
     def comm_report(self) -> Optional[dict]:
         """Times and bus bandwidths of the last factored exchange recorded with ``timing = True``
