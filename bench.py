@@ -339,11 +339,43 @@ def self_launch(n_ranks: int) -> int:
         if not js or l is not js[-1]:
             print(l, file=sys.stderr)
     if js:
-        print(js[-1], flush=True)
+        _emit(json.loads(js[-1]))
     return r.returncode if (r.returncode != 0 or js) else 1
 
 
+_REAL_STDOUT = None
+
+
+def _emit(line: dict) -> None:
+    """The ONE JSON line of the run, on the real stdout (see main)."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)   # RCCL's banner (C stdio) first, the JSON line last
+    except Exception:  # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (json.dumps(line) + "\n").encode())
+
+
 def main():
+    """Contract: rank 0 prints ONE JSON line on stdout.  Everything else the run prints on the way -- the trainer's
+    progress lines and eval dictionaries of the train_quality runs (JSON-shaped themselves), RCCL's banner, warnings of
+    child processes -- is sent to stderr by pointing file descriptor 1 at stderr for the duration of the run; _emit
+    writes the result to the saved descriptor."""
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        _main()
+    finally:
+        sys.stdout.flush()
+        os.dup2(_REAL_STDOUT, 1)
+        os.close(_REAL_STDOUT)
+        _REAL_STDOUT = None
+
+
+def _main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -472,15 +504,10 @@ def main():
     value = args.steps * dp.world / elapsed
     if args.loop_only:
         if dp.rank == 0:
-            import ctypes
-            try:
-                ctypes.CDLL(None).fflush(None)   # RCCL's banner (C stdio) first, the JSON line last
-            except Exception:  # noqa: BLE001
-                pass
-            print(json.dumps({"metric": "train iters/s (timed loop only)", "value": round(value, 3), "unit": "iters/s",
-                              "n_gpus": dp.world, "steps": args.steps, "warmup": args.warmup,
-                              "ms_per_step": round(ms_per_step, 4), "launched_steps": done[0],
-                              "config": {"workload": workload, "name": args.config, "layout": args.layout}}), flush=True)
+            _emit({"metric": "train iters/s (timed loop only)", "value": round(value, 3), "unit": "iters/s",
+                   "n_gpus": dp.world, "steps": args.steps, "warmup": args.warmup,
+                   "ms_per_step": round(ms_per_step, 4), "launched_steps": done[0],
+                   "config": {"workload": workload, "name": args.config, "layout": args.layout}})
         dp.barrier()
         return
 
@@ -709,14 +736,7 @@ def main():
         import torch.distributed as dist
         dist.destroy_process_group()
     if out is not None:
-        # the JSON line is the LAST thing on stdout: RCCL prints its version banner through C stdio, which
-        # is block-buffered on a pipe and would otherwise land behind it at process exit
-        import ctypes
-        try:
-            ctypes.CDLL(None).fflush(None)
-        except Exception:  # noqa: BLE001
-            pass
-        print(json.dumps(out), flush=True)
+        _emit(out)    # the only thing on stdout
 
 
 if __name__ == "__main__":

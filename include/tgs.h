@@ -141,7 +141,7 @@ int tgs_sh_bwd(int N, int sh_deg, int sh_stride, const float* dirs, const float*
  *                       block b runs on XCD b % 8; XCD x owns every 8th granule of 8 consecutive
  *                       tiles (balanced for any view) and visits its tiles longest list first inside
  *                       chunks of <= 1024; entry [i * 8 + x] = i-th visit of XCD x, T = "no tile"
- *      status[4]        {#intersections, overflow flag, sufficient capacity, reserved}.  The pair index
+ *      status[4]        {#intersections, overflow flag, sufficient capacity, longest list}.  The pair index
  *                       space [0, capacity) is cut into 8 equal regions, one per XCD: every K1 workgroup
  *                       takes its 256-Gaussian group's contiguous pair range from the region of the XCD
  *                       it runs on, or from the first other region with room.  A frame can therefore
@@ -157,11 +157,18 @@ int tgs_sh_bwd(int N, int sh_deg, int sh_stride, const float* dirs, const float*
  *                       the optimizer entry points this lets a caller read the status words late,
  *                       without a per-frame host sync: after an overflow nothing touches the model
  *                       until the caller has cleared the word, grown the buffers and replayed.
+ *      max_list_hint    < 0: no promise (every sort class is launched).  >= 0: the caller vouches that no tile's
+ *                       list is longer than this (e.g. 1.25 x the largest status[3] its recent frames of this scene
+ *                       reported): the launches for list classes beyond it -- (1024, 4096] and (4096, ..) entries,
+ *                       each ~4.6 us of the stream even when it finds nothing to sort -- are not issued.  A frame
+ *                       that breaks the promise is VOID like one that overflowed: the unsorted ids of the long
+ *                       lists are copied through (valid indices: the compositing kernels do not fault), status[1]
+ *                       = 1, the sticky word is raised, status[3] = the longest list -- raise the hint and replay.
  * tmp: tile_cursor[tgs_tile_counter_len(W,H)], scratch (tgs_sort_scratch_bytes(capacity)). */
 int tgs_bin_sort(const TgsCamera* cam /*[host]*/, int N, float* splats, int32_t* group_base,
                  int32_t* tile_start, int64_t tile_start_len, int32_t* tile_cursor, int32_t* sorted_gid,
                  int32_t* tile_order, int64_t capacity, void* scratch, int32_t* status,
-                 int32_t* sticky_overflow, void* stream);
+                 int32_t* sticky_overflow, int32_t max_list_hint, void* stream);
 
 /* K1 + K2-K5 in one call (the fast path): the projection workgroup IS the 256-Gaussian binning
  *     group, so it also builds the group scan and counts its tile intersections -- the records are
@@ -172,7 +179,7 @@ int tgs_project_bin_sort(const TgsCamera* cam /*[host]*/, int N, const float* me
                          const float* sh, int sh_stride, int sh_deg, float* splats, int32_t* radii,
                          int32_t* group_base, int32_t* tile_start, int64_t tile_start_len, int32_t* tile_cursor,
                          int32_t* sorted_gid, int32_t* tile_order, int64_t capacity, void* scratch,
-                         int32_t* status, int32_t* sticky_overflow, void* stream);
+                         int32_t* status, int32_t* sticky_overflow, int32_t max_list_hint, void* stream);
 
 /* Colour prefetch (single-process training loop): the Gaussians' 3K SH coefficients are needed by K1
  *     only for the colour they give from the camera.  tgs_project_bwd_adam_next (below) evaluates
@@ -191,7 +198,7 @@ int tgs_project_bin_sort_colors(const TgsCamera* cam /*[host]*/, int N, const fl
                                 int32_t* radii, int32_t* group_base, int32_t* tile_start, int64_t tile_start_len,
                                 int32_t* tile_cursor, int32_t* sorted_gid, int32_t* tile_order,
                                 int64_t capacity, void* scratch, int32_t* status,
-                                int32_t* sticky_overflow, const float* colors_in,
+                                int32_t* sticky_overflow, int32_t max_list_hint, const float* colors_in,
                                 const int32_t* color_tag, int32_t tag_expect, void* stream);
 
 /* Per-call choice of the compositing kernels' forms (tgs_rasterize_fwd / _bwd / _bwd_band; NULL = every field -1).
@@ -373,13 +380,15 @@ int tgs_project_bin_sort_front(const TgsCamera* cam /*[host]*/, int N, const flo
                                const float* sh, int sh_stride, int sh_deg, float* splats, int32_t* radii,
                                int32_t* group_base, int32_t* tile_start, int64_t tile_start_len, int32_t* tile_cursor,
                                int32_t* sorted_gid, int32_t* tile_order, int64_t capacity, void* scratch,
-                               int32_t* status, int32_t* sticky_overflow, const int32_t* tag_word,
-                               int32_t tag_expect,
+                               int32_t* status, int32_t* sticky_overflow, int32_t max_list_hint,
+                               const int32_t* tag_word, int32_t tag_expect,
                                const TgsCamera* next_cam /*[host] or NULL*/, int32_t* next_tile_cursor /*or NULL*/,
                                int32_t* next_status /*or NULL*/, void* stream);
-/* next_tile_cursor != NULL: the (otherwise idle) threads of this call's K1-check launch also clear the counters and
- * the status word of the frame AFTER this one (next_cam's size; sticky_overflow as usual) -- pass counters_cleared = 1
- * to the optimizer call that fills them.  Needs ceil(N/256)*256 >= 8 * #tiles of that frame: */
+/* A tag mismatch (the fused kernel was voided by its overflow guard) VOIDS the frame -- empty lists, status[1] = 1,
+ * sticky raised -- instead of re-running K1 (TGS_VERSION < 300 did, in a launch of its own): the parameter pointers
+ * are kept in the signature but no longer read.  next_tile_cursor != NULL: extra workgroups of this call's scan launch
+ * also clear the counters and the status word of the frame AFTER this one (next_cam's size; sticky_overflow as usual)
+ * -- pass counters_cleared = 1 to the optimizer call that fills them.  tgs_front_can_clear_next is always true now: */
 int tgs_front_can_clear_next(int N, int W, int H);
 
 /* Data-parallel step (one view per rank, SURVEY section 8 row e).  The SH gradient of a rank is the

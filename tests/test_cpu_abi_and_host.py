@@ -512,13 +512,13 @@ def test_c_abi_refuses_a_short_tile_start_buffer():
         rc = lib.tgs_rasterize_bwd(C.byref(cam), fake, fake, fake, fake, short, None, fake, fake, fake, fake, None, None, None,
                                    None, fake, None, None, None, None)
         assert rc == -1 and b"tgs_tile_start_len" in lib.tgs_last_error(), lib.tgs_last_error()
-        rc = lib.tgs_bin_sort(C.byref(cam), 0, None, fake, fake, short, fake, fake, None, 1024, fake, fake, None, None)
+        rc = lib.tgs_bin_sort(C.byref(cam), 0, None, fake, fake, short, fake, fake, None, 1024, fake, fake, None, -1, None)
         assert rc == -1 and b"tgs_tile_start_len" in lib.tgs_last_error(), lib.tgs_last_error()
         rc = lib.tgs_project_bin_sort(C.byref(cam), 0, None, None, None, None, None, 0, -1, None, None, fake, fake, short, fake,
-                                      fake, None, 1024, fake, fake, None, None)
+                                      fake, None, 1024, fake, fake, None, -1, None)
         assert rc == -1 and b"tgs_tile_start_len" in lib.tgs_last_error(), lib.tgs_last_error()
         rc = lib.tgs_project_bin_sort_front(C.byref(cam), 256, fake, fake, fake, fake, fake, 16, 3, fake, None, fake, fake, short,
-                                            fake, fake, None, 1024, fake, fake, None, fake, 0, None, None, None, None)
+                                            fake, fake, None, 1024, fake, fake, None, -1, fake, 0, None, None, None, None)
         assert rc == -1 and b"tgs_tile_start_len" in lib.tgs_last_error(), lib.tgs_last_error()
 
 

@@ -767,6 +767,54 @@ def test_speculative_budget_equals_synchronous_budget(dev, capacity, announce):
     assert torch.equal(spec.last["rgb"], ref.last["rgb"])
 
 
+def test_learned_list_hint_skips_launches_and_a_broken_hint_is_replayed(dev):
+    """Speculative budget: after LIST_HINT_AFTER settled frames the trainer bounds the longest tile list by 1.5 x the
+    longest it has seen and the sort launches for longer list classes are no longer issued.  Here the first views have
+    lists of a few hundred entries and a later view looks along the row of Gaussians (one tile list beyond 1024): that
+    frame breaks the learned bound, is voided on the device, and the replay (hint off) puts the model exactly where
+    the trainer without the hint ends -- parameters and moments bit for bit."""
+    from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
+    from touch_gs_amd.optim import GaussianParams
+    from touch_gs_amd.scene import make_view, synthetic_gaussians
+    N, W, H, deg = 2600, 160, 96, 3      # 1000 scattered Gaussians (lists of a few dozen entries) + the row
+    views = [make_view(N, W, H, deg, 7, dev, view=v, n_views=4) for v in range(4)]
+    P, _ = synthetic_gaussians(N, W, H, deg, 99)
+    # 1600 small Gaussians on the optical axis of view 3 only: one tile of that view gets a list > 1024
+    c2w = torch.linalg.inv(torch.tensor(views[3].cam.viewmat, dtype=torch.float64).reshape(4, 4))
+    g = torch.Generator().manual_seed(5)
+    z = 2.0 + 3.0 * torch.rand(1600, generator=g, dtype=torch.float64)
+    pts = torch.stack([0.002 * torch.randn(1600, generator=g, dtype=torch.float64) * z,
+                       0.002 * torch.randn(1600, generator=g, dtype=torch.float64) * z, z, torch.ones(1600, dtype=torch.float64)], 1)
+    P["means"][:1600] = (pts @ c2w.T)[:, :3].to(P["means"].dtype)
+    P["log_scales"][:1600] = -5.5
+    P["opac_logit"][:1600] = -3.0          # faint: the pixels behind them stay live, the whole list is walked
+
+    def run(hint):
+        params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
+        m = DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=0), params)
+        m.list_hint, m.LIST_HINT_AFTER = hint, 4
+        m.enable_speculative_budget(capacity=0, max_in_flight=2)
+        order = [0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 3, 1, 2, 3, 0]
+        hints = []
+        for i, v in enumerate(order):
+            m.train_step(views[v], next_view=views[order[i + 1]] if i + 1 < len(order) else None)
+            hints.append(m.budget.max_list_hint)
+        m.flush()
+        torch.cuda.synchronize()
+        return m, hints
+
+    a, ha = run(True)
+    b, hb = run(False)
+    assert all(h == -1 for h in hb) and getattr(b, "speculative_replays", 0) == 0
+    assert max(ha[:10]) > 0 and max(ha[:10]) < 1024, ha          # a bound below the wg4 class was learned ...
+    assert getattr(a, "speculative_replays", 0) > 0, ha          # ... view 3 broke it and was replayed
+    assert a._seen_longest > 1024
+    assert a.step == b.step == 15 and a.optimizer.t == b.optimizer.t == 15
+    for x, y in ((a.params.flat, b.params.flat), (a.optimizer.exp_avg, b.optimizer.exp_avg),
+                 (a.optimizer.exp_avg_sq, b.optimizer.exp_avg_sq)):
+        assert torch.equal(x, y)
+
+
 _RCCL_WORKER = r'''
 import os, sys, torch
 sys.path.insert(0, sys.argv[1])
@@ -1400,7 +1448,7 @@ def test_front_prefetch_is_bit_identical(dev, densify, speculative):
     just updated; step t+1 only scans, fills and sorts.  Records, images, parameters and moments bit for bit equal to
     the same sequence with the prefetch switched off, with the synchronous and the sync-free budget, with radii
     requested (densification statistics), when the announced view is not the one that comes, and across an
-    overflowing frame (the voided optimizer kernel leaves the tag word alone: K1 runs in the next step)."""
+    overflowing frame (the voided optimizer kernel leaves the tag word alone: the next frame is voided by its scan launch)."""
     from touch_gs_amd import ops
     from touch_gs_amd.densify import DensifyConfig
     from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
@@ -1451,15 +1499,15 @@ def test_front_prefetch_is_bit_identical(dev, densify, speculative):
 
     if not densify and not speculative:
         # an overflowing frame between two announced steps, SAME budget object (sync-free, fixed capacity): the fused
-        # kernel of the overflowing step is voided, the sticky word voids the next frame too -- whose K1 therefore runs
-        # in k_project_fwd_unless_done (tag mismatch) on counters the voided call had cleared; nothing is updated
+        # kernel of the overflowing step is voided, the sticky word voids the next frame too -- the scan launch of its
+        # front finish sees the tag mismatch and empties the frame (no K1 is re-run for it); nothing is updated
         m = fresh(True)
         m.budget = ops.IntersectBudget(capacity=16, sync=False)
         flat = m.params.flat.clone()
         m.train_step(views[0], next_view=views[1])           # overflows: no update, front of view 1 announced
         ready = m._prefetch_ready
         assert ready is not None and ready.front_issued and int(ready.tag_word) != ready.tag
-        m.train_step(views[1], next_view=views[2])           # front path taken on the host, K1 falls back on the device
+        m.train_step(views[1], next_view=views[2])           # front path taken on the host, voided on the device
         assert ready.front is None and int(m.last["status"][1]) == 1
         assert torch.equal(m.params.flat, flat)
         with pytest.raises(RuntimeError):

@@ -541,6 +541,49 @@ def test_sort_classes(dev, N, lo, hi):
     assert n == len(gid) and np.array_equal(sg[:n].cpu().numpy().astype(np.int64), gid)
 
 
+@pytest.mark.parametrize("N,hint,ok", [(700, 1024, True), (700, 0, True), (1500, 1024, False), (1500, 2000, True),
+                                        (1500, 4096, True), (5200, 4096, False), (5200, 6000, True), (5200, -1, True)])
+def test_max_list_hint_skips_sort_classes_or_voids_the_frame(dev, N, hint, ok):
+    """tgs_bin_sort's max_list_hint (TGS_VERSION 300): the launches for list classes beyond the caller's bound are not
+    issued.  A frame that keeps the promise is sorted bit for bit as without a hint; one that breaks it is VOID like an
+    overflow -- status[1] = 1, sticky word raised, status[3] = the longest list -- and its long lists hold the tile's own
+    ids in arrival order (valid indices: K6 / K7 behind it must not fault), never stale memory."""
+    from touch_gs_amd import ops
+    P, cam = scene(N, 32, 32, 0, 90 + N)
+    P["means"][:] = torch.tensor([0.0, 0.0, 4.0], dtype=torch.float64) + 0.01 * torch.randn(N, 3, dtype=torch.float64)
+    P["log_scales"][:] = -6.0
+    D = to_dev(P, dev)
+    acam = amd_cam(cam)
+    sp = ops.project_fwd(acam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], 0)
+    gb0, ts0, sg0, st0 = ops.bin_sort(acam, sp.clone(), ops.IntersectBudget(capacity=40 * N, sync=False))
+    b = ops.IntersectBudget(capacity=40 * N, sync=False, max_list_hint=hint)
+    sp1 = sp.clone()
+    gb, ts, sg, st = ops.bin_sort(acam, sp1, b)
+    n, ovf, need, longest = b.last_status4.tolist()
+    lens = (ts0[1:] - ts0[:-1]).cpu().numpy()
+    assert longest == lens.max() and n == int(st0.tolist()[0])
+    assert torch.equal(ts, ts0)
+    if ok:
+        assert ovf == 0 and int(b.sticky.item()) == 0
+        assert torch.equal(sg[:n], sg0[:n])
+        assert b.check() == n
+    else:
+        assert ovf == 1 and int(b.sticky.item()) == 1
+        a, r = sg[:n].cpu().numpy(), sg0[:n].cpu().numpy()
+        starts = ts0.cpu().numpy()
+        for t in np.nonzero(lens)[0]:          # every list is a permutation of the tile's ids; short lists are sorted
+            x, y = a[starts[t]:starts[t + 1]], r[starts[t]:starts[t + 1]]
+            assert np.array_equal(np.sort(x), np.sort(y))
+            if lens[t] <= 1024:
+                assert np.array_equal(x, y)
+        # the compositing kernels run on the void frame without faulting
+        rgb, depth, fT, _ = ops.rasterize_fwd(acam, sp1, sg, ts)
+        ops.rasterize_bwd(acam, sp1, gb, sg, ts, rgb, depth, fT, v_rgb=torch.ones_like(rgb))
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="max_list_hint"):
+            b.check()
+
+
 def test_sort_fallback_global(dev):
     """> 16384 Gaussians in one tile exercises the global-memory sort fallback."""
     from touch_gs_amd import ops

@@ -58,11 +58,11 @@ SIGNATURES = {
     "tgs_project_fwd": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "tgs_sh_fwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P]),
     "tgs_sh_bwd": (C.c_int, [_I, _I, _I, _P, _P, _P, _P]),
-    "tgs_bin_sort": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, C.c_int64, _P, _P, _P, C.c_int64, _P, _P, _P, _P]),
+    "tgs_bin_sort": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, C.c_int64, _P, _P, _P, C.c_int64, _P, _P, _P, C.c_int32, _P]),
     "tgs_project_bin_sort": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, C.c_int64, _P, _P,
-                                       _P, C.c_int64, _P, _P, _P, _P]),
+                                       _P, C.c_int64, _P, _P, _P, C.c_int32, _P]),
     "tgs_project_bin_sort_colors": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, C.c_int64, _P,
-                                              _P, _P, C.c_int64, _P, _P, _P, _P, _P, C.c_int32, _P]),
+                                              _P, _P, C.c_int64, _P, _P, _P, C.c_int32, _P, _P, C.c_int32, _P]),
     "tgs_rasterize_fwd": (C.c_int, [C.POINTER(TgsCamera), _P, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, C.POINTER(TgsRasterOpts), _P]),
     "tgs_set_raster_variant": (C.c_int, [_I, _I]),
     "tgs_set_k7_quad": (C.c_int, [_I, _I]),
@@ -81,7 +81,7 @@ SIGNATURES = {
     "tgs_adam_geom_project_next": (C.c_int, [C.POINTER(TgsCamera), _I, _I, _I, _P, _P, _P, _P, C.POINTER(TgsAdamSpec), C.c_float,
                                              _P, _P, C.c_int32, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _I, _P]),
     "tgs_project_bin_sort_front": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, C.c_int64, _P,
-                                             _P, _P, C.c_int64, _P, _P, _P, _P, C.c_int32, C.POINTER(TgsCamera), _P, _P, _P]),
+                                             _P, _P, C.c_int64, _P, _P, _P, C.c_int32, _P, C.c_int32, C.POINTER(TgsCamera), _P, _P, _P]),
     "tgs_front_can_clear_next": (C.c_int, [_I, _I, _I]),
     "tgs_project_bwd_color": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I] + [_P] * 11),
     "tgs_project_bwd_color_rows": (C.c_int, [C.POINTER(TgsCamera), _I, _I, _I, _P, _P, _P, _P, _P, _I, _I] + [_P] * 11),

@@ -63,15 +63,36 @@ __global__ __launch_bounds__(TGS_GROUP) void k_tile_count(
 // but visits it longest list first.  With ~2 tiles per resident wave slot the spatial order leaves
 // the last slots running alone for a whole tile; longest-first shortens that tail (K6 -3 %, K7 -4 %,
 // alternating same-box runs after clock warm-up).
+//
+// Front prefetch (tgs_project_bin_sort_front): this frame's K1 ran inside the previous step's fused optimizer kernel,
+// which stores `tag_expect` into *front_tag as its last act.  A kernel that was voided by its overflow guard leaves the
+// old tag -- and the sticky overflow word raised, which empties this frame anyway: a mismatch therefore simply VOIDS
+// the frame (empty lists, status[1] = 1, sticky raised; every workgroup takes the decision from the same two words).
+// Rounds 3-4 spent a launch of N idle threads on it (k_project_fwd_unless_done: 4.9 us at cfg3) that re-ran K1 for a
+// frame nothing would ever look at.  The n_clear workgroups behind the order blocks clear the counters and the status
+// word of the frame AFTER this one (whose K1 this step's optimizer kernel will run) -- that launch's other job.
+struct ScanFront {
+  const int32_t* tag;      // NULL: no front prefetch involved
+  int32_t tag_expect;
+  int32_t* sticky;         // raised on a mismatch (may be NULL)
+  int32_t* next_cursor;    // NULL: nothing to clear
+  int32_t* next_status;
+  int next_T, n_clear, n_order8;
+};
 __global__ __launch_bounds__(1024) void k_scan_tiles(int T, int NB, int32_t* __restrict__ tile_count,
                                                      int32_t* __restrict__ tile_start,
                                                      int32_t* __restrict__ status,
                                                      int32_t* __restrict__ tile_order,
-                                                     const float* __restrict__ splats, int N) {
+                                                     const float* __restrict__ splats, int N, ScanFront fr) {
   __shared__ int wave_tot[16];
   __shared__ int wave_mg[16];
   __shared__ int s_base;
   const int tid = threadIdx.x;
+  const bool voided = fr.tag && *fr.tag != fr.tag_expect;
+  if ((int)blockIdx.x >= NB + fr.n_order8 && (int)blockIdx.x < NB + fr.n_order8 + fr.n_clear) {
+    clear_counters_elem(((int)blockIdx.x - NB - fr.n_order8) * 1024 + tid, fr.next_cursor, fr.next_T, fr.next_status, fr.sticky);
+    return;
+  }
   if ((int)blockIdx.x == (int)gridDim.x - 1) {
     // The LAST workgroup writes the status word, beside the scan (it needs nothing from it):
     // status[0]: the frame's intersection count = the 8 per-XCD allocators + the pairs that found no
@@ -97,8 +118,13 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int T, int NB, int32_t* __r
       for (int x = 0; x < TGS_XCC; x++)   // allocated (+ overshoot of failed attempts, word 2) + pairs that found no room
         n += (long long)xa[x * TGS_ALLOC_STRIDE] - xa[x * TGS_ALLOC_STRIDE + 2] + xa[x * TGS_ALLOC_STRIDE + 1];
       const long long need = n + (long long)TGS_XCC * mg;
-      status[0] = (int32_t)min(status[1] != 0 ? need : n, 0x7fffffffll);
+      if (voided) {                 // (the scan workgroups read the tag themselves: this store is for the later kernels)
+        status[1] = 1;
+        if (fr.sticky) *fr.sticky = 1;
+      }
+      status[0] = (int32_t)min((status[1] != 0 || voided) ? need : n, 0x7fffffffll);
       status[2] = (int32_t)min(need, 0x7fffffffll);
+      status[3] = 0;                // longest list of the frame: k_fill_bins fills it in (no Gaussians: no lists)
     }
     return;
   }
@@ -110,7 +136,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int T, int NB, int32_t* __r
     for (int i = tid; i < per; i += 1024) tile_order[i * TGS_XCDS + x] = tgs_xcd_slot_tile(T, x, i);
     return;
   }
-  const bool overflow = status[1] != 0;
+  const bool overflow = status[1] != 0 || voided;
   int32_t* __restrict__ sub_start = tile_count + TGS_XCC * T;
   int32_t* __restrict__ agg = sub_start + TGS_XCC * T;     // [NB] aggregate + 1 of every scan workgroup, 0 = not yet
   const int b = blockIdx.x, t = b * 1024 + tid;
@@ -175,7 +201,9 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int T, int NB, int32_t* __r
 __global__ __launch_bounds__(TGS_GROUP) void k_fill_bins(
     CamK cam, int N, const float* __restrict__ splats, const int32_t* __restrict__ group_base,
     const int32_t* __restrict__ sub_start, const int32_t* __restrict__ rank,
-    uint2* __restrict__ pairs, const int32_t* __restrict__ status) {
+    uint2* __restrict__ pairs, int32_t* __restrict__ status, const int32_t* __restrict__ max_list) {
+  // status[3] = the frame's longest list (complete: the scan launch has ended): what a caller sizes `max_list_hint` from
+  if (blockIdx.x == 0 && threadIdx.x == 0) status[3] = *max_list;
   if (status[1]) return;
   const int T = cam.TW * cam.TH;
   __shared__ GroupScan S;
@@ -373,9 +401,14 @@ __device__ __forceinline__ void xcd_order_regs(int T, int x, int c, int chunk,
 }
 
 // common classes: lists <= 512 (8 keys per lane) and <= 1024 (16 keys per lane); one wave per tile
+// `sorted_up_to`: the longest list some launch of this frame sorts (1024 / 4096 / INT_MAX by the caller's
+// max_list_hint).  A longer list means the caller's hint was wrong: the wave copies the ids UNSORTED -- valid indices,
+// so the compositing kernels run on without faulting -- and raises the overflow flag and the sticky word: the frame
+// is void exactly like one that overflowed its capacity, status[3] tells the caller what the hint should have been.
 __global__ __launch_bounds__(TGS_WAVE) void k_sort_tiles_wave(
     int T, const int32_t* __restrict__ tile_start, const u64* __restrict__ pairs,
-    int32_t* __restrict__ sorted_gid, int32_t* __restrict__ tile_order, int n_order, int chunk) {
+    int32_t* __restrict__ sorted_gid, int32_t* __restrict__ tile_order, int n_order, int chunk,
+    int sorted_up_to, int32_t* __restrict__ status, int32_t* __restrict__ sticky) {
   // the first n_order (0 or 8 x chunks per XCD) blocks build the K6 / K7 schedule of one chunk of one
   // XCD's slots each; they are the longest blocks of the launch, so they are dispatched first
   if ((int)blockIdx.x < n_order) {
@@ -386,6 +419,14 @@ __global__ __launch_bounds__(TGS_WAVE) void k_sort_tiles_wave(
   const int s = tile_start[tile];
   const int n = tile_start[tile + 1] - s;
   const int lane = threadIdx.x;
+  if (n > sorted_up_to) {
+    for (int i = lane; i < n; i += TGS_WAVE) sorted_gid[s + i] = (int)(pairs[s + i] & 0xffffffffull);
+    if (lane == 0) {
+      status[1] = 1;
+      if (sticky) *sticky = 1;
+    }
+    return;
+  }
   if (n <= 0 || n > 1024) return;
   if (n == 1) {
     if (lane == 0) sorted_gid[s] = (int)(pairs[s] & 0xffffffffull);
@@ -489,7 +530,7 @@ extern "C" size_t tgs_sort_scratch_bytes(int64_t capacity) {
 int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* group_base,
                    int32_t* tile_start, int64_t tile_start_len, int32_t* tile_cursor, int32_t* sorted_gid,
                    int32_t* tile_order, int64_t capacity, void* scratch, int32_t* status,
-                   hipStream_t s) {
+                   int32_t* sticky_overflow, int32_t max_list_hint, const BinFront* front, hipStream_t s) {
   const int T = k.TW * k.TH;
   TGS_CHECK_ARG(tile_start_len >= (int64_t)T + 1 + TGS_TILE_START_SCRATCH,
                 "tile_start buffer shorter than tgs_tile_start_len(W, H) (the scan zeroes the rasterizer's scratch behind the starts)");
@@ -504,23 +545,42 @@ int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* gro
   const int chunk = tgs_band_slots(T), n_sub = tgs_band_count(T);
   const int n_order = order_in_sort ? TGS_XCDS * n_sub : 0;
   (void)per;
-  hipLaunchKernelGGL(k_scan_tiles, dim3(NB + ((tile_order && !order_in_sort) ? 8 : 0) + 1), dim3(1024), 0, s, T, NB,
-                     tile_cursor, tile_start, status, tile_order, splats, N);
+  ScanFront fr;
+  fr.tag = front ? front->tag_word : nullptr;
+  fr.tag_expect = front ? front->tag_expect : 0;
+  fr.sticky = sticky_overflow;
+  fr.next_cursor = front ? front->next_tile_cursor : nullptr;
+  fr.next_status = front ? front->next_status : nullptr;
+  fr.next_T = front ? front->next_T : 0;
+  fr.n_clear = fr.next_cursor ? (max(TGS_XCC * fr.next_T, 2) + 1023) / 1024 : 0;
+  fr.n_order8 = (tile_order && !order_in_sort) ? 8 : 0;
+  hipLaunchKernelGGL(k_scan_tiles, dim3(NB + fr.n_order8 + fr.n_clear + 1), dim3(1024), 0, s, T, NB,
+                     tile_cursor, tile_start, status, tile_order, splats, N, fr);
   TGS_CHECK_LAUNCH();
   if (G > 0) {
-    hipLaunchKernelGGL(k_fill_bins, dim3(G), dim3(TGS_GROUP), 0, s, k, N, splats, group_base,
-                       tile_cursor + TGS_XCC * T, sc.rank, (uint2*)sc.pairs, status);
-    TGS_CHECK_LAUNCH();
     const int32_t* max_list = tile_cursor + 2 * TGS_XCC * T + TGS_SCAN_WGS;
+    hipLaunchKernelGGL(k_fill_bins, dim3(G), dim3(TGS_GROUP), 0, s, k, N, splats, group_base,
+                       tile_cursor + TGS_XCC * T, sc.rank, (uint2*)sc.pairs, status, max_list);
+    TGS_CHECK_LAUNCH();
+    // The long-list classes are launched only if the caller's bound on the frame's longest list allows such lists
+    // (max_list_hint < 0: no bound, every class): an unused class launch returns at once but still costs ~4.6 us of
+    // the stream (profiles/r4_b_reconcile.json: 9.3 us per step at cfg3 for two launches that never had a list).
+    const bool want_wg4 = max_list_hint < 0 || max_list_hint > 1024;
+    const bool want_huge = max_list_hint < 0 || max_list_hint > 4096;
+    const int sorted_up_to = want_huge ? 0x7fffffff : (want_wg4 ? 4096 : 1024);
     hipLaunchKernelGGL(k_sort_tiles_wave, dim3(T + n_order), dim3(TGS_WAVE), 0, s, T, tile_start,
-                       sc.pairs, sorted_gid, tile_order, n_order, chunk);
+                       sc.pairs, sorted_gid, tile_order, n_order, chunk, sorted_up_to, status, sticky_overflow);
     TGS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_sort_tiles_wg4, dim3(T < 2048 ? T : 2048), dim3(TGS_WAVE * 4), 0, s, T, tile_start,
-                       sc.pairs, sorted_gid, max_list);
-    TGS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_sort_tiles_huge, dim3(T < 256 ? T : 256), dim3(1024), 0, s, T, tile_start, sc.pairs,
-                       sc.fb, sorted_gid, max_list);
-    TGS_CHECK_LAUNCH();
+    if (want_wg4) {
+      hipLaunchKernelGGL(k_sort_tiles_wg4, dim3(T < 2048 ? T : 2048), dim3(TGS_WAVE * 4), 0, s, T, tile_start,
+                         sc.pairs, sorted_gid, max_list);
+      TGS_CHECK_LAUNCH();
+    }
+    if (want_huge) {
+      hipLaunchKernelGGL(k_sort_tiles_huge, dim3(T < 256 ? T : 256), dim3(1024), 0, s, T, tile_start, sc.pairs,
+                         sc.fb, sorted_gid, max_list);
+      TGS_CHECK_LAUNCH();
+    }
   }
   return TGS_OK;
 }
@@ -528,7 +588,7 @@ int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* gro
 extern "C" int tgs_bin_sort(const TgsCamera* cam, int N, float* splats, int32_t* group_base,
                             int32_t* tile_start, int64_t tile_start_len, int32_t* tile_cursor, int32_t* sorted_gid,
                             int32_t* tile_order, int64_t capacity, void* scratch, int32_t* status,
-                            int32_t* sticky_overflow, void* stream) {
+                            int32_t* sticky_overflow, int32_t max_list_hint, void* stream) {
   TGS_CHECK_ARG(camera_ok(cam), "bad camera");
   TGS_CHECK_ARG(N >= 0 && capacity >= 0, "negative size");
   TGS_CHECK_ARG(capacity < (1ll << 31), "capacity must be < 2^31");
@@ -550,5 +610,5 @@ extern "C" int tgs_bin_sort(const TgsCamera* cam, int N, float* splats, int32_t*
     TGS_CHECK_LAUNCH();
   }
   return tgs_bin_finish(k, N, splats, group_base, tile_start, tile_start_len, tile_cursor, sorted_gid, tile_order,
-                        capacity, scratch, status, s);
+                        capacity, scratch, status, sticky_overflow, max_list_hint, nullptr, s);
 }

@@ -393,27 +393,6 @@ __global__ __launch_bounds__(256) void k_project_fwd_colors(
                                        splats, radii, group_base, tile_count, rank, status, capacity, sticky, &S);
 }
 
-// K1 of a frame whose records and tile counts the previous step's fused optimizer kernel may already have
-// produced (front prefetch): nothing to do if its tag word says so, else the full K1 from the SH rows (the counters
-// are clear in that case: the fused kernel returned at its overflow guard before touching them).
-template <int DEG>
-__global__ __launch_bounds__(256) void k_project_fwd_unless_done(
-    CamK cam, int N, const float* __restrict__ means, const float* __restrict__ log_scales,
-    const float* __restrict__ quats, const float* __restrict__ opac_logit,
-    const float* __restrict__ sh, int sh_stride,
-    float* __restrict__ splats, int32_t* __restrict__ radii, int32_t* __restrict__ group_base,
-    int32_t* __restrict__ tile_count, int32_t* __restrict__ rank, int32_t* __restrict__ status,
-    long long capacity, int32_t* __restrict__ sticky, const int32_t* __restrict__ front_tag,
-    int32_t tag_expect, int32_t* __restrict__ next_cursor, int next_T, int32_t* __restrict__ next_status) {
-  __shared__ GroupScan S;
-  // this launch has N otherwise idle threads: they clear the counters of the frame AFTER this one (whose K1 this
-  // step's optimizer kernel will run), which saves that call its own clearing launch
-  if (next_cursor) clear_counters_elem(blockIdx.x * 256 + threadIdx.x, next_cursor, next_T, next_status, sticky);
-  if (*front_tag == tag_expect) return;
-  project_fwd_body<DEG, true, false>(cam, N, means, log_scales, quats, opac_logit, sh, sh_stride, nullptr,
-                                     splats, radii, group_base, tile_count, rank, status, capacity, sticky, &S);
-}
-
 // Data-parallel step: Adam on the 11 geometry parameters of every Gaussian from the all-reduced gradients AND the
 // next view's K1 on the result (front prefetch of the data-parallel form: there the optimizer is not fused with K8,
 // and the SH rows were stepped just before by the gathered-SH kernel, so the colour comes from the SH rows as in the
@@ -1339,55 +1318,41 @@ extern "C" int tgs_adam_geom_project_next(const TgsCamera* next_cam, int N, int 
 
 // Can tgs_project_bin_sort_front (N Gaussians) clear the counters of a W x H frame on the side?
 extern "C" int tgs_front_can_clear_next(int N, int W, int H) {
-  const int T = ((W + TGS_BLOCK - 1) / TGS_BLOCK) * ((H + TGS_BLOCK - 1) / TGS_BLOCK);
-  return N > 0 && (long long)((N + 255) / 256) * 256 >= max(TGS_XCC * T, 2);
+  // the scan launch brings its own workgroups for the clearing job (binning.hip: ScanFront.n_clear): any N > 0 will do
+  (void)W; (void)H;
+  return N > 0;
 }
 
-// The rest of a frame whose K1 tgs_project_bwd_adam_next_front (tag_word == tag_expect) has run: scan / fill /
-// sort.  If the tag does not match (the fused kernel was voided by its overflow guard) K1 runs here, from the SH rows.
+// The rest of a frame whose K1 tgs_project_bwd_adam_next_front (tag_word == tag_expect) has run: scan / fill / sort.
+// If the tag does not match (the fused kernel was voided by its overflow guard, which also left the sticky word raised)
+// the scan launch voids the frame: empty lists, status[1] = 1 (binning.hip, ScanFront) -- no K1 is re-run for a frame
+// nobody will look at.  The caller replays through tgs_project_bin_sort once it has dealt with the overflow.
 extern "C" int tgs_project_bin_sort_front(const TgsCamera* cam, int N, const float* means,
                                           const float* log_scales, const float* quats,
                                           const float* opac_logit, const float* sh, int sh_stride,
                                           int sh_deg, float* splats, int32_t* radii, int32_t* group_base,
                                           int32_t* tile_start, int64_t tile_start_len, int32_t* tile_cursor, int32_t* sorted_gid,
                                           int32_t* tile_order, int64_t capacity, void* scratch,
-                                          int32_t* status, int32_t* sticky_overflow,
+                                          int32_t* status, int32_t* sticky_overflow, int32_t max_list_hint,
                                           const int32_t* tag_word, int32_t tag_expect,
                                           const TgsCamera* next_cam, int32_t* next_tile_cursor,
                                           int32_t* next_status, void* stream) {
   TGS_CHECK_ARG(camera_ok(cam), "bad camera");
   TGS_CHECK_ARG(N > 0 && capacity >= 0 && capacity < (1ll << 31), "bad size");
-  int next_T = 0;
+  BinFront front;
+  front.tag_word = tag_word; front.tag_expect = tag_expect;
+  front.next_tile_cursor = next_tile_cursor; front.next_status = next_status; front.next_T = 0;
   if (next_tile_cursor) {
     TGS_CHECK_ARG(camera_ok(next_cam) && next_status, "next frame's counters without its camera / status word");
     const CamK kn = make_camk(next_cam);
-    next_T = kn.TW * kn.TH;
-    TGS_CHECK_ARG((long long)((N + 255) / 256) * 256 >= max(TGS_XCC * next_T, 2),
-                  "too few Gaussians to clear the next frame's counters (tgs_front_can_clear_next)");
+    front.next_T = kn.TW * kn.TH;
   }
   TGS_CHECK_ARG(group_base && tile_start && tile_cursor && sorted_gid && scratch && status && tag_word, "null pointer");
-  TGS_CHECK_ARG(means && log_scales && quats && opac_logit && sh && splats, "null pointer (the SH rows stay the fallback)");
-  TGS_CHECK_ARG(sh_deg >= 0 && sh_deg <= 3 && sh_stride >= (sh_deg + 1) * (sh_deg + 1), "bad SH degree / stride");
+  TGS_CHECK_ARG(splats, "null pointer");
+  (void)means; (void)log_scales; (void)quats; (void)opac_logit; (void)sh; (void)sh_stride; (void)sh_deg; (void)radii;
   const CamK k = make_camk(cam);
-  // checked BEFORE the first launch (tgs_bin_finish checks again): nothing is enqueued for a short buffer
-  TGS_CHECK_ARG(tile_start_len >= (int64_t)k.TW * k.TH + 1 + TGS_TILE_START_SCRATCH, "tile_start buffer shorter than tgs_tile_start_len(W, H)");
-  hipStream_t s = (hipStream_t)stream;
-  const BinScratch sc = carve_scratch(scratch, capacity);
-  const dim3 grid((N + 255) / 256), block(256);
-#define LAUNCH_U(D)                                                                                   \
-  hipLaunchKernelGGL((k_project_fwd_unless_done<D>), grid, block, 0, s, k, N, means, log_scales, quats, \
-                     opac_logit, sh, sh_stride, splats, radii, group_base, tile_cursor, sc.rank, status, \
-                     (long long)capacity, sticky_overflow, tag_word, tag_expect, next_tile_cursor, next_T, next_status)
-  switch (sh_deg) {
-    case 0: LAUNCH_U(0); break;
-    case 1: LAUNCH_U(1); break;
-    case 2: LAUNCH_U(2); break;
-    default: LAUNCH_U(3); break;
-  }
-#undef LAUNCH_U
-  TGS_CHECK_LAUNCH();
   return tgs_bin_finish(k, N, splats, group_base, tile_start, tile_start_len, tile_cursor, sorted_gid, tile_order,
-                        capacity, scratch, status, s);
+                        capacity, scratch, status, sticky_overflow, max_list_hint, &front, (hipStream_t)stream);
 }
 
 // K1 + K3a fused, then scan / fill / sort: the whole front half of a frame in one call.
@@ -1397,7 +1362,7 @@ static int project_bin_sort_impl(const TgsCamera* cam, int N, const float* means
                                  int sh_deg, float* splats, int32_t* radii, int32_t* group_base,
                                  int32_t* tile_start, int64_t tile_start_len, int32_t* tile_cursor, int32_t* sorted_gid,
                                  int32_t* tile_order, int64_t capacity, void* scratch,
-                                 int32_t* status, int32_t* sticky_overflow, const float* colors_in,
+                                 int32_t* status, int32_t* sticky_overflow, int32_t max_list_hint, const float* colors_in,
                                  const int32_t* color_tag, int32_t tag_expect, void* stream) {
   TGS_CHECK_ARG(camera_ok(cam), "bad camera");
   TGS_CHECK_ARG(N >= 0 && capacity >= 0 && capacity < (1ll << 31), "bad size");
@@ -1446,7 +1411,7 @@ static int project_bin_sort_impl(const TgsCamera* cam, int N, const float* means
     TGS_CHECK_LAUNCH();
   }
   return tgs_bin_finish(k, N, splats, group_base, tile_start, tile_start_len, tile_cursor, sorted_gid, tile_order,
-                        capacity, scratch, status, s);
+                        capacity, scratch, status, sticky_overflow, max_list_hint, nullptr, s);
 }
 
 extern "C" int tgs_project_bin_sort(const TgsCamera* cam, int N, const float* means,
@@ -1455,10 +1420,10 @@ extern "C" int tgs_project_bin_sort(const TgsCamera* cam, int N, const float* me
                                     int sh_deg, float* splats, int32_t* radii, int32_t* group_base,
                                     int32_t* tile_start, int64_t tile_start_len, int32_t* tile_cursor, int32_t* sorted_gid,
                                     int32_t* tile_order, int64_t capacity, void* scratch,
-                                    int32_t* status, int32_t* sticky_overflow, void* stream) {
+                                    int32_t* status, int32_t* sticky_overflow, int32_t max_list_hint, void* stream) {
   return project_bin_sort_impl(cam, N, means, log_scales, quats, opac_logit, sh, sh_stride, sh_deg, splats,
                                radii, group_base, tile_start, tile_start_len, tile_cursor, sorted_gid, tile_order, capacity,
-                               scratch, status, sticky_overflow, nullptr, nullptr, 0, stream);
+                               scratch, status, sticky_overflow, max_list_hint, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int tgs_project_bin_sort_colors(const TgsCamera* cam, int N, const float* means,
@@ -1468,13 +1433,13 @@ extern "C" int tgs_project_bin_sort_colors(const TgsCamera* cam, int N, const fl
                                            int32_t* group_base, int32_t* tile_start, int64_t tile_start_len,
                                            int32_t* tile_cursor, int32_t* sorted_gid,
                                            int32_t* tile_order, int64_t capacity, void* scratch,
-                                           int32_t* status, int32_t* sticky_overflow,
+                                           int32_t* status, int32_t* sticky_overflow, int32_t max_list_hint,
                                            const float* colors_in, const int32_t* color_tag,
                                            int32_t tag_expect, void* stream) {
   TGS_CHECK_ARG(sh && colors_in && color_tag, "null pointer (the SH rows stay the fallback)");
   return project_bin_sort_impl(cam, N, means, log_scales, quats, opac_logit, sh, sh_stride, sh_deg, splats,
                                radii, group_base, tile_start, tile_start_len, tile_cursor, sorted_gid, tile_order, capacity,
-                               scratch, status, sticky_overflow, colors_in, color_tag, tag_expect, stream);
+                               scratch, status, sticky_overflow, max_list_hint, colors_in, color_tag, tag_expect, stream);
 }
 
 extern "C" int tgs_sh_fwd(int N, int sh_deg, int sh_stride, const float* dirs, const float* coeffs,

@@ -189,6 +189,15 @@ __device__ __forceinline__ float stop_code(int pos) { return __uint_as_float(0xC
 __device__ __forceinline__ int stop_of(float smax) {
   return smax > 0.f ? TGS_NO_STOP : (int)(__float_as_uint(smax) & 0x3fffffffu);
 }
+// 4x4-block form: the code of a stop at entry j (< 64) of the CURRENT batch -- 0xE0000000 | j (= -2^65 (1 + ..): dead
+// like stop_code) -- and, at the end of the batch, its conversion to stop_code(batch base + j).  "Fresh" codes are the
+// words 0xE00000xx; the out-of-image sentinel -3e38 = 0xFF61B1E6 and finished codes 0xC....... are left alone, and
+// list positions stay below 2^29.
+__device__ __forceinline__ float batch_stop_code(int j) { return __uint_as_float(0xE0000000u | (unsigned)j); }
+__device__ __forceinline__ float finish_batch_stop(float smax, int batch_rel) {
+  const unsigned b = __float_as_uint(smax);
+  return (b & 0xffffff00u) == 0xE0000000u ? stop_code(batch_rel + (int)(b & 0xffu)) : smax;
+}
 
 // The frame's deepest walk -- how far into its list the busiest tile's pixels reach, = the length of K7's longest
 // chain -- is what decides whether K7 splits its tiles over four waves (frame_is_chain_bound).  Every K6 block folds
@@ -227,10 +236,16 @@ __device__ __forceinline__ void publish_walk(const int32_t* __restrict__ tile_st
 //          sits next to the compare so that it IS the compare's scalar result (no extra VALU)
 //   okb  : WANT_OK = 1: lane mask of `ok`; WANT_OK = 2: lane mask of `go` (both ballots sit next to their
 //          compares, so they ARE the compares' scalar results: no extra VALU)
-//   stopv: what smax becomes when THIS Gaussian stops the pixel -- stop_code(list position): a negative
-//          float (so the pixel is dead for every later `s <= smax`, s >= 0 up to rounding) whose low 30
-//          bits are the list position; the forward stores it per pixel (stop_pos) and the backward, which
-//          walks the list back to front, starts each pixel there.  One v_cndmask, as with a literal.
+//   stopv: what smax becomes when THIS Gaussian stops the pixel -- a negative float (so the pixel is dead for
+//          every later `s <= smax`, s >= 0 up to rounding) that carries the list position: stop_code(position)
+//          where the position is wave-uniform (quadrant forms: an SGPR operand), batch_stop_code(j) in the
+//          4x4-block form, whose rows walk different entries -- there the batch-relative index j is the lane's
+//          own (it addressed the record) and one v_or with a literal makes the code; the batch's base is added
+//          once per batch (finish_batch_stops).  The forward stores the position per pixel (stop_pos) and the
+//          backward, which walks the list back to front, starts each pixel there.
+//          Round 4 kept stop_code(position) in a spare slot of the staged record instead: no VALU at all, but the
+//          block form's per-lane record read grew from 40 to 44 B (ds_read_b96 for b64) and that loop sits at ~85 %
+//          of the CU's LDS bandwidth: K6 +10 % (156 vs 141.7 us 8-view mean, same box, profiles/r5_ab_runs.txt).
 template <bool MAYCLAMP = true, int WANT_OK = 0>
 __device__ __forceinline__ float blend_step(float s, float& T, float& smax, float& Tnew, bool& go,
                                             unsigned long long& okb, float stopv = -3.0e38f) {
@@ -242,11 +257,7 @@ __device__ __forceinline__ float blend_step(float s, float& T, float& smax, floa
   const bool above = Tnew > T_STOP;
   if constexpr (WANT_OK == 2) okb = __builtin_amdgcn_ballot_w64(ok) & __builtin_amdgcn_ballot_w64(above);
   go = ok & above;
-#ifdef TGS_AB_LITERAL_STOP
-  smax = (ok != go) ? -3.0e38f : smax;
-#else
   smax = (ok != go) ? stopv : smax;  // stop (ok and not go; go implies ok): T' <= 1e-4, this Gaussian excluded
-#endif
   return go ? al : 0.f;
 }
 
@@ -293,8 +304,7 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
       const float4 q0 = ld4(r), q1 = ld4(r + 4), q2 = ld4(r + 8);
       float gx, gy;
       centre_rel(q0, q2, tx, ty, cam.pix_center, gx, gy);
-      TileRec t = make_tile_rec(q0, q1, q2, gx, gy);
-      t.c.z = stop_code(base - start + lane);
+      const TileRec t = make_tile_rec(q0, q1, q2, gx, gy);
       recs[lane * 3] = t.a; recs[lane * 3 + 1] = t.b; recs[lane * 3 + 2] = t.c;
       my_mask = __float_as_uint(t.c.w);
     }
@@ -325,7 +335,7 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
           const float s = eval_s(qa, qb, pc, k);
           float Tn; bool go;
           unsigned long long okb = 0ull;
-          const float al = blend_step<true, WANT_OK ? 1 : 0>(s, T[k], smax[k], Tn, go, okb, qc.z);
+          const float al = blend_step<true, WANT_OK ? 1 : 0>(s, T[k], smax[k], Tn, go, okb, stop_code(pos));
           const float w = al * T[k];
           Cr[k] = fmaf(w, qb.w, Cr[k]); Cg[k] = fmaf(w, qc.x, Cg[k]);
           Cb[k] = fmaf(w, qc.y, Cb[k]); D[k] = fmaf(w, qb.z, D[k]);
@@ -350,14 +360,13 @@ __global__ __launch_bounds__(64) void k_raster_fwd(
       out_depth[p] = D[k];
       final_T[p] = T[k];
       if (WANT_IDX) final_idx[p] = last[k];
-#ifndef TGS_AB_NO_STOPSTORE
       if (stop_pos) stop_pos[p] = stop_of(smax[k]);
-#endif
     }
   }
-#ifndef TGS_AB_NO_PUBLISH   // (A/B switch, tools/abn.py: what the walk statistics cost K6)
-  publish_walk(tile_start, T_total, smax, end - start, lane);
-#endif
+  // the walk statistics are K7's (chain-bound test): a render-only forward (no stop_pos) publishes nothing -- and
+  // does not disturb the sums a training forward on the same lists has left (they accumulate: one publishing forward
+  // per backward; 1.5 us of K6 at cfg3)
+  if (stop_pos) publish_walk(tile_start, T_total, smax, end - start, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -459,8 +468,7 @@ __device__ __forceinline__ void raster_fwd_quadrant(
       const float4 q0 = ld4(r), q1 = ld4(r + 4), q2 = ld4(r + 8);
       float gx, gy;
       centre_rel(q0, q2, tx, ty, cam.pix_center, gx, gy);
-      TileRec t = make_tile_rec(q0, q1, q2, gx, gy);
-      t.c.z = stop_code(base - start + lane);
+      const TileRec t = make_tile_rec(q0, q1, q2, gx, gy);
       recs[lane * 3] = t.a; recs[lane * 3 + 1] = t.b; recs[lane * 3 + 2] = t.c;
       my_mask = __float_as_uint(t.c.w);
     }
@@ -477,7 +485,7 @@ __device__ __forceinline__ void raster_fwd_quadrant(
       s = fmaf(qb.y, pvv, s);
       float Tn; bool go;
       unsigned long long okb = 0ull;
-      const float al = blend_step<true, 0>(s, T, smax, Tn, go, okb, qc.z);
+      const float al = blend_step<true, 0>(s, T, smax, Tn, go, okb, stop_code(base - start + j));
       const float w = al * T;
       Cr = fmaf(w, qb.w, Cr); Cg = fmaf(w, qc.x, Cg);
       Cb = fmaf(w, qc.y, Cb); D = fmaf(w, qb.z, D);
@@ -497,7 +505,7 @@ __device__ __forceinline__ void raster_fwd_quadrant(
   }
   // the quadrant's walk: the maximum is the tile's once all four have reported; a quarter each into the sum
   int wl = wave_minmax_i<true>(inb ? min(stop_of(smax), end - start) : 0);
-  if (lane == 0 && wl > 0) {
+  if (lane == 0 && wl > 0 && stop_pos) {   // (render-only forwards publish nothing, as in the unsplit forms)
     const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & (TGS_WALK_WORDS - 1));
     atomicMax(frame_scratch(tile_start) + TGS_WALK_AT(T_total, xcc), wl);
     atomicAdd(frame_scratch(tile_start) + TGS_WALKSUM_AT(T_total, xcc), (wl + 3) >> 2);
@@ -597,8 +605,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TGS_BLK_WAVE
       const float4 q0 = ld4(r), q1 = ld4(r + 4), q2 = ld4(r + 8);
       float gx, gy;
       centre_rel(q0, q2, tx, ty, cam.pix_center, gx, gy);
-      TileRec t = make_tile_rec<false>(q0, q1, q2, gx, gy);
-      t.c.z = stop_code(base - start + lane);
+      const TileRec t = make_tile_rec<false>(q0, q1, q2, gx, gy);
       recs[lane * 3] = t.a; recs[lane * 3 + 1] = t.b; recs[lane * 3 + 2] = t.c;
       my_mask = block_mask16(gx, gy, q1.x, q1.y, q1.z, -__log2f(q0.w)) & live16;
       my_opac = q0.w;
@@ -631,7 +638,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TGS_BLK_WAVE
             const float s = eval_s(qa, qb, pc, k);
             float Tn; bool go;
             unsigned long long okb = 0ull;
-            const float al = blend_step<MAYCLAMP, 0>(s, T[k], smax[k], Tn, go, okb, qc.z);
+            const float al = blend_step<MAYCLAMP, 0>(s, T[k], smax[k], Tn, go, okb, batch_stop_code(j));
             const float w = al * T[k];
             Cr[k] = fmaf(w, qb.w, Cr[k]); Cg[k] = fmaf(w, qc.x, Cg[k]);
             Cb[k] = fmaf(w, qc.y, Cb[k]); D[k] = fmaf(w, qb.z, D[k]);
@@ -644,6 +651,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TGS_BLK_WAVE
     // batches without an opacity above CLAMP_FREE_OPACITY (nearly all) run the copy of the loops without the
     // v_min of the 0.999 clamp (identity there: bit-identical) -- a per-BATCH choice, no branch inside the loops
     if (clampy) walk(std::true_type{}); else walk(std::false_type{});   // 144 -> 139 us at cfg3 (same box)
+    // pixels that stopped in this batch: batch-relative code -> list position (4 selects per batch, not per entry)
+#pragma unroll
+    for (int k = 0; k < 4; k++) smax[k] = finish_batch_stop(smax[k], base - start);
   }
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -655,14 +665,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TGS_BLK_WAVE
       out_depth[p] = D[k];
       final_T[p] = T[k];
       if (WANT_IDX) final_idx[p] = last[k];
-#ifndef TGS_AB_NO_STOPSTORE
       if (stop_pos) stop_pos[p] = stop_of(smax[k]);
-#endif
     }
   }
-#ifndef TGS_AB_NO_PUBLISH   // (A/B switch, tools/abn.py: what the walk statistics cost K6)
-  publish_walk(tile_start, T_total, smax, end - start, lane);
-#endif
+  // the walk statistics are K7's (chain-bound test): a render-only forward (no stop_pos) publishes nothing -- and
+  // does not disturb the sums a training forward on the same lists has left (they accumulate: one publishing forward
+  // per backward; 1.5 us of K6 at cfg3)
+  if (stop_pos) publish_walk(tile_start, T_total, smax, end - start, lane);
 }
 
 // ---------------------------------------------------------------------------------------------

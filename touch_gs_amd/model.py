@@ -134,6 +134,8 @@ class View:
 
 class DepthGaussianSplattingModel:
     """The trainable scene: flat SoA parameters + the render/loss/step methods."""
+    list_hint = True          # speculative budget: learn a bound on the longest tile list, skip the unused sort launches
+    LIST_HINT_AFTER = 16      # ... after this many settled frames since the last refinement / replay
 
     def __init__(self, config: ModelConfig, params: GaussianParams):
         self.config = config
@@ -361,6 +363,10 @@ class DepthGaussianSplattingModel:
         self._pinned = []
         self._dp_status = None      # device {0, any rank overflowed} of the last data-parallel step
         self._dp = None
+        # longest tile list the settled frames have shown (status[3]) -> the budget's max_list_hint: after LIST_HINT_AFTER
+        # good frames the sort launches for list classes beyond 1.5 x that are no longer issued (two near-empty launches,
+        # ~9 us per step at cfg3); a frame that breaks the bound is void and replayed like an overflow, with the hint off
+        self._seen_longest, self._good_frames = 0, 0
 
     def _speculative_track(self, view: View, distributed: bool = False) -> None:
         # pinned int32[7]: {#intersections, overflow, sufficient capacity, -} of this rank's frame | the verdict | the
@@ -393,6 +399,10 @@ class DepthGaussianSplattingModel:
             if int(host[5]) == 0:
                 self._pending.popleft()
                 self._seen_need = max(getattr(self, "_seen_need", 0), int(host[2]), int(host[0]))
+                self._seen_longest = max(self._seen_longest, int(host[3]))
+                self._good_frames += 1
+                if self.list_hint and self._good_frames >= self.LIST_HINT_AFTER:
+                    self.budget.max_list_hint = max(self.budget.max_list_hint, int(1.5 * self._seen_longest) + 64)
                 self._pinned.append(host)
                 if only_one:
                     return
@@ -403,6 +413,9 @@ class DepthGaussianSplattingModel:
             self._pending.clear()
             need = max(int(h[0]) for _, h, _ in redo)      # this rank's own largest frame
             self.budget.capacity = max(self.budget.capacity, int(need * self.budget.growth) + 1024)
+            # (if a list longer than the hint voided the frame: every sort class again until enough frames have been seen)
+            self._seen_longest = max([self._seen_longest] + [int(h[3]) for _, h, _ in redo])
+            self.budget.max_list_hint, self._good_frames = -1, 0
             self.budget.sticky.zero_()
             self._prefetch_ready = None     # announced by a voided step: its front buffers were cleared under the sticky word
             self.optimizer.t -= len(redo)
@@ -603,6 +616,7 @@ class DepthGaussianSplattingModel:
                 ratio = max(1.0, self.params.N / max(n_before, 1))
                 cap = int(seen * ratio * 1.25) + 4096 if seen > 0 else int(self.budget.capacity * ratio) + 4096
                 self._seen_need = 0
+                self._seen_longest, self._good_frames = 0, 0     # the lists change with the Gaussians: learn the bound again
                 self.budget = ops.IntersectBudget(capacity=cap, sync=False, speculative=True)
             else:
                 self.budget = ops.IntersectBudget()  # the intersection count changes with N

@@ -58,8 +58,13 @@ class IntersectBudget:
     clear the word and replay (``DepthGaussianSplattingModel.enable_speculative_budget``).
     """
 
-    def __init__(self, capacity: int = 0, sync: bool = True, growth: float = 1.25, speculative: bool = False):
+    def __init__(self, capacity: int = 0, sync: bool = True, growth: float = 1.25, speculative: bool = False,
+                 max_list_hint: int = -1):
         self.capacity = int(capacity)
+        # the caller's bound on the longest tile list of the frames binned with this budget (tgs.h, max_list_hint):
+        # -1 = none, every sort class is launched; a frame that breaks it is void like one that overflowed (sticky
+        # word, replay) -- so only budgets that do NOT read the status back per frame may carry one
+        self.max_list_hint = int(max_list_hint)
         self.sync = sync and not speculative
         self.speculative = speculative
         self.growth = growth
@@ -67,6 +72,7 @@ class IntersectBudget:
         self.last_status4 = None  # ... and the full word {.., .., required capacity, reserved}
         self.last_n = None       # #intersections of the last frame that was read back
         self.last_need = None    # capacity that frame needs under the per-XCD split (>= last_n; tgs.h)
+        self.last_longest = None  # longest tile list of that frame (status[3])
         self.sticky = None       # device int32[1], allocated on first use
 
     def sticky_word(self, device):
@@ -84,6 +90,9 @@ class IntersectBudget:
             self.sticky = torch.zeros(1, dtype=torch.int32, device=device)
         return self.sticky
 
+    def list_hint(self) -> int:
+        return -1 if self.sync else self.max_list_hint
+
     def initial(self, N: int):
         if self.capacity <= 0:
             self.capacity = max(8 * N, 1 << 16)
@@ -95,8 +104,12 @@ class IntersectBudget:
         if self.last_status is None:
             return None
         if self.last_status4 is not None:
-            n, ovf, need, _ = self.last_status4.tolist()
+            n, ovf, need, longest = self.last_status4.tolist()
             self.last_need = max(n, need)
+            self.last_longest = longest
+            if ovf and 0 <= self.max_list_hint < longest:
+                raise RuntimeError(f"a tile list of {longest} entries broke max_list_hint = {self.max_list_hint}: that frame "
+                                   "and every frame since were dropped (raise the hint or pass -1)")
         else:
             n, ovf = self.last_status.tolist()
         self.last_n = n
@@ -154,12 +167,12 @@ def bin_sort(cam: Camera, splats, budget: Optional[IntersectBudget] = None):
         scratch = torch.empty(lib.tgs_sort_scratch_bytes(cap), dtype=torch.uint8, device=dev)
         check(lib.tgs_bin_sort(C.byref(cs), N, ptr(splats), ptr(group_base), ptr(tile_start), _tile_start_len(tile_start),
                                ptr(tile_cursor), ptr(sorted_gid), ptr(tile_order), cap, ptr(scratch),
-                               ptr(status), ptr(budget.sticky_word(dev)), _stream()), "tgs_bin_sort")
+                               ptr(status), ptr(budget.sticky_word(dev)), budget.list_hint(), _stream()), "tgs_bin_sort")
         budget.last_status = status
         budget.last_status4 = status4
         if not budget.sync:
             break
-        n, ovf, need, _ = status4.tolist()
+        n, ovf, need, budget.last_longest = status4.tolist()
         budget.last_n, budget.last_need = n, max(n, need)
         if not ovf:
             break
@@ -268,7 +281,7 @@ def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_d
                                                  ptr(sh), sh_stride, sh_deg, ptr(splats), ptr(radii), ptr(group_base),
                                                  ptr(tile_start), _tile_start_len(tile_start), ptr(tile_cursor), ptr(sorted_gid),
                                                  ptr(tile_order), cap, ptr(scratch), ptr(status), ptr(budget.sticky_word(dev)),
-                                                 ptr(tag_holder.tag_word), tag_holder.tag,
+                                                 budget.list_hint(), ptr(tag_holder.tag_word), tag_holder.tag,
                                                  C.byref(ncs) if nf is not None else None,
                                                  ptr(nf.tile_cursor) if nf is not None else None,
                                                  ptr(nf.status) if nf is not None else None, _stream()),
@@ -281,21 +294,21 @@ def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_d
                                            ptr(sh), sh_stride, sh_deg if sh is not None else -1, ptr(splats),
                                            ptr(radii), ptr(group_base), ptr(tile_start), _tile_start_len(tile_start),
                                            ptr(tile_cursor), ptr(sorted_gid), ptr(tile_order), cap, ptr(scratch), ptr(status),
-                                           ptr(budget.sticky_word(dev)), _stream()),
+                                           ptr(budget.sticky_word(dev)), budget.list_hint(), _stream()),
                   "tgs_project_bin_sort")
         else:
             check(lib.tgs_project_bin_sort_colors(C.byref(cs), N, ptr(means), ptr(log_scales), ptr(quats),
                                                   ptr(opac_logit), ptr(sh), sh_stride, sh_deg, ptr(splats),
                                                   ptr(radii), ptr(group_base), ptr(tile_start), _tile_start_len(tile_start),
                                                   ptr(tile_cursor), ptr(sorted_gid), ptr(tile_order), cap, ptr(scratch), ptr(status),
-                                                  ptr(budget.sticky_word(dev)), ptr(colors.colors),
+                                                  ptr(budget.sticky_word(dev)), budget.list_hint(), ptr(colors.colors),
                                                   ptr(colors.tag_word), colors.tag, _stream()),
                   "tgs_project_bin_sort_colors")
         budget.last_status = status
         budget.last_status4 = status4
         if not budget.sync:
             break
-        n, ovf, need, _ = status4.tolist()
+        n, ovf, need, budget.last_longest = status4.tolist()
         budget.last_n, budget.last_need = n, max(n, need)
         if not ovf:
             break
