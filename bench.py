@@ -378,6 +378,8 @@ def main():
 def _main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--no-list-hint", action="store_true",
+                    help="launch every sort class every frame (A/B of tgs_bin_sort's max_list_hint)")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg3",
@@ -448,14 +450,19 @@ def _main():
              for v in range(args.views)]
     for v in views:
         v.valid_count()
-    n_isect, n_need = [], []
+    n_isect, n_need, n_longest = [], [], []
     for v in views:  # size the intersection buffers once; no host sync inside the timed region
         sp = ops.project_fwd(v.cam, params.means, params.log_scales, params.quats, params.opac_logit, params.sh, deg)
         b = ops.IntersectBudget()
         ops.bin_sort(v.cam, sp, b)
         n_isect.append(b.last_n)
         n_need.append(b.last_need)   # capacity under the per-XCD split of the pair index space (tgs.h)
-    model.budget = ops.IntersectBudget(capacity=int(max(n_need) * 1.25) + 4096, sync=False)
+        n_longest.append(b.last_longest)
+    # ... and bound the longest tile list the same way (1.5 x the longest list of any view + 64: what the trainer's
+    # speculative budget learns from its settled frames): the sort launches for longer list classes are not issued; a
+    # frame that broke the bound would be void and budget.check() after the timed region would raise
+    model.budget = ops.IntersectBudget(capacity=int(max(n_need) * 1.25) + 4096, sync=False,
+                                       max_list_hint=-1 if args.no_list_hint else int(1.5 * max(n_longest)) + 64)
     del sp
     torch.cuda.empty_cache()
 

@@ -32,13 +32,15 @@ if %(morton)d:
     model.spatial_sort()
     p = model.params
 views = [make_view(N, W, H, deg, seed, dev, view=v, n_views=8, clustered=cl) for v in range(nv)]
-need = 0
+need = longest = 0
 for v in views:
     v.valid_count()
     b = ops.IntersectBudget()
     ops.project_bin_sort(v.cam, p.means, p.log_scales, p.quats, p.opac_logit, p.sh, deg, b)
     need = max(need, b.last_need)
-budget = ops.IntersectBudget(capacity=int(need * 1.25) + 4096, sync=False)
+    longest = max(longest, b.last_longest)
+budget = ops.IntersectBudget(capacity=int(need * 1.25) + 4096, sync=False,
+                             max_list_hint=-1 if os.environ.get("TGS_AB_NO_LIST_HINT") else int(1.5 * longest) + 64)
 ev = lambda: torch.cuda.Event(enable_timing=True)
 names = ["front", "k6", "ssim", "k7", "k8"]
 per_view = []
