@@ -658,6 +658,56 @@ def test_ssim_fwd_bwd(dev, W, H):
     assert (v.cpu().double() - a.grad).abs().max().item() < 1e-4 * scale
 
 
+_SSIM_WORKER = r'''
+import sys, torch, ctypes as C
+sys.path.insert(0, sys.argv[1])
+from touch_gs_amd import _lib, ops
+dev = torch.device("cuda:0")
+out = {}
+for W, H in ((54, 35), (55, 36), (200, 123), (640, 360), (1000, 57)):
+    g = torch.Generator().manual_seed(W * 7 + H)
+    a = torch.rand(H, W, 3, generator=g).to(dev)
+    b = (a + 0.2 * torch.randn(H, W, 3, generator=g).to(dev)).clamp(0, 1)
+    tot, v = ops.ssim_fwd_bwd(a, b, weight=-0.2 / (3 * H * W))
+    out[f"{W}x{H}/v"] = v.cpu(); out[f"{W}x{H}/tot"] = tot.double().cpu()
+    # bands (tgs_ssim_fwd_bwd_rows): v_img rows [y0, y1), the map summed over the same rows
+    lib = _lib.load()
+    nb = ((H + 15) // 16) * ((W + 15) // 16)
+    vb = torch.zeros_like(a); scratch = torch.empty(9 * H * W, device=dev)
+    tots = []
+    for y0, y1 in ((0, H // 3), (H // 3, H // 3 + 7), (H // 3 + 7, H)):
+        bp = torch.empty(nb, device=dev)
+        _lib.check(lib.tgs_ssim_fwd_bwd_rows(W, H, _lib.ptr(a), _lib.ptr(b), C.c_float(-0.2 / (3 * H * W)), _lib.ptr(bp), nb,
+                                             _lib.ptr(vb), _lib.ptr(scratch), y0, y1, y0, y1, None), "rows")
+        tots.append(bp.double().sum())
+    out[f"{W}x{H}/vb"] = vb.cpu(); out[f"{W}x{H}/totb"] = sum(tots).cpu()
+torch.save(out, sys.argv[2])
+'''
+
+
+def test_ssim_one_pass_equals_two_kernels(dev, tmp_path):
+    """k_ssim_fused (forward + backward of a strip in one pass, adjoint planes in LDS; the default) against the
+    two-kernel path with the adjoint planes in HBM (TGS_SSIM_FUSED=0, read once per process: two worker processes):
+    v_img bit for bit -- whole images and bands, sizes around the 54-column / segment boundaries -- and the map sum to
+    fp32 summation order."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for fused in ("1", "0"):
+        f = str(tmp_path / f"ssim_{fused}.pt")
+        env = dict(os.environ, TGS_SSIM_FUSED=fused)
+        r = subprocess.run([sys.executable, "-c", _SSIM_WORKER, root, f], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[fused] = torch.load(f)
+    for k, v in res["1"].items():
+        if k.endswith("/v") or k.endswith("/vb"):
+            assert torch.equal(v, res["0"][k]), (k, (v - res["0"][k]).abs().max())
+        else:
+            assert abs(float(v) - float(res["0"][k])) < 2e-6 * abs(float(res["0"][k])) + 1e-6, (k, float(v), float(res["0"][k]))
+    for k in [k for k in res["1"] if k.endswith("/v")]:      # the bands together = the whole image
+        assert torch.equal(res["1"][k], res["1"][k + "b"]), k
+
+
 def test_selforacle_fixtures_gpu(dev):
     """HIP pipeline against the committed known-answer fixtures (tests/golden/raster_selforacle.npz)."""
     import os

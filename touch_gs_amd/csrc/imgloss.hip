@@ -242,7 +242,143 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// One pass (round 5): forward + backward of a strip without the adjoint planes in HBM
+// ---------------------------------------------------------------------------------------------
+// k_ssim_fwd writes nine adjoint values per pixel (75 MB at 1080p) that k_ssim_bwd reads back with its own halo
+// (x 1.5): 351 MB of HBM traffic for 75 MB of compulsory bytes (img, gt in; v_img out), 10 % of the train step.
+// Here a workgroup owns SWO = 54 output columns x SEG rows and keeps everything between the two filters on chip:
+// its 192 threads = (64 adjoint columns [xo0 - 5, xo0 + 59)) x 3 channels.  Per block of 11 staged input rows
+//   phase 1  = k_ssim_fwd's loop verbatim on the strip shifted by the halo: horizontal moments from LDS, the last 11 rows
+//              in registers, SSIM map + the three adjoint values of (row r - 5, own column) -> LDS (zero outside the
+//              image: the backward filter's zero padding), 11 rows x 64 x 9 floats;
+//   phase 2  = k_ssim_bwd's loop verbatim, reading those rows from LDS instead of staging them from HBM: horizontal
+//              filter of the three adjoint maps (threads of the 54 inner columns), the last 11 rows in registers,
+//              v_img of row r - 10.
+// Same arithmetic in the same order per value: v_img is bit-identical to the two-kernel path.  Costs: the forward part
+// runs on (64 / 54) x ((SEG + 10) / SEG) more pixels, img / gt are read with a 10-pixel halo ((74 / 54) x ((SEG + 20) / SEG));
+// LDS 45 KB per workgroup (3 per CU).  The map sum counts a pixel in the workgroup that owns its OUTPUT.
+constexpr int SWO = SW - 2 * HALO;
+__host__ __device__ constexpr int fused_seg_rows(int nblk) { return RB * nblk - 4 * HALO; }
+
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_ssim_fused(
+    int W, int H, float weight, const float* __restrict__ img, const float* __restrict__ gt,
+    float* __restrict__ v_img, float* __restrict__ block_partials, int n_partials, int NBLK,
+    int y_lo, int y_hi, int c_lo, int c_hi) {
+  const int SEG = fused_seg_rows(NBLK);
+  constexpr int ROWF = RowBlock<3>::ROWF;
+  constexpr int ADJF = SW * 9;                       // floats per adjoint row: [column][channel][3 maps]
+  __shared__ float sa[RB * ROWF], sb[RB * ROWF];
+  __shared__ float sadj[RB * ADJF];
+  __shared__ float red[NTH / TGS_WAVE];
+  const int tid = threadIdx.x;
+  const int col = tid / 3, c = tid - col * 3;
+  const int xa0 = blockIdx.x * SWO - HALO;           // first adjoint column of the strip (thread column 0)
+  const int gx = xa0 + col;
+  const int ys = y_lo + blockIdx.y * SEG, ye = min(ys + SEG, y_hi);
+  const bool own_col = col >= HALO && col < SW - HALO;
+  // phase 2 reads the 11 adjoint columns col - 5 .. col + 5; the threads of the halo columns produce no output and
+  // read a clamped (in-row) window instead
+  const int cb = min(max(col - HALO, 0), SWO - 1);
+  float w[RB][5], w2[RB][3];
+#pragma unroll
+  for (int p = 0; p < RB; p++) {
+#pragma unroll
+    for (int q = 0; q < 5; q++) w[p][q] = 0.f;
+    w2[p][0] = 0.f; w2[p][1] = 0.f; w2[p][2] = 0.f;
+  }
+  float msum = 0.f;
+  for (int blk = 0; blk < NBLK; blk++) {
+    const int r0 = ys - 2 * HALO + blk * RB;         // first input row of this block; its output rows are r0 - 10 ..
+    if (r0 - 2 * HALO >= ye) break;                  // no output row left (uniform)
+    __syncthreads();                                 // previous block fully consumed (sa / sb and sadj)
+    RowBlock<3>::stage2(img, gt, sa, sb, W, H, xa0, r0, tid);
+    __syncthreads();
+    // ---- phase 1: moments -> SSIM map -> adjoint values of row r0 + p - 5 at column gx
+#pragma unroll
+    for (int p = 0; p < RB; p++) {
+      const float* ra = sa + p * ROWF + tid;
+      const float* rb = sb + p * ROWF + tid;
+      float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+      for (int k = 0; k < WIN; k++) {
+        const float a = ra[3 * k], b = rb[3 * k];
+        const float ga = WK(k) * a, gb = WK(k) * b;
+        m1 += ga; m2 += gb;
+        e11 = fmaf(ga, a, e11); e22 = fmaf(gb, b, e22); e12 = fmaf(ga, b, e12);
+      }
+      w[p][0] = m1; w[p][1] = m2; w[p][2] = e11; w[p][3] = e22; w[p][4] = e12;
+      const int gy = r0 + p - HALO;                  // map / adjoint row
+      float A = 0.f, B = 0.f, C = 0.f;
+      if (gy >= ys - HALO && gy < ye + HALO && gy >= 0 && gy < H) {      // uniform
+        float o[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < WIN; k++) {
+#pragma unroll
+          for (int q = 0; q < 5; q++) o[q] = fmaf(WK(k), w[(p + 1 + k) % RB][q], o[q]);
+        }
+        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+        const float mu1 = o[0], mu2 = o[1];
+        const float s11 = o[2] - mu1 * mu1, s22 = o[3] - mu2 * mu2, s12 = o[4] - mu1 * mu2;
+        const float n1 = 2.f * mu1 * mu2 + C1, n2 = 2.f * s12 + C2;
+        const float d1 = mu1 * mu1 + mu2 * mu2 + C1, d2 = s11 + s22 + C2;
+        const float id1 = __builtin_amdgcn_rcpf(d1), id2 = __builtin_amdgcn_rcpf(d2);
+        const float m = n1 * n2 * id1 * id2;
+        if (gx >= 0 && gx < W) {
+          if (own_col && gy >= ys && gy < ye && gy >= c_lo && gy < c_hi) msum += m;
+          const float dm_ds12 = 2.f * n1 * id1 * id2;
+          const float dm_ds11 = -m * id2;
+          const float dm_dmu1 = 2.f * mu2 * n2 * id1 * id2 - m * 2.f * mu1 * id1;
+          A = dm_dmu1 - 2.f * mu1 * dm_ds11 - mu2 * dm_ds12;
+          B = dm_ds11;
+          C = dm_ds12;
+        }
+      }
+      float* o3 = sadj + p * ADJF + tid * 3;
+      o3[0] = A; o3[1] = B; o3[2] = C;
+    }
+    __syncthreads();
+    // ---- phase 2: filtered adjoint maps -> v_img of row r0 + p - 10
+#pragma unroll
+    for (int p = 0; p < RB; p++) {
+      const float* r = sadj + p * ADJF + (cb * 3 + c) * 3;
+      float h0 = 0.f, h1 = 0.f, h2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < WIN; k++) {
+        h0 = fmaf(WK(k), r[9 * k], h0);
+        h1 = fmaf(WK(k), r[9 * k + 1], h1);
+        h2 = fmaf(WK(k), r[9 * k + 2], h2);
+      }
+      w2[p][0] = h0; w2[p][1] = h1; w2[p][2] = h2;
+      const int gy = r0 + p - 2 * HALO;              // output row
+      if (gy >= ys && gy < ye) {                     // uniform
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < WIN; k++) {
+          o0 = fmaf(WK(k), w2[(p + 1 + k) % RB][0], o0);
+          o1 = fmaf(WK(k), w2[(p + 1 + k) % RB][1], o1);
+          o2 = fmaf(WK(k), w2[(p + 1 + k) % RB][2], o2);
+        }
+        if (own_col && gx < W) {
+          const size_t pidx = ((size_t)gy * W + gx) * 3 + c;
+          v_img[pidx] = weight * (o0 + 2.f * img[pidx] * o1 + gt[pidx] * o2);
+        }
+      }
+    }
+  }
+  const float tot = wave_sum(msum);
+  if ((tid & 63) == 0) red[tid >> 6] = tot;
+  __syncthreads();
+  const int wg = blockIdx.y * gridDim.x + blockIdx.x, nwg = gridDim.x * gridDim.y;
+  if (tid == 0) block_partials[wg] = red[0] + red[1] + red[2];
+  for (int i = nwg + wg * NTH + tid; i < n_partials; i += nwg * NTH) block_partials[i] = 0.f;
+}
+
 }  // namespace
+
+// the fused kernel counts a map pixel in the workgroup that owns its output row: the counted rows must be output rows
+static inline bool count_inside(int y0, int y1, int c0, int c1) { return c0 >= c1 || (c0 >= y0 && c1 <= y1); }
 
 static int ssim_impl(int W, int H, const float* img, const float* gt, float weight,
                      float* block_partials, int n_partials, float* v_img, float* scratch,
@@ -255,6 +391,25 @@ static int ssim_impl(int W, int H, const float* img, const float* gt, float weig
   double g[WIN], sum = 0.0;
   for (int i = 0; i < WIN; i++) { g[i] = exp(-(double)((i - HALO) * (i - HALO)) / (2.0 * 1.5 * 1.5)); sum += g[i]; }
   for (int i = 0; i < WIN; i++) win.g[i] = (float)(g[i] / sum);
+  static const int env_nblk = [] { const char* e = getenv("TGS_SSIM_NBLK"); return e ? max(2, min(16, atoi(e))) : 0; }();
+  static const int env_fused = [] { const char* e = getenv("TGS_SSIM_FUSED"); return e ? atoi(e) : 1; }();   // 0: the two-kernel path (A/B)
+  if (v_img && env_fused && y1 > y0 && count_inside(y0, y1, c0, c1)) {
+    // one pass, adjoint planes on chip (k_ssim_fused); `scratch` is not touched.  Strip = 54 columns x (11 nblk - 20) rows:
+    // long segments keep the vertical halo small ((SEG + 20) / SEG input rows, (SEG + 10) / SEG of the forward arithmetic);
+    // the kernel holds 3 workgroups per CU (LDS), so the longest segment that still gives every slot a workgroup is taken
+    const int fx = (W + SWO - 1) / SWO;
+    auto wgs = [&](int nb) { return (long long)fx * ((y1 - y0 + fused_seg_rows(nb) - 1) / fused_seg_rows(nb)); };
+    int nblk = 7;
+    while (nblk > 3 && wgs(nblk) < 600) nblk--;
+    if (env_nblk) nblk = max(3, env_nblk);
+    while (nblk < 16 && wgs(nblk) > n_partials) nblk++;
+    TGS_CHECK_ARG(wgs(nblk) <= n_partials, "block_partials too small");
+    const int SEGF = fused_seg_rows(nblk);
+    hipLaunchKernelGGL(k_ssim_fused, dim3(fx, (y1 - y0 + SEGF - 1) / SEGF, 1), dim3(NTH), 0, (hipStream_t)stream, W, H, weight,
+                       img, gt, v_img, block_partials, n_partials, nblk, y0, y1, c0, c1);
+    TGS_CHECK_LAUNCH();
+    return TGS_OK;
+  }
   // forward rows: the gradient rows plus the 5-row halo the backward filter reads (adjoint maps)
   const int f0 = v_img ? max(0, y0 - HALO) : y0, f1 = v_img ? min(H, y1 + HALO) : y1;
   const int rows = f1 - f0;
@@ -262,10 +417,7 @@ static int ssim_impl(int W, int H, const float* img, const float* gt, float weig
   const int sx = (W + SW - 1) / SW;
   int nblk = 4;
   while (nblk > 2 && (long long)sx * ((rows + seg_rows(nblk) - 1) / seg_rows(nblk)) < 3 * 256) nblk--;
-  {   // tuning override, read from the environment ONCE (function-local static: thread-safe initialisation)
-    static const int env_nblk = [] { const char* e = getenv("TGS_SSIM_NBLK"); return e ? max(2, min(16, atoi(e))) : 0; }();
-    if (env_nblk) nblk = env_nblk;
-  }
+  if (env_nblk) nblk = env_nblk;   // tuning override (read once, above)
   // one workgroup sum goes into each of the first entries of block_partials, the rest is zeroed
   while (nblk < 16 && (long long)sx * ((rows + seg_rows(nblk) - 1) / seg_rows(nblk)) > n_partials) nblk++;
   TGS_CHECK_ARG((long long)sx * ((rows + seg_rows(nblk) - 1) / seg_rows(nblk)) <= n_partials, "block_partials too small");

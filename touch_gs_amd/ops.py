@@ -585,12 +585,12 @@ def dp_agree_overflow(world: int, N: int, v_color_all, status_out, sticky=None):
 # ------------------------------------------------------------------------------------------------
 class _Render(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means, log_scales, quats, opac_logit, sh, means2d, cam, sh_deg, budget):
+    def forward(ctx, means, log_scales, quats, opac_logit, sh, means2d, cam, sh_deg, budget, need_bwd=True):
         means, log_scales, quats, opac_logit, sh = map(_f32c, (means, log_scales, quats, opac_logit, sh))
         splats, radii, group_base, tile_start, sorted_gid, _ = project_bin_sort(
             cam, means, log_scales, quats, opac_logit, sh, sh_deg, budget, want_radii=True)
-        # render only (evaluation, get_outputs under no_grad): no backward will ask for the stop positions
-        need_bwd = torch.is_grad_enabled() and any(ctx.needs_input_grad)
+        # need_bwd = False: render only (evaluation, get_outputs under no_grad; decided by render(): grad mode is always
+        # off in here and needs_input_grad ignores it) -- no backward will ask for the stop positions
         rgb, depth, fT, fidx = rasterize_fwd(cam, splats, sorted_gid, tile_start, want_stop=need_bwd)
         ctx.cam, ctx.sh_deg = cam, sh_deg
         ctx.want_xy = means2d is not None
@@ -611,7 +611,7 @@ class _Render(torch.autograd.Function):
         v_means, v_ls, v_q, v_ol, v_sh, v_xy = project_bwd(
             cam, means, log_scales, quats, opac_logit, sh, ctx.sh_deg, splats, group_base, partials,
             want_v_xy=ctx.want_xy)
-        return v_means, v_ls, v_q, v_ol, v_sh, v_xy, None, None, None
+        return v_means, v_ls, v_q, v_ol, v_sh, v_xy, None, None, None, None
 
 
 def render(means, log_scales, quats, opac_logit, sh, cam: Camera, sh_deg: int,
@@ -624,7 +624,9 @@ def render(means, log_scales, quats, opac_logit, sh, cam: Camera, sh_deg: int,
     Returns (rgb [H,W,3] incl. background, depth_acc [H,W] = sum w*z, alpha [H,W], radii [N]).
     Expected depth is ``depth_acc / alpha`` (consumer side, as Splatfacto does).
     """
-    return _Render.apply(means, log_scales, quats, opac_logit, sh, means2d, cam, sh_deg, budget)
+    need_bwd = torch.is_grad_enabled() and any(t is not None and t.requires_grad
+                                               for t in (means, log_scales, quats, opac_logit, sh, means2d))
+    return _Render.apply(means, log_scales, quats, opac_logit, sh, means2d, cam, sh_deg, budget, need_bwd)
 
 
 # ------------------------------------------------------------------------------------------------
