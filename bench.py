@@ -392,6 +392,10 @@ def _main():
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-busbw-sweep", action="store_true", help="skip the message-size sweep of the exchange (N > 1)")
+    ap.add_argument("--dp-report", action="store_true",
+                    help="N > 1: after the headline loop (TGS_DP_TRANSPORT, default rccl) time the same loop over every "
+                         "transport back to back -- RCCL, peer stores with flags behind the kernel boundary, peer stores "
+                         "with in-kernel flags -- each followed by the replica check: dp_exchange.transports")
     ap.add_argument("--loop-only", action="store_true",
                     help="run ONLY warm-up + the timed loop (no other layout, no per-kernel repetitions, no render-only / "
                          "densifying / CPU measurements) and print a short JSON line: the command tools/collect_round.sh "
@@ -526,6 +530,40 @@ def _main():
             step(done[0]); done[0] += 1
         comm = dp.comm_report()
         dp.timing = False
+    # --dp-report: the SAME timed loop over every transport, back to back on this job's ranks (every rank takes part; all
+    # ranks walk the list in the same order).  A transport that fails (a peer wait that times out poisons its steps and
+    # raises at the check) is reported with its error and the next one starts from a fresh PeerExchange.
+    transports = None
+    if dp.world > 1 and args.dp_report:
+        transports = {}
+        first = (dp.transport, os.environ.get("TGS_PEER_SAFE_FLAGS", "1"))
+        for name, tr, safe in (("rccl", "rccl", None), ("ipc_flags_behind_kernel_boundary", "ipc", "1"),
+                               ("ipc_flags_in_kernel", "ipc", "0")):
+            if dp.peer is not None:
+                dp.check_transport(); dp.peer.close(); dp.peer = None
+            dp.transport = tr
+            if safe is not None:
+                os.environ["TGS_PEER_SAFE_FLAGS"] = safe
+            try:
+                k = min(args.steps, 100)
+                el = timed(min(args.warmup, 20), k)
+                dp.check_transport()
+                model.budget.check()
+                dp.assert_replicas_identical(model.params.flat)
+                transports[name] = {"ms_per_step": round(el / k * 1e3, 4), "iters_per_s": round(k * dp.world / el, 2),
+                                    "replicas_identical": True, "steps": k}
+                if dp.peer is not None:
+                    transports[name]["memory_kind"] = dp.peer.memory_kind
+            except Exception as ex:  # noqa: BLE001 -- the report must survive one transport failing
+                transports[name] = {"error": repr(ex)[:400]}
+        if dp.peer is not None:
+            try:
+                dp.check_transport(); dp.peer.close()
+            except Exception:  # noqa: BLE001
+                pass
+            dp.peer = None
+        dp.transport = first[0]
+        os.environ["TGS_PEER_SAFE_FLAGS"] = first[1]
     # message-size sweep of the exchange primitives on this job's ranks (every rank takes part): replaces the link
     # figures assumed in DESIGN.md section 6 by measurements the moment a multi-GPU node runs this
     busbw = None
@@ -702,6 +740,8 @@ def _main():
             if comm:
                 out["dp_exchange"].update(comm)
             out["dp_exchange"]["busbw_sweep"] = busbw
+            if transports is not None:
+                out["dp_exchange"]["transports"] = transports
         if dp.world == 1 and not args.no_densify_run:
             try:
                 del sp, partials, rgb, dacc

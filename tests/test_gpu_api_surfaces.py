@@ -914,15 +914,20 @@ def test_bench_two_ranks_share_one_gpu(dev):
     env = dict(os.environ, TGS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                         "--master-addr", "127.0.0.1", "--master-port", free_port(), os.path.join(root, "bench.py"),
-                        "--gpus", "2", "--steps", "4", "--warmup", "2", "--config", "cfg2", "--no-cpu-baseline"],
+                        "--gpus", "2", "--steps", "4", "--warmup", "2", "--config", "cfg2", "--no-cpu-baseline", "--dp-report"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, lines          # rank 0 prints ONE JSON line
-    line = json.loads(lines[0])
+    assert r.stdout.count("\n") == 1 and r.stdout.startswith("{"), r.stdout[:2000]   # ONE JSON line and nothing else on stdout
+    line = json.loads(r.stdout)
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
     assert line["dp_exchange"]["replicas_identical"] is True
     assert line["config"]["parallelism"] == "dp2"
+    # --dp-report: the same loop over every transport, each with its replica check (the collective one runs over gloo here)
+    tr = line["dp_exchange"]["transports"]
+    assert set(tr) == {"rccl", "ipc_flags_behind_kernel_boundary", "ipc_flags_in_kernel"}, tr
+    for name, t in tr.items():
+        assert t.get("replicas_identical") is True and t["ms_per_step"] > 0, (name, t)
+    assert tr["ipc_flags_in_kernel"]["memory_kind"] in ("uncached", "fine-grained")
 
 
 @pytest.mark.parametrize("transport", ["rccl", "ipc"])
