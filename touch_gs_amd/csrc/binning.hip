@@ -101,7 +101,9 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int T, int NB, int32_t* __r
     // last Gaussian (record slot 11) + that Gaussian's tile count (rect in slot 10).  On overflow
     // status[0] = status[2], so that a caller that grows to status[0] x growth converges in one retry.
     int mg = 0;
-    const int G = (N + TGS_GROUP - 1) / TGS_GROUP;
+    // (a frame voided by its front tag has no records: the K1 that would have written them never ran -- the buffers hold
+    // whatever the allocator left, and a garbage "sufficient capacity" would make the caller grow to it)
+    const int G = voided ? 0 : (N + TGS_GROUP - 1) / TGS_GROUP;
     for (int g = tid; g < G; g += 1024) {
       const float* rec = splats + (size_t)min(g * TGS_GROUP + TGS_GROUP - 1, N - 1) * TGS_SPLAT_FLOATS;
       int x0, y0, w, h;
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int T, int NB, int32_t* __r
       long long n = 0;
       for (int x = 0; x < TGS_XCC; x++)   // allocated (+ overshoot of failed attempts, word 2) + pairs that found no room
         n += (long long)xa[x * TGS_ALLOC_STRIDE] - xa[x * TGS_ALLOC_STRIDE + 2] + xa[x * TGS_ALLOC_STRIDE + 1];
-      const long long need = n + (long long)TGS_XCC * mg;
+      const long long need = voided ? 0 : n + (long long)TGS_XCC * mg;
       if (voided) {                 // (the scan workgroups read the tag themselves: this store is for the later kernels)
         status[1] = 1;
         if (fr.sticky) *fr.sticky = 1;

@@ -256,7 +256,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 //   phase 2  = k_ssim_bwd's loop verbatim, reading those rows from LDS instead of staging them from HBM: horizontal
 //              filter of the three adjoint maps (threads of the 54 inner columns), the last 11 rows in registers,
 //              v_img of row r - 10.
-// Same arithmetic in the same order per value: v_img is bit-identical to the two-kernel path.  Costs: the forward part
+// Same arithmetic in the same order per value: v_img is bit-identical to the two-kernel path (test_ssim_one_pass_equals_two_kernels).
+// NOT the default -- it is slower (see ssim_impl).  Costs: the forward part
 // runs on (64 / 54) x ((SEG + 10) / SEG) more pixels, img / gt are read with a 10-pixel halo ((74 / 54) x ((SEG + 20) / SEG));
 // LDS 45 KB per workgroup (3 per CU).  The map sum counts a pixel in the workgroup that owns its OUTPUT.
 constexpr int SWO = SW - 2 * HALO;
@@ -392,7 +393,10 @@ static int ssim_impl(int W, int H, const float* img, const float* gt, float weig
   for (int i = 0; i < WIN; i++) { g[i] = exp(-(double)((i - HALO) * (i - HALO)) / (2.0 * 1.5 * 1.5)); sum += g[i]; }
   for (int i = 0; i < WIN; i++) win.g[i] = (float)(g[i] / sum);
   static const int env_nblk = [] { const char* e = getenv("TGS_SSIM_NBLK"); return e ? max(2, min(16, atoi(e))) : 0; }();
-  static const int env_fused = [] { const char* e = getenv("TGS_SSIM_FUSED"); return e ? atoi(e) : 1; }();   // 0: the two-kernel path (A/B)
+  // TGS_SSIM_FUSED=1 selects the one-pass kernel.  Default 0: measured SLOWER (1080p 119 against 108 us alone, 104 against 100
+  // inside the step, profiles/r5_ssim_one_pass.txt) although it moves a third of the bytes -- the two kernels are not
+  // HBM-bound (3.3 TB/s), and the one-pass form pays 1.5x the forward arithmetic (halo) at 3 workgroups per CU (45 KB of LDS)
+  static const int env_fused = [] { const char* e = getenv("TGS_SSIM_FUSED"); return e ? atoi(e) : 0; }();
   if (v_img && env_fused && y1 > y0 && count_inside(y0, y1, c0, c1)) {
     // one pass, adjoint planes on chip (k_ssim_fused); `scratch` is not touched.  Strip = 54 columns x (11 nblk - 20) rows:
     // long segments keep the vertical halo small ((SEG + 20) / SEG input rows, (SEG + 10) / SEG of the forward arithmetic);
