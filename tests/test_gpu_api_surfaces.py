@@ -770,14 +770,14 @@ def test_speculative_budget_equals_synchronous_budget(dev, capacity, announce):
 def test_learned_list_hint_skips_launches_and_a_broken_hint_is_replayed(dev):
     """Speculative budget: after LIST_HINT_AFTER settled frames the trainer bounds the longest tile list by 1.5 x the
     longest it has seen and the sort launches for longer list classes are no longer issued.  Here the first views have
-    lists of a few hundred entries and a later view looks along the row of Gaussians (one tile list beyond 1024): that
+    lists of a few dozen entries and a later view looks along a row of Gaussians (one tile list beyond 1024): that
     frame breaks the learned bound, is voided on the device, and the replay (hint off) puts the model exactly where
     the trainer without the hint ends -- parameters and moments bit for bit."""
     from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
     from touch_gs_amd.optim import GaussianParams
     from touch_gs_amd.scene import make_view, synthetic_gaussians
     N, W, H, deg = 2600, 160, 96, 3      # 1000 scattered Gaussians (lists of a few dozen entries) + the row
-    views = [make_view(N, W, H, deg, 7, dev, view=v, n_views=4) for v in range(4)]
+    views = [make_view(N, W, H, deg, 7, dev, view=v, n_views=8) for v in (0, 1, 2, 7)]   # (7 is opposite to none of the others)
     P, _ = synthetic_gaussians(N, W, H, deg, 99)
     # 1600 small Gaussians on the optical axis of view 3 only: one tile of that view gets a list > 1024
     c2w = torch.linalg.inv(torch.tensor(views[3].cam.viewmat, dtype=torch.float64).reshape(4, 4))

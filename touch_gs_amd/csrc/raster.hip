@@ -998,6 +998,9 @@ __device__ __forceinline__ bool frame_is_chain_bound(const int32_t* __restrict__
 //     -- is k_raster_bwd_f2b's.  Batches behind the last pixel's stop position are never staged; their
 //     partial records are zero-filled up front.
 // (5 waves per SIMD -- amdgpu_waves_per_eu(5, 8): 96 VGPRs + 14 spilled -- 386 -> 508 us, same-box A/B: 112 VGPRs / 4 waves stay)
+#ifndef TGS_K7_PAIR
+#define TGS_K7_PAIR 0      // 1: two Gaussians per reduction round (A/B switch; tools/build_variant.sh k7pair -DTGS_K7_PAIR=1)
+#endif
 __global__ __launch_bounds__(64) void k_raster_bwd(
     CamK cam, int T_total, const float* __restrict__ splats, const int32_t* __restrict__ group_base,
     const int32_t* __restrict__ sorted_gid, const int32_t* __restrict__ tile_start,
@@ -1095,7 +1098,7 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
   __shared__ float4 sums[64 * 4];  // [Gaussian j][16 slots], slot c < 14 = total of term c (table in k_raster_bwd_f2b)
   constexpr int RED_RS = 68;
   constexpr int RED_ROWS = 8;
-  __shared__ float4 red4[RED_ROWS * RED_RS / 4];
+  __shared__ float4 red4[(TGS_K7_PAIR ? 2 : 1) * RED_ROWS * RED_RS / 4];
   float* red = reinterpret_cast<float*>(red4);
   const int red_c = lane & 15;
   const int red_part = (lane >> 4) ^ ((red_c >= 4 && red_c < 12) ? 1 : 0);
@@ -1155,18 +1158,16 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
     auto walk = [&](auto mayclamp) {
     constexpr bool MAYCLAMP = decltype(mayclamp)::value;
     unsigned long long rem = rem0;
-    while (rem) {
-      const int j = 63 - __builtin_clzll(rem);
-      rem &= ~(1ull << j);
+    // one Gaussian against the (up to four) quadrants it reaches: the lane's 8 partial sums + "some pixel took it"
+    auto blend = [&](int j, float (&acc)[RED_ROWS], unsigned long long& any) {
       const float4 qa = recs[j * 3], qb = recs[j * 3 + 1], qc = recs[j * 3 + 2];
       const unsigned m = (unsigned)((qm[0] >> j) & 1ull) | ((unsigned)((qm[1] >> j) & 1ull) << 1) |
                          ((unsigned)((qm[2] >> j) & 1ull) << 2) | ((unsigned)((qm[3] >> j) & 1ull) << 3);
       const int pos = rel + j;
       // acc: 0..2 v_rgb, 3 v_depth, 4 S = sum q, 5 Sx, 6 Sy, 7 Quv   (rows of the reduction scratch)
-      float acc[RED_ROWS];
 #pragma unroll
       for (int c = 0; c < RED_ROWS; c++) acc[c] = 0.f;
-      unsigned long long any = 0ull;   // lanes with a contributing pixel, kept as a scalar mask (see k_raster_bwd_f2b)
+      any = 0ull;   // lanes with a contributing pixel, kept as a scalar mask (see k_raster_bwd_f2b)
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         if (m & (1u << k)) {  // wave-uniform
@@ -1201,21 +1202,66 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
           any |= gob;
         }
       }
+    };
+    // the weighted transposed sum of one Gaussian's 64 x 8 lane values out of `rd` (see the kernel's head comment)
+    auto reduce_rows = [&](const float* rd) {
+      const float4 r0 = ld4(rd), r1 = ld4(rd + 4), r2 = ld4(rd + 8), r3 = ld4(rd + 12);
+      float o0 = r0.x * wt[0], o1 = r1.x * wt[4], o2 = r2.x * wt[8], o3 = r3.x * wt[12];
+      o0 = fmaf(r0.y, wt[1], o0); o1 = fmaf(r1.y, wt[5], o1); o2 = fmaf(r2.y, wt[9], o2); o3 = fmaf(r3.y, wt[13], o3);
+      o0 = fmaf(r0.z, wt[2], o0); o1 = fmaf(r1.z, wt[6], o1); o2 = fmaf(r2.z, wt[10], o2); o3 = fmaf(r3.z, wt[14], o3);
+      o0 = fmaf(r0.w, wt[3], o0); o1 = fmaf(r1.w, wt[7], o1); o2 = fmaf(r2.w, wt[11], o2); o3 = fmaf(r3.w, wt[15], o3);
+      return (o0 + o1) + (o2 + o3);
+    };
+    while (rem) {
+      const int j = 63 - __builtin_clzll(rem);
+      rem &= ~(1ull << j);
+      float acc[RED_ROWS];
+      unsigned long long any;
+      blend(j, acc, any);
+#if TGS_K7_PAIR
+      // Two Gaussians per reduction round (VERDICT r4 next #9a): the second one's blend runs before the first one's
+      // scatter -> transposed read round trip is waited for, and the two round trips overlap.  Same sums in the same
+      // order per Gaussian: bit-identical.  Costs 8 + ~16 VGPRs (3 waves per SIMD) and a second scratch image.
+      int j2 = -1;
+      float acc2[RED_ROWS];
+      unsigned long long any2 = 0ull;
+      if (rem) {
+        j2 = 63 - __builtin_clzll(rem);
+        rem &= ~(1ull << j2);
+        blend(j2, acc2, any2);
+      }
+      if (any != 0ull && any2 != 0ull) {
+#pragma unroll
+        for (int c = 0; c < RED_ROWS; c++) { red[c * RED_RS + lane] = acc[c]; red[RED_ROWS * RED_RS + c * RED_RS + lane] = acc2[c]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float O = reduce_rows(red_rd), O2 = reduce_rows(red_rd + RED_ROWS * RED_RS);
+        O = fold_xor16(O); O2 = fold_xor16(O2);
+        O = fold_xor32(O); O2 = fold_xor32(O2);
+        if (lane < 16) { reinterpret_cast<float*>(sums)[j * 16 + lane] = O; reinterpret_cast<float*>(sums)[j2 * 16 + lane] = O2; }
+        __builtin_amdgcn_wave_barrier();
+        continue;
+      }
+      if (any2 != 0ull) {        // only the second one contributed: it takes the single path below
+#pragma unroll
+        for (int c = 0; c < RED_ROWS; c++) acc[c] = acc2[c];
+        any = any2;
+      }
+      const int jr = (any2 != 0ull) ? j2 : j;
+#else
+      const int jr = j;
+#endif
       if (any != 0ull) {
 #pragma unroll
         for (int c = 0; c < RED_ROWS; c++) red[c * RED_RS + lane] = acc[c];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const float4 r0 = ld4(red_rd), r1 = ld4(red_rd + 4), r2 = ld4(red_rd + 8), r3 = ld4(red_rd + 12);
-        float o0 = r0.x * wt[0], o1 = r1.x * wt[4], o2 = r2.x * wt[8], o3 = r3.x * wt[12];
-        o0 = fmaf(r0.y, wt[1], o0); o1 = fmaf(r1.y, wt[5], o1); o2 = fmaf(r2.y, wt[9], o2); o3 = fmaf(r3.y, wt[13], o3);
-        o0 = fmaf(r0.z, wt[2], o0); o1 = fmaf(r1.z, wt[6], o1); o2 = fmaf(r2.z, wt[10], o2); o3 = fmaf(r3.z, wt[14], o3);
-        o0 = fmaf(r0.w, wt[3], o0); o1 = fmaf(r1.w, wt[7], o1); o2 = fmaf(r2.w, wt[11], o2); o3 = fmaf(r3.w, wt[15], o3);
-        float O = (o0 + o1) + (o2 + o3);
+        float O = reduce_rows(red_rd);
         O = fold_xor16(O);
         O = fold_xor32(O);
-        if (lane < 16) reinterpret_cast<float*>(sums)[j * 16 + lane] = O;
+        if (lane < 16) reinterpret_cast<float*>(sums)[jr * 16 + lane] = O;
         __builtin_amdgcn_wave_barrier();
       }
     }
