@@ -96,6 +96,29 @@ def test_inria_shaped_rasterizer(dev):
     assert torch.allclose(c1, c2, atol=1e-6)
     with pytest.raises(Exception):
         GaussianRasterizer(rs)(means, means2D, opac, scales=scales, rotations=rot)
+    # cov3D_precomp (SURVEY 8(b) lists it in the signature): Sigma = R S^2 R^T given directly renders what the scales + rotations
+    # render (the covariance is split back by eigh: other axes order / quaternion sign, same Gaussian), scale_modifier is
+    # NOT applied to it (INRIA rule), and its gradient is finite and agrees with the directional derivative of the image sum
+    w, x, y, z = rot.detach().unbind(1)
+    R = torch.stack([torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], -1),
+                     torch.stack([2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)], -1),
+                     torch.stack([2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1)], -2)
+    Sig = R @ torch.diag_embed(scales.detach() ** 2) @ R.transpose(1, 2)
+    cov6 = torch.stack([Sig[:, 0, 0], Sig[:, 0, 1], Sig[:, 0, 2], Sig[:, 1, 1], Sig[:, 1, 2], Sig[:, 2, 2]], -1).requires_grad_(True)
+    rs2 = rs._replace(scale_modifier=2.0)            # must not matter for a given covariance
+    c3, r3 = GaussianRasterizer(rs2)(means.detach(), None, opac.detach(), shs=shs.detach(), cov3D_precomp=cov6)
+    e = relerr(c3.permute(1, 2, 0).detach().cpu().numpy(), color.permute(1, 2, 0).detach().cpu().numpy(), floor=1e-2)
+    assert np.quantile(e, 0.999) < 1e-4, np.quantile(e, 0.999)
+    wgt = torch.rand_like(c3)
+    (c3 * wgt).sum().backward()
+    assert torch.isfinite(cov6.grad).all() and cov6.grad.abs().sum() > 0
+    d = torch.randn_like(cov6) * cov6.detach().abs().mean() * 1e-3
+    f = lambda c: float((GaussianRasterizer(rs2)(means.detach(), None, opac.detach(), shs=shs.detach(), cov3D_precomp=c)[0] * wgt).double().sum())
+    fd = (f(cov6.detach() + d) - f(cov6.detach() - d)) / 2
+    an = float((cov6.grad.double() * d.double()).sum())
+    assert abs(fd - an) < 0.05 * abs(an) + 1e-3, (fd, an)
+    with pytest.raises(Exception):      # exactly one of (scales, rotations) / cov3D_precomp
+        GaussianRasterizer(rs)(means, None, opac, shs=shs, scales=scales, rotations=rot, cov3D_precomp=cov6)
 
 
 def test_model_autograd_path_equals_fused_path(dev):

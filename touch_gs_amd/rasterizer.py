@@ -10,7 +10,11 @@ written against it runs unchanged.  Conventions handled here:
 * ``means2D`` is a dummy [N,3] tensor whose ``.grad`` receives the screen-space mean gradient
   (pixel units, columns 0:2) for densification;
 * the normative rules of SURVEY App. B (tile rect, 0.3 px blur, 1/255 alpha cut, T <= 1e-4 stop)
-  apply.  ``cov3D_precomp`` is not supported.
+  apply;
+* ``cov3D_precomp`` ([N,6]: xx, xy, xz, yy, yz, zz; used as given, ``scale_modifier`` is not applied to it -- the INRIA
+  rule) is split into scales and a rotation by ``torch.linalg.eigh`` and then takes the same kernels.  The render is the
+  one of the equivalent scales + rotations; the gradient w.r.t. the covariance flows back through ``eigh`` and is, like
+  ``eigh``'s own, ill-conditioned for Gaussians with (nearly) equal axes.  Touch-GS / Splatfacto never take this path.
 """
 from __future__ import annotations
 
@@ -47,14 +51,38 @@ def _camera_from_settings(rs: GaussianRasterizationSettings) -> Camera:
                   glob_scale=float(rs.scale_modifier))
 
 
+def _scales_rotations_from_cov3d(cov6: torch.Tensor):
+    """Sigma = R diag(s^2) R^T  ->  (s [N,3], quaternion (w, x, y, z) [N,4]); differentiable (torch.linalg.eigh)."""
+    c = cov6
+    S = torch.stack([torch.stack([c[:, 0], c[:, 1], c[:, 2]], -1), torch.stack([c[:, 1], c[:, 3], c[:, 4]], -1),
+                     torch.stack([c[:, 2], c[:, 4], c[:, 5]], -1)], -2)
+    lam, Q = torch.linalg.eigh(S)
+    Q = Q * torch.where(torch.linalg.det(Q) < 0, -1.0, 1.0).to(Q.dtype)[:, None, None]   # proper rotation (det -Q = -det Q in 3-D)
+    s = torch.sqrt(torch.clamp(lam, min=1e-20))
+    # rotation matrix -> quaternion, the branch with the largest pivot (no division by a small number)
+    m00, m11, m22 = Q[:, 0, 0], Q[:, 1, 1], Q[:, 2, 2]
+    t = torch.stack([1 + m00 + m11 + m22, 1 + m00 - m11 - m22, 1 - m00 + m11 - m22, 1 - m00 - m11 + m22], -1)
+    k = t.argmax(-1)
+    r = torch.sqrt(torch.clamp(t.gather(-1, k[:, None])[:, 0], min=1e-20)) * 2      # 4 x the dominant component
+    a, b, cc = Q[:, 2, 1] - Q[:, 1, 2], Q[:, 0, 2] - Q[:, 2, 0], Q[:, 1, 0] - Q[:, 0, 1]
+    d, e, f = Q[:, 0, 1] + Q[:, 1, 0], Q[:, 0, 2] + Q[:, 2, 0], Q[:, 1, 2] + Q[:, 2, 1]
+    cand = torch.stack([torch.stack([r * r / 4, a, b, cc], -1), torch.stack([a, r * r / 4, d, e], -1),
+                        torch.stack([b, d, r * r / 4, f], -1), torch.stack([cc, e, f, r * r / 4], -1)], 1)   # x r
+    q = cand.gather(1, k[:, None, None].expand(-1, 1, 4))[:, 0] / r[:, None]
+    return s, q
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings: GaussianRasterizationSettings, budget: Optional[ops.IntersectBudget] = None):
     """-> (color [3,H,W], radii [N], depth [H,W] expected depth, alpha [H,W])."""
-    if cov3Ds_precomp is not None and cov3Ds_precomp.numel() > 0:
-        raise NotImplementedError("cov3D_precomp is not supported; pass scales + rotations")
     if (sh is None) == (colors_precomp is None):
         raise ValueError("Please provide exactly one of either SHs or precomputed colors!")
     cam = _camera_from_settings(raster_settings)
+    if cov3Ds_precomp is not None and cov3Ds_precomp.numel() > 0:
+        if cov3Ds_precomp.shape != (means3D.shape[0], 6):
+            raise ValueError("cov3D_precomp must be [N, 6] (xx, xy, xz, yy, yz, zz)")
+        scales, rotations = _scales_rotations_from_cov3d(cov3Ds_precomp)
+        cam.glob_scale = 1.0       # the INRIA rasterizer applies scale_modifier to scales only, not to a given covariance
     N = means3D.shape[0]
     eps = 1e-7
     o = opacities.reshape(N).clamp(eps, 1 - eps)
@@ -90,8 +118,9 @@ class GaussianRasterizer(torch.nn.Module):
                 cov3D_precomp=None):
         if (shs is None) == (colors_precomp is None):
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")
-        if scales is None or rotations is None:
-            raise Exception("Please provide scales and rotations (cov3D_precomp is not supported)")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         color, radii, depth, alpha = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales,
                                                          rotations, cov3D_precomp, self.raster_settings)
         if self.return_depth:
