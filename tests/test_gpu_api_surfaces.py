@@ -799,18 +799,18 @@ def test_learned_list_hint_skips_launches_and_a_broken_hint_is_replayed(dev):
     from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
     from touch_gs_amd.optim import GaussianParams
     from touch_gs_amd.scene import make_view, synthetic_gaussians
-    N, W, H, deg = 2600, 160, 96, 3      # 1000 scattered Gaussians (lists of a few dozen entries) + the row
+    N, W, H, deg = 2300, 160, 96, 3      # 1000 scattered Gaussians (lists of a few dozen entries) + the row
     views = [make_view(N, W, H, deg, 7, dev, view=v, n_views=8) for v in (0, 1, 2, 7)]   # (7 is opposite to none of the others)
     P, _ = synthetic_gaussians(N, W, H, deg, 99)
-    # 1600 small Gaussians on the optical axis of view 3 only: one tile of that view gets a list > 1024
+    # 1300 small Gaussians on the optical axis of view 3 only: one tile of that view gets a list > 1024
     c2w = torch.linalg.inv(torch.tensor(views[3].cam.viewmat, dtype=torch.float64).reshape(4, 4))
     g = torch.Generator().manual_seed(5)
-    z = 2.0 + 3.0 * torch.rand(1600, generator=g, dtype=torch.float64)
-    pts = torch.stack([0.002 * torch.randn(1600, generator=g, dtype=torch.float64) * z,
-                       0.002 * torch.randn(1600, generator=g, dtype=torch.float64) * z, z, torch.ones(1600, dtype=torch.float64)], 1)
-    P["means"][:1600] = (pts @ c2w.T)[:, :3].to(P["means"].dtype)
-    P["log_scales"][:1600] = -5.5
-    P["opac_logit"][:1600] = -3.0          # faint: the pixels behind them stay live, the whole list is walked
+    z = 1.0 + 8.0 * torch.rand(1300, generator=g, dtype=torch.float64)     # a long row: from the side it crosses many tiles
+    pts = torch.stack([0.002 * torch.randn(1300, generator=g, dtype=torch.float64) * z,
+                       0.002 * torch.randn(1300, generator=g, dtype=torch.float64) * z, z, torch.ones(1300, dtype=torch.float64)], 1)
+    P["means"][:1300] = (pts @ c2w.T)[:, :3].to(P["means"].dtype)
+    P["log_scales"][:1300] = -5.5
+    P["opac_logit"][:1300] = -3.0          # faint: the pixels behind them stay live, the whole list is walked
 
     def run(hint):
         params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
@@ -829,7 +829,7 @@ def test_learned_list_hint_skips_launches_and_a_broken_hint_is_replayed(dev):
     a, ha = run(True)
     b, hb = run(False)
     assert all(h == -1 for h in hb) and getattr(b, "speculative_replays", 0) == 0
-    assert max(ha[:10]) > 0 and max(ha[:10]) < 1024, ha          # a bound below the wg4 class was learned ...
+    assert 0 < max(ha[:10]) <= 1024, ha          # a bound below the wg4 class was learned ...
     assert getattr(a, "speculative_replays", 0) > 0, ha          # ... view 3 broke it and was replayed
     assert a._seen_longest > 1024
     assert a.step == b.step == 15 and a.optimizer.t == b.optimizer.t == 15
@@ -1329,7 +1329,11 @@ def test_nerfstudio_plugin_trains_with_touch_supervision_from_disk(dev, tmp_path
         v0 = make_view(N, W, H, deg, 11, dev, view=0, n_views=6)
         sc = outs.dataparser_scale
         assert torch.allclose(batch0["depth_image"][..., 0], v0.depth.cpu() * sc, atol=1e-3 * sc + 1e-6)   # mm quantisation
-        assert torch.allclose(batch0["uncertainty"][..., 0], v0.uncertainty.cpu() * sc, atol=1e-3 * sc + 1e-6)
+        # (the dataparser's uncertainty floor -- default 0.05 in the map's own units, DESIGN 10 item 6 -- bounds the touch : vision
+        # weight ratio of the depth loss; the map the model sees is the floored one)
+        floor = dmc.dataparser.uncertainty_floor
+        assert floor == 0.05 and (v0.uncertainty < floor).any()
+        assert torch.allclose(batch0["uncertainty"][..., 0], v0.uncertainty.cpu().clamp(min=floor) * sc, atol=1e-3 * sc + 1e-6)
         assert (batch0["depth_image"] == 0).float().mean() > 0.2          # unsupervised pixels stay 0
 
         mc = spec.config.pipeline.model
