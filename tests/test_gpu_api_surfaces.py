@@ -1372,7 +1372,9 @@ def test_nerfstudio_plugin_trains_with_touch_supervision_from_disk(dev, tmp_path
         callbacks = model.get_training_callbacks(Attrs)
         Loc = sys.modules["nerfstudio.engine.callbacks"].TrainingCallbackLocation
         n0, depth_losses, seen_n, degs = model.gaussians.num_points, [], set(), []
-        for step in range(10):
+        # 14 iterations: Splatfacto pauses splitting and culling for num_train_data + refine_every = 9 steps after a reset
+        # boundary (step 0 is one: densify.py `refinement_after`), so the first refinement that changes N is the one at step 12
+        for step in range(14):
             for cb in callbacks:
                 cb.run_callback_at_location(step, Loc.BEFORE_TRAIN_ITERATION)
             cam, batch = dm.next_train(step)

@@ -36,6 +36,13 @@ __device__ constexpr float WGT[WIN] = {0x1.0d956cp-10f, 0x1.f1fe02p-8f, 0x1.26eb
 #define WK(k) WGT[k]
 #endif
 
+// TGS_SSIM_DMA (bit 0: k_ssim_fwd, bit 1: k_ssim_bwd): the staged rows are brought in by LDS-DMA (`buffer_load_dword ... lds`: no
+// VGPRs, zero fill outside the image by the buffer's own range check) into one of TWO LDS images, and the next block's
+// rows are requested before the current block is filtered -- a request stays in flight across the barrier, so the
+// load -> barrier -> filter chain of a workgroup becomes max(load, filter) per block.
+#ifndef TGS_SSIM_DMA
+#define TGS_SSIM_DMA 0
+#endif
 constexpr int SW = 64;              // strip width (output columns per workgroup)
 constexpr int NTH = 3 * SW;         // threads: (column, channel)
 constexpr int RB = WIN;             // input rows per staged block = window height (phase p = row in block)
@@ -68,6 +75,29 @@ struct RowBlock {
       for (int u = 0; u < B; u++) {
         const int i = tid + NTH * (it0 + u);
         if (i < RB * ROWF) lds[i] = v[u];
+      }
+    }
+  }
+  // LDS-DMA staging: wave w of the workgroup fills floats [64 w + NTH u, + 64) of the image in iteration u (one
+  // `buffer_load_dword ... lds` per wave and iteration: 64 lanes x 4 B land contiguously at M0 + 4 lane); an element
+  // outside the image gets an offset beyond the buffer and reads as zero.  PADF: the image rounded up to whole waves.
+  static constexpr int PADF = (RB * ROWF + TGS_WAVE - 1) / TGS_WAVE * TGS_WAVE;
+  static constexpr int NDMA = PADF / TGS_WAVE;                       // wave-chunks per staged block
+  static __device__ __forceinline__ void dma(__amdgpu_buffer_rsrc_t rsrc, float* __restrict__ lds, int W, int H, int x0, int r0, int tid) {
+    typedef __attribute__((address_space(3))) float lds_float;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    constexpr int NW = NTH / TGS_WAVE;
+    const int gx0 = (x0 - HALO) * CH, WC = W * CH;
+#pragma unroll
+    for (int u = 0; u * NW < NDMA; u++) {
+      const int chunk = u * NW + wave;                               // wave-uniform
+      if (chunk < NDMA) {
+        const int i = chunk * TGS_WAVE + lane;
+        const int j = i / ROWF, e = i - j * ROWF;                    // (constant divisor: a multiply)
+        const int gy = r0 + j, gxf = gx0 + e;
+        const bool in = i < RB * ROWF && (unsigned)gy < (unsigned)H && (unsigned)gxf < (unsigned)WC;
+        const unsigned off = in ? (unsigned)(gy * WC + gxf) * 4u : 0xffffffffu;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_float*)(lds + chunk * TGS_WAVE), 4, off, 0, 0, 0);
       }
     }
   }
@@ -110,7 +140,13 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   // 5-row halo its backward pass needs); rows [c_lo, c_hi) count towards the sum
   const int SEG = seg_rows(NBLK);
   constexpr int ROWF = RowBlock<3>::ROWF;
+#if TGS_SSIM_DMA & 1
+  __shared__ float sa2[2][RowBlock<3>::PADF], sb2[2][RowBlock<3>::PADF];
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, (int)((size_t)W * H * 12), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)gt, 0, (int)((size_t)W * H * 12), 0x00020000);
+#else
   __shared__ float sa[RB * ROWF], sb[RB * ROWF];
+#endif
   __shared__ float red[NTH / TGS_WAVE];
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x * SW, ys = y_lo + blockIdx.y * SEG;
@@ -122,9 +158,25 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 #pragma unroll
     for (int q = 0; q < 5; q++) w[p][q] = 0.f;
   float msum = 0.f;
+#if TGS_SSIM_DMA & 1
+  RowBlock<3>::dma(rs_a, sa2[0], W, H, x0, ys - HALO, tid);
+  RowBlock<3>::dma(rs_b, sb2[0], W, H, x0, ys - HALO, tid);
+#endif
   for (int blk = 0; blk < NBLK; blk++) {
     const int r0 = ys - HALO + blk * RB;          // first input row of this block
     if (r0 - HALO >= ye) break;                   // no output row left (uniform)
+#if TGS_SSIM_DMA & 1
+    // this block's rows have landed (own requests: vmcnt; the other waves': the barrier) -- and every wave is done with
+    // the OTHER image, which the next block's requests overwrite while this block is filtered
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (blk + 1 < NBLK && r0 + RB - HALO < ye) {
+      RowBlock<3>::dma(rs_a, sa2[(blk + 1) & 1], W, H, x0, r0 + RB, tid);
+      RowBlock<3>::dma(rs_b, sb2[(blk + 1) & 1], W, H, x0, r0 + RB, tid);
+    }
+    const float* sa = sa2[blk & 1];
+    const float* sb = sb2[blk & 1];
+#else
     __syncthreads();                              // previous block fully consumed
     {
       // no register prefetch of the next block: the window already holds 55 VGPRs per thread and
@@ -134,6 +186,7 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
       RowBlock<3>::stage2(img, gt, sa, sb, W, H, x0, r0, tid);
     }
     __syncthreads();
+#endif
 #pragma unroll
     for (int p = 0; p < RB; p++) {
       // horizontal pass of input row r0 + p for (column, channel) = this thread
@@ -196,7 +249,12 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                                                   float* __restrict__ v_img, int NBLK, int y_lo, int y_hi) {
   const int SEG = seg_rows(NBLK);
   constexpr int ROWF = RowBlock<9>::ROWF;
+#if TGS_SSIM_DMA & 2
+  __shared__ float sadj2[2][RowBlock<9>::PADF];
+  const __amdgpu_buffer_rsrc_t rs_j = __builtin_amdgcn_make_buffer_rsrc((void*)adj, 0, (int)((size_t)W * H * 36), 0x00020000);
+#else
   __shared__ float sadj[RB * ROWF];
+#endif
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x * SW, ys = y_lo + blockIdx.y * SEG;
   const int gx = x0 + tid / 3;
@@ -204,15 +262,25 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   float w[RB][3];
 #pragma unroll
   for (int p = 0; p < RB; p++) { w[p][0] = 0.f; w[p][1] = 0.f; w[p][2] = 0.f; }
+#if TGS_SSIM_DMA & 2
+  RowBlock<9>::dma(rs_j, sadj2[0], W, H, x0, ys - HALO, tid);
+#endif
   for (int blk = 0; blk < NBLK; blk++) {
     const int r0 = ys - HALO + blk * RB;
     if (r0 - HALO >= ye) break;
+#if TGS_SSIM_DMA & 2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (blk + 1 < NBLK && r0 + RB - HALO < ye) RowBlock<9>::dma(rs_j, sadj2[(blk + 1) & 1], W, H, x0, r0 + RB, tid);
+    const float* sadj = sadj2[blk & 1];
+#else
     __syncthreads();
     {
       // 38 loads per thread and block: three rounds of 13 in flight (the kernel has registers to spare)
       RowBlock<9>::stage<13>(adj, sadj, W, H, x0, r0, tid);
     }
     __syncthreads();
+#endif
 #pragma unroll
     for (int p = 0; p < RB; p++) {
       const float* r = sadj + p * ROWF + 3 * tid;     // (pixel, channel) -> its three adjoint maps
