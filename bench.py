@@ -159,15 +159,22 @@ def cpu_baseline(N, W, H, deg, seed, frac=None, clustered=False):
                              project_bwd=t5 - t4))
 
 
-def cpu_baseline_torch(cfg_name="cfg2"):
+def cpu_baseline_torch(cfg_name="cfg2", full=False):
     """north_star: "the reference's pure-PyTorch CPU rasterizer timed on the same box's host cores".  The reference's
     rasterizer source is absent (empty submodule), so this is the build's vectorised PyTorch restatement of the published
-    algorithm (oracle/torch_oracle.py, fp32 here; its autograd is the backward) -- forward + backward of configs[1] IN FULL
-    (BASELINE.md section 2), one view, on torch's intra-op thread pool."""
+    algorithm (oracle/torch_oracle.py, fp32 here; its autograd is the backward) -- forward + backward of configs[1], one view,
+    on torch's intra-op thread pool.  ``full``: the whole frame (55 + 107 s on 128 cores:
+    profiles/r5_a_bench_cfg3.json).  Default: a BOUNDED sample -- all 100 k Gaussians through the centre quarter of the frame
+    (400 x 400 of 800 x 800: a quarter of the tiles, ~40 s) with the whole-frame rate extrapolated x 1/4 and labelled so --
+    so that the default `python bench.py` stays within a few minutes."""
     from oracle import torch_oracle as O
     c = CONFIGS[cfg_name]
     N, W, H, deg = c["gaussians"], c["width"], c["height"], 3
     P, intr = O.synthetic_scene(N, W, H, deg, c["seed"], dtype=torch.float32)
+    frac = 1.0
+    if not full:       # centre window: same intrinsics, principal point shifted, a quarter of the pixels
+        intr = dict(intr, W=W // 2, H=H // 2, cx=intr["cx"] - W // 4, cy=intr["cy"] - H // 4)
+        frac = 0.25
     cam = O.Camera(viewmat=O.orbit_viewmat(0, 8, dtype=torch.float32), **intr)
     Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
     t0 = time.perf_counter()
@@ -175,10 +182,13 @@ def cpu_baseline_torch(cfg_name="cfg2"):
     t1 = time.perf_counter()
     (out["rgb"].sum() + out["depth_acc"].sum()).backward()
     t2 = time.perf_counter()
-    return dict(value=round(1.0 / (t2 - t0), 5), unit="train iters/s (fwd+bwd, no SSIM/Adam)", cores=torch.get_num_threads(),
-                kind="port", config=c["label"],
-                sample=f"build's PyTorch-CPU oracle (oracle/torch_oracle.py, fp32, autograd backward), {c['label']} in full, "
-                       f"one view: forward {t1 - t0:.1f} s + backward {t2 - t1:.1f} s",
+    what = "in full" if full else ("the centre quarter of the frame (all Gaussians projected, a quarter of the tiles composited); "
+                                   "value = whole-frame rate EXTRAPOLATED as sample rate x 1/4 (measured in full on this "
+                                   "class of box: 0.0062 iters/s, profiles/r5_a_bench_cfg3.json; --cpu-baseline-torch-full)")
+    return dict(value=round(frac / (t2 - t0), 5), unit="train iters/s (fwd+bwd, no SSIM/Adam)", cores=torch.get_num_threads(),
+                kind="port", config=c["label"], extrapolated=not full,
+                sample=f"build's PyTorch-CPU oracle (oracle/torch_oracle.py, fp32, autograd backward), {c['label']}, one view, "
+                       f"{what}: forward {t1 - t0:.1f} s + backward {t2 - t1:.1f} s",
                 seconds=dict(forward=round(t1 - t0, 2), backward=round(t2 - t1, 2)))
 
 
@@ -378,6 +388,8 @@ def main():
 def _main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--cpu-baseline-torch-full", action="store_true",
+                    help="time the PyTorch-CPU oracle on the whole configs[1] frame (~3 min on 128 cores) instead of its centre quarter")
     ap.add_argument("--no-list-hint", action="store_true",
                     help="launch every sort class every frame (A/B of tgs_bin_sort's max_list_hint)")
     ap.add_argument("--steps", type=int, default=200)
@@ -771,7 +783,7 @@ def _main():
             except Exception as ex:  # the oracle is test infrastructure; never fail the bench on it
                 out["cpu_baseline"] = {"value": None, "error": repr(ex)}
             try:
-                out["cpu_baseline"]["torch"] = cpu_baseline_torch("cfg2")
+                out["cpu_baseline"]["torch"] = cpu_baseline_torch("cfg2", full=args.cpu_baseline_torch_full)
             except Exception as ex:  # noqa: BLE001
                 out["cpu_baseline"]["torch"] = {"value": None, "error": repr(ex)}
     dp.barrier()

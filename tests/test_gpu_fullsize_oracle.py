@@ -328,13 +328,29 @@ def test_ssim_matches_oracle_fullsize(dev, W, H):
                                            size=(H, W), mode="bilinear", align_corners=False)[0].permute(1, 2, 0)
     gt = base.clamp(0, 1).contiguous()
     img = (base + 0.1 * torch.randn(H, W, 3, generator=g, dtype=torch.float64)).clamp(0, 1).contiguous()
-    img.requires_grad_(True)
-    s = O.ssim(img, gt)
-    (0.2 * (1 - s)).backward()
-    tot, v = ops.ssim_fwd_bwd(img.detach().float().to(dev), gt.float().to(dev), weight=-0.2 / (3 * H * W))
+    tot, v = ops.ssim_fwd_bwd(img.float().to(dev), gt.float().to(dev), weight=-0.2 / (3 * H * W))
+    if H <= 1080:
+        img.requires_grad_(True)
+        s = O.ssim(img, gt)
+        (0.2 * (1 - s)).backward()
+        ref = img.grad.numpy()
+        got = v.cpu().double().numpy()
+    else:
+        # 4K: the fp64 autograd of the whole image costs a minute of the GPU-test budget.  SSIM is local -- the gradient at a
+        # pixel depends on the 21 x 21 pixels around it -- so the oracle differentiates three full-width bands (top edge,
+        # middle, bottom edge; every strip of the kernels, both image borders, segment boundaries inside) and the
+        # comparison keeps the rows at least 10 pixels away from a cut; the map sum is checked on the whole image (no grad).
+        with torch.no_grad():
+            s = O.ssim(img, gt)
+        refs, gots = [], []
+        for a, b in ((0, 170), (H // 2 - 85, H // 2 + 85), (H - 170, H)):
+            crop = img[a:b].clone().requires_grad_(True)
+            (0.2 * (1 - O.ssim(crop, gt[a:b])) * ((b - a) / H)).backward()      # mean over the band -> share of the image mean
+            lo, hi = (0 if a == 0 else 10), ((b - a) if b == H else (b - a) - 10)
+            refs.append(crop.grad[lo:hi].numpy())
+            gots.append(v[a + lo:a + hi].cpu().double().numpy())
+        ref, got = np.concatenate(refs), np.concatenate(gots)
     assert abs(tot.item() / (3 * H * W) - s.item()) < 1e-5, (tot.item() / (3 * H * W), s.item())
-    ref = img.grad.numpy()
-    got = v.cpu().double().numpy()
     scale = np.abs(ref).max()
     assert np.abs(got - ref).max() < 1e-4 * scale, np.abs(got - ref).max() / scale
     rel_l2 = np.sqrt(((got - ref) ** 2).sum() / (ref * ref).sum())
