@@ -227,7 +227,12 @@ int tgs_rasterize_fwd(const TgsCamera* cam /*[host]*/, const float* splats,
                       uint64_t* slot_ok /*may be NULL*/, const TgsRasterOpts* opts /*[host], may be NULL*/,
                       void* stream);
 /* tile_start is NOT const: the forward folds the frame's walk statistics into the scratch ints behind the starts and
- * the backward keeps a slot counter there (tgs_tile_start_len).  The starts themselves are only read. */
+ * the backward keeps a slot counter there (tgs_tile_start_len).  The starts themselves are only read.
+ * The statistics (deepest walk: a maximum; sum of walks: a sum) are zeroed by the scan of tgs_*bin_sort* and ACCUMULATE
+ * over the forwards that follow on the same lists: issue ONE forward with stop_pos != NULL per backward.  A forward
+ * with stop_pos == NULL (render only) neither stores stop positions nor touches the statistics; pixels outside the
+ * image count as walk 0.  (A doubled sum can only move the chain-bound verdict of tgs_rasterize_bwd towards "one wave
+ * per tile": the two forms of K7 differ by the rounding of one four-term sum, never in which pairs they visit.) */
 /* stop_pos[H,W] (optional; REQUIRED by tgs_rasterize_bwd*): per pixel the list position (relative to the
  * tile's first entry) of the Gaussian whose T' <= 1e-4 stopped the pixel (App. B.6) -- every earlier position
  * with alpha >= 1/255 contributed, nothing else did -- or 0x7fffffff if the pixel never stopped.  The
