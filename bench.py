@@ -705,7 +705,9 @@ def _main():
             "value_asis_layout": None if value_asis is None else round(value_asis, 3),
             "config": {"workload": workload, "name": args.config if not custom else "custom",
                        "gaussians": N, "width": W, "height": H, "sh_degree": deg, "views": args.views,
-                       "intersections": I, "tiles": T, "longest_tile_list": longest, "parallelism": f"dp{dp.world}",
+                       "intersections": I, "tiles": T, "longest_tile_list": longest,
+                       "longest_tile_list_any_view": max(n_longest), "max_list_hint": model.budget.max_list_hint,
+                       "parallelism": f"dp{dp.world}",
                        "layout": "morton (model.spatial_sort(): same scene, rows permuted)" if args.layout == "morton"
                                  else "as generated (random order)",
                        "depth_loss_type": cfg.depth_loss_type},
