@@ -1779,6 +1779,14 @@ def test_data_parallel_fullsize(dev, tmp_path, world, N, W, H, seed, transport):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "dp_full_worker.py"
     script.write_text(_DP_FULL_WORKER)
+    # the ranks share this box's ONE GPU with the pytest process: hand back what its allocator has cached from the tests
+    # before (8 x 5 M replicas need ~160 GB of the 288)
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    print("pytest process before the ranks start: reserved %.1f GB, free on the device %.1f GB" %
+          (torch.cuda.memory_reserved() / 1e9, torch.cuda.mem_get_info()[0] / 1e9))
+    torch.cuda.empty_cache()
     port = free_port()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0",
                TGS_DP_TRANSPORT=transport)

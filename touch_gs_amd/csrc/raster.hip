@@ -998,8 +998,14 @@ __device__ __forceinline__ bool frame_is_chain_bound(const int32_t* __restrict__
 //     -- is k_raster_bwd_f2b's.  Batches behind the last pixel's stop position are never staged; their
 //     partial records are zero-filled up front.
 // (5 waves per SIMD -- amdgpu_waves_per_eu(5, 8): 96 VGPRs + 14 spilled -- 386 -> 508 us, same-box A/B: 112 VGPRs / 4 waves stay)
+#ifndef TGS_K7_RECPF
+#define TGS_K7_RECPF 0     // 1: the next entry's staged record is read from LDS while the current entry is blended (A/B switch)
+#endif
 #ifndef TGS_K7_PAIR
 #define TGS_K7_PAIR 0      // 1: two Gaussians per reduction round (A/B switch; tools/build_variant.sh k7pair -DTGS_K7_PAIR=1)
+#endif
+#if TGS_K7_RECPF
+__attribute__((amdgpu_waves_per_eu(4, 8)))
 #endif
 __global__ __launch_bounds__(64) void k_raster_bwd(
     CamK cam, int T_total, const float* __restrict__ splats, const int32_t* __restrict__ group_base,
@@ -1159,8 +1165,7 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
     constexpr bool MAYCLAMP = decltype(mayclamp)::value;
     unsigned long long rem = rem0;
     // one Gaussian against the (up to four) quadrants it reaches: the lane's 8 partial sums + "some pixel took it"
-    auto blend = [&](int j, float (&acc)[RED_ROWS], unsigned long long& any) {
-      const float4 qa = recs[j * 3], qb = recs[j * 3 + 1], qc = recs[j * 3 + 2];
+    auto blend = [&](int j, const float4 qa, const float4 qb, const float4 qc, float (&acc)[RED_ROWS], unsigned long long& any) {
       const unsigned m = (unsigned)((qm[0] >> j) & 1ull) | ((unsigned)((qm[1] >> j) & 1ull) << 1) |
                          ((unsigned)((qm[2] >> j) & 1ull) << 2) | ((unsigned)((qm[3] >> j) & 1ull) << 3);
       const int pos = rel + j;
@@ -1212,12 +1217,46 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
       o0 = fmaf(r0.w, wt[3], o0); o1 = fmaf(r1.w, wt[7], o1); o2 = fmaf(r2.w, wt[11], o2); o3 = fmaf(r3.w, wt[15], o3);
       return (o0 + o1) + (o2 + o3);
     };
+#if TGS_K7_RECPF
+    // (A/B switch) the NEXT entry's staged record is requested from LDS before the current entry is blended: its three
+    // broadcast ds_read_b128 are in flight under ~70 VALU instead of in front of them (+12 VGPRs: 124, still 4 waves / SIMD)
+    if (rem == 0ull) return;
+    int jn = 63 - __builtin_clzll(rem);
+    rem &= ~(1ull << jn);
+    float4 na = recs[jn * 3], nb = recs[jn * 3 + 1], nc = recs[jn * 3 + 2];
+    for (;;) {
+      const int j = jn;
+      const float4 qa = na, qb = nb, qc = nc;
+      const bool more = rem != 0ull;
+      if (more) {
+        jn = 63 - __builtin_clzll(rem);
+        rem &= ~(1ull << jn);
+        na = recs[jn * 3]; nb = recs[jn * 3 + 1]; nc = recs[jn * 3 + 2];
+      }
+      float acc[RED_ROWS];
+      unsigned long long any;
+      blend(j, qa, qb, qc, acc, any);
+      if (any != 0ull) {
+#pragma unroll
+        for (int c = 0; c < RED_ROWS; c++) red[c * RED_RS + lane] = acc[c];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float O = reduce_rows(red_rd);
+        O = fold_xor16(O);
+        O = fold_xor32(O);
+        if (lane < 16) reinterpret_cast<float*>(sums)[j * 16 + lane] = O;
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (!more) break;
+    }
+#else
     while (rem) {
       const int j = 63 - __builtin_clzll(rem);
       rem &= ~(1ull << j);
       float acc[RED_ROWS];
       unsigned long long any;
-      blend(j, acc, any);
+      blend(j, recs[j * 3], recs[j * 3 + 1], recs[j * 3 + 2], acc, any);
 #if TGS_K7_PAIR
       // Two Gaussians per reduction round (VERDICT r4 next #9a): the second one's blend runs before the first one's
       // scatter -> transposed read round trip is waited for, and the two round trips overlap.  Same sums in the same
@@ -1228,7 +1267,7 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
       if (rem) {
         j2 = 63 - __builtin_clzll(rem);
         rem &= ~(1ull << j2);
-        blend(j2, acc2, any2);
+        blend(j2, recs[j2 * 3], recs[j2 * 3 + 1], recs[j2 * 3 + 2], acc2, any2);
       }
       if (any != 0ull && any2 != 0ull) {
 #pragma unroll
@@ -1265,6 +1304,7 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
         __builtin_amdgcn_wave_barrier();
       }
     }
+#endif
     };
     if (__ballot(lane < cnt && a0.w > CLAMP_FREE_OPACITY) != 0ull) walk(std::true_type{});
     else walk(std::false_type{});
