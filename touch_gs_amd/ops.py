@@ -210,7 +210,7 @@ class ColorPrefetch:
         return self.cam is cam and self.N == N and self.sh_deg == sh_deg and self.tag > 0
 
 
-_SIDE_CLEAR = _os.environ.get("TGS_FRONT_SIDE_CLEAR", "1") != "0"   # A/B switch: next frame's counters cleared by the K1-check launch
+_SIDE_CLEAR = _os.environ.get("TGS_FRONT_SIDE_CLEAR", "1") != "0"   # A/B switch: next frame's counters cleared by extra workgroups of this frame's scan launch
 
 
 class FrontBuffers:
@@ -236,7 +236,7 @@ class FrontBuffers:
         self.tile_start.slot_ok = None     # quadrant bitmaps K6 leaves for K7 (rasterize_fwd allocates and fills them)
         self.sorted_gid = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
         self.scratch = torch.empty(lib.tgs_sort_scratch_bytes(cap), dtype=torch.uint8, device=dev)
-        self.cleared = False     # counters + status word already cleared (by the previous frame's K1-check launch)
+        self.cleared = False     # counters + status word already cleared (by the previous frame's scan launch)
 
 
 def project_bin_sort(cam: Camera, means, log_scales, quats, opac_logit, sh, sh_deg: int,
