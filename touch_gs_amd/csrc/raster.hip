@@ -998,6 +998,9 @@ __device__ __forceinline__ bool frame_is_chain_bound(const int32_t* __restrict__
 //     -- is k_raster_bwd_f2b's.  Batches behind the last pixel's stop position are never staged; their
 //     partial records are zero-filled up front.
 // (5 waves per SIMD -- amdgpu_waves_per_eu(5, 8): 96 VGPRs + 14 spilled -- 386 -> 508 us, same-box A/B: 112 VGPRs / 4 waves stay)
+#ifndef TGS_K7_FIRSTQ
+#define TGS_K7_FIRSTQ 0    // 1: the first quadrant a Gaussian reaches assigns its eight lane sums instead of clearing + accumulating (A/B switch: slower)
+#endif
 #ifndef TGS_K7_RECPF
 #define TGS_K7_RECPF 0     // 1: the next entry's staged record is read from LDS while the current entry is blended (A/B switch)
 #endif
@@ -1170,43 +1173,75 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
                          ((unsigned)((qm[2] >> j) & 1ull) << 2) | ((unsigned)((qm[3] >> j) & 1ull) << 3);
       const int pos = rel + j;
       // acc: 0..2 v_rgb, 3 v_depth, 4 S = sum q, 5 Sx, 6 Sy, 7 Quv   (rows of the reduction scratch)
-#pragma unroll
-      for (int c = 0; c < RED_ROWS; c++) acc[c] = 0.f;
       any = 0ull;   // lanes with a contributing pixel, kept as a scalar mask (see k_raster_bwd_f2b)
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        if (m & (1u << k)) {  // wave-uniform
-          const float s = eval_s(qa, qb, pc, k);
-          const float e = __builtin_amdgcn_exp2f(-s);
-          const float al0 = MAYCLAMP ? fminf(ALPHA_MAX, e) : e;
-          // the forward's alpha test (same bits) below the pixel's stop position: exactly the contributions
-          const bool ok = s <= LOG2_255, in = pos < lim[k];
-          const bool go = ok & in;
-          // each ballot sits next to its compare, so it IS the compare's scalar result (a ballot of `go` costs
-          // a v_cndmask + v_cmp per slot)
-          const unsigned long long gob = __builtin_amdgcn_ballot_w64(ok) & __builtin_amdgcn_ballot_w64(in);
-          const float al = go ? al0 : 0.f;
-          const float ra = __builtin_amdgcn_rcpf(1.0f - al);    // = 1 exactly when al == 0
-          const float Tp = T[k] * ra;                           // transmittance in front of this Gaussian
-          const float w = al * Tp;
+      // One quadrant of the Gaussian.  FIRST (TGS_K7_FIRSTQ, an experiment that LOST): the first quadrant a Gaussian
+      // reaches ASSIGNS the eight sums (w v instead of fma(w, v, 0): the same bits), which removes the eight v_mov that
+      // clear them -- 6 of ~86 VALU instructions per pair -- at the price of a four-way scalar switch and ten copies of
+      // this body instead of four: 383 -> 419 us (profiles/r5_ab_runs.txt).  Scalar branches are not free here.
+      auto quad = [&](auto KC, auto FC) {
+        constexpr int k = decltype(KC)::value;
+        constexpr bool FIRST = decltype(FC)::value;
+        const float s = eval_s(qa, qb, pc, k);
+        const float e = __builtin_amdgcn_exp2f(-s);
+        const float al0 = MAYCLAMP ? fminf(ALPHA_MAX, e) : e;
+        // the forward's alpha test (same bits) below the pixel's stop position: exactly the contributions
+        const bool ok = s <= LOG2_255, in = pos < lim[k];
+        const bool go = ok & in;
+        // each ballot sits next to its compare, so it IS the compare's scalar result (a ballot of `go` costs
+        // a v_cndmask + v_cmp per slot)
+        const unsigned long long gob = __builtin_amdgcn_ballot_w64(ok) & __builtin_amdgcn_ballot_w64(in);
+        const float al = go ? al0 : 0.f;
+        const float ra = __builtin_amdgcn_rcpf(1.0f - al);    // = 1 exactly when al == 0
+        const float Tp = T[k] * ra;                           // transmittance in front of this Gaussian
+        const float w = al * Tp;
+        float cv = qb.w * vCr[k];
+        cv = fmaf(qc.x, vCg[k], cv); cv = fmaf(qc.y, vCb[k], cv); cv = fmaf(qb.z, vD[k], cv);
+        // q = opacity e^-sigma dL/dalpha = alpha (T c.v - SX / (1 - alpha))   (B.7); = 0 when al == 0.
+        // Under the 0.999 clamp (opacity > 0.999 and sigma ~ 0) q is rescaled by e^-s / 0.999 (pass-through).
+        const float z = w * cv;
+        float q = fmaf(-(al * ra), SX[k], z);
+        if constexpr (MAYCLAMP) q *= fmaxf(e * (1.0f / ALPHA_MAX), 1.0f);
+        SX[k] += z;
+        T[k] = Tp;
+        if constexpr (FIRST) {
+          acc[0] = w * vCr[k]; acc[1] = w * vCg[k]; acc[2] = w * vCb[k]; acc[3] = w * vD[k];
+          acc[4] = q;
+          acc[5] = (k & 1) ? q : 0.f;
+          acc[6] = (k >> 1) ? q : 0.f;
+          acc[7] = q * pc.uv[k];
+        } else {
           acc[0] = fmaf(w, vCr[k], acc[0]); acc[1] = fmaf(w, vCg[k], acc[1]);
           acc[2] = fmaf(w, vCb[k], acc[2]); acc[3] = fmaf(w, vD[k], acc[3]);
-          float cv = qb.w * vCr[k];
-          cv = fmaf(qc.x, vCg[k], cv); cv = fmaf(qc.y, vCb[k], cv); cv = fmaf(qb.z, vD[k], cv);
-          // q = opacity e^-sigma dL/dalpha = alpha (T c.v - SX / (1 - alpha))   (B.7); = 0 when al == 0.
-          // Under the 0.999 clamp (opacity > 0.999 and sigma ~ 0) q is rescaled by e^-s / 0.999 (pass-through).
-          const float z = w * cv;
-          float q = fmaf(-(al * ra), SX[k], z);
-          if constexpr (MAYCLAMP) q *= fmaxf(e * (1.0f / ALPHA_MAX), 1.0f);
-          SX[k] += z;
-          T[k] = Tp;
           acc[4] += q;
           if (k & 1) acc[5] += q;
           if (k >> 1) acc[6] += q;
           acc[7] = fmaf(q, pc.uv[k], acc[7]);
-          any |= gob;
         }
+        any |= gob;
+      };
+#if TGS_K7_FIRSTQ
+      using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+      const std::true_type F{}; const std::false_type A{};
+      // a four-way scalar switch on the first quadrant (separate code per case: an `if (first)` inside one body is
+      // if-converted into eight more selects per quadrant)
+      switch (__builtin_ctz(m | 16u)) {
+        case 0: quad(I0{}, F); if (m & 2u) quad(I1{}, A); if (m & 4u) quad(I2{}, A); if (m & 8u) quad(I3{}, A); break;
+        case 1: quad(I1{}, F); if (m & 4u) quad(I2{}, A); if (m & 8u) quad(I3{}, A); break;
+        case 2: quad(I2{}, F); if (m & 8u) quad(I3{}, A); break;
+        case 3: quad(I3{}, F); break;
+        default:     // (cannot happen: the walk only visits entries with a quadrant bit) keep the sums defined
+#pragma unroll
+          for (int c = 0; c < RED_ROWS; c++) acc[c] = 0.f;
       }
+#else
+#pragma unroll
+      for (int c = 0; c < RED_ROWS; c++) acc[c] = 0.f;
+      if (m & 1u) quad(std::integral_constant<int, 0>{}, std::false_type{});
+      if (m & 2u) quad(std::integral_constant<int, 1>{}, std::false_type{});
+      if (m & 4u) quad(std::integral_constant<int, 2>{}, std::false_type{});
+      if (m & 8u) quad(std::integral_constant<int, 3>{}, std::false_type{});
+#endif
     };
     // the weighted transposed sum of one Gaussian's 64 x 8 lane values out of `rd` (see the kernel's head comment)
     auto reduce_rows = [&](const float* rd) {
