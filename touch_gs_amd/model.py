@@ -594,8 +594,10 @@ class DepthGaussianSplattingModel:
         self.step += 1
         if self.budget.speculative:
             self._speculative_track(full_view, distributed)
-        elif distributed and getattr(dp, "peer", None) is not None:
-            # synchronous budget: no guard words exist, so the error word is read every step (this mode syncs per step anyway)
+        elif self.budget.sync and distributed and getattr(dp, "peer", None) is not None:
+            # synchronous budget: no guard words exist, so the error word is read every step (this mode syncs per step
+            # anyway).  A pre-sized sync-free budget (bench.py) neither syncs nor polls: its caller checks the transport
+            # at its own sync point (GradSync.check_transport), as it checks the budget.
             dp.peer.raise_if(int(dp.peer.err_word.item()))
         if density is not None and density.due(self.step) and getattr(self, "_refined_at", None) != self.step:
             if self.budget.speculative:
