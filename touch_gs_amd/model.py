@@ -562,8 +562,9 @@ class DepthGaussianSplattingModel:
             if self.budget.speculative:   # agree the overflow verdict across ranks before anything touches the model
                 if self._dp_status is None:
                     self._dp_status = torch.zeros(2, dtype=torch.int32, device=self.params.flat.device)
-                    # a peer-exchange wait that times out raises both words: this step and every later one are voided
-                    dp.set_poison_words(self.budget.sticky_word(self.params.flat.device), self._dp_status)
+                # a peer-exchange wait that times out raises both words: this step and every later one are voided.  Set every
+                # step: a refinement replaces the budget, and with it the sticky word the transport would otherwise keep pointing at
+                dp.set_poison_words(self.budget.sticky_word(self.params.flat.device), self._dp_status)
                 dguard = self._dp_status
 
             rows = self._color_rows
