@@ -3,6 +3,8 @@ GaussianRasterizer, the Splatfacto-style model (autograd path == fused path) and
 import math
 
 import numpy as np
+import time
+
 import pytest
 import torch
 
@@ -788,6 +790,55 @@ def test_speculative_budget_equals_synchronous_budget(dev, capacity, announce):
                  (spec.optimizer.exp_avg_sq, ref.optimizer.exp_avg_sq)):
         assert torch.equal(x, y)
     assert torch.equal(spec.last["rgb"], ref.last["rgb"])
+
+
+def test_peer_wait_timeout_poisons_the_step_and_alloc_reports_its_memory_kind(dev):
+    """ADVICE r4 / VERDICT r4 next #5c.  tgs_peer_alloc returns the kind of device memory it obtained and refuses what the
+    caller did not allow (no silent downgrade to plain memory).  A tgs_peer_wait whose flag never arrives gives up after
+    its timeout, records which flag was missing, and raises the two poison words -- with the sticky word raised
+    tgs_dp_agree_overflow declares the step void whatever the ranks' flags say, and a guarded optimizer kernel behind it
+    changes nothing."""
+    import ctypes as C
+    from touch_gs_amd import _lib, ops
+    from touch_gs_amd.optim import FusedAdam, GaussianParams
+    lib = _lib.load()
+    base, handle, kind = C.c_void_p(), (C.c_ubyte * 64)(), C.c_int(0)
+    _lib.check(lib.tgs_peer_alloc(4096, 1 | 2, C.byref(base), handle, C.byref(kind)), "tgs_peer_alloc")
+    assert kind.value in (1, 2)                                  # uncached or fine-grained, as asked
+    try:
+        assert lib.tgs_peer_alloc(4096, 0, C.byref(C.c_void_p()), handle, None) == -1        # nothing allowed: refused
+        sticky = torch.zeros(1, dtype=torch.int32, device=dev)
+        verdict = torch.zeros(2, dtype=torch.int32, device=dev)
+        flags = (C.c_void_p * 1)(base.value)                     # a flag word (zeroed) that nobody will raise
+        err = base.value + 64
+        t0 = time.perf_counter()
+        _lib.check(lib.tgs_peer_wait(1, flags, 5, err, C.c_float(0.05), _lib.ptr(sticky), _lib.ptr(verdict) + 4, None), "tgs_peer_wait")
+        torch.cuda.synchronize()
+        assert time.perf_counter() - t0 < 5.0                    # gave up after ~50 ms, not after the default 20 s
+        # the error word lives in the peer buffer: read it through a device tensor view, as PeerExchange does
+        from touch_gs_amd.parallel import _RawDeviceArray
+        e = torch.as_tensor(_RawDeviceArray(err, 1, "<i4"), device=dev)
+        assert int(e.item()) == 1                                # 1 + index of the missing flag
+        assert int(sticky.item()) == 1 and verdict.tolist() == [0, 1]
+        # the agreed verdict with the sticky word raised: void, whatever the gathered flags say
+        N = 64
+        blocks = torch.zeros(2, 3 * N + 4, device=dev)           # two ranks' colour blocks, overflow pads = 0
+        out = torch.zeros(2, dtype=torch.int32, device=dev)
+        ops.dp_agree_overflow(2, N, blocks, out, sticky)
+        assert out.tolist() == [0, 1]
+        sticky.zero_()
+        ops.dp_agree_overflow(2, N, blocks, out, sticky)
+        assert out.tolist() == [0, 0]
+        # a guarded optimizer kernel behind the poisoned verdict is a no-op
+        gp = GaussianParams.allocate(N, 16, dev)
+        gp.flat.copy_(torch.randn_like(gp.flat)); gp.grad.copy_(torch.randn_like(gp.flat))
+        opt = FusedAdam(gp, dict(means=1e-3, log_scales=1e-3, quats=1e-3, opac_logit=1e-3, sh_dc=1e-3, sh_rest=1e-3))
+        before = gp.flat.clone()
+        opt.step(guard=verdict)
+        torch.cuda.synchronize()
+        assert torch.equal(gp.flat, before)
+    finally:
+        lib.tgs_peer_free(base)
 
 
 def test_learned_list_hint_skips_launches_and_a_broken_hint_is_replayed(dev):
