@@ -462,7 +462,7 @@ static int ssim_impl(int W, int H, const float* img, const float* gt, float weig
   for (int i = 0; i < WIN; i++) win.g[i] = (float)(g[i] / sum);
   static const int env_nblk = [] { const char* e = getenv("TGS_SSIM_NBLK"); return e ? max(2, min(16, atoi(e))) : 0; }();
   // TGS_SSIM_FUSED=1 selects the one-pass kernel.  Default 0: measured SLOWER (1080p 119 against 108 us alone, 104 against 100
-  // inside the step, profiles/r5_ssim_one_pass.txt) although it moves a third of the bytes -- the two kernels are not
+  // inside the step, profiles/r5_ssim_one_pass.txt) although it moves half the bytes (171 against 343 MB, PMC) -- the two kernels are not
   // HBM-bound (3.3 TB/s), and the one-pass form pays 1.5x the forward arithmetic (halo) at 3 workgroups per CU (45 KB of LDS)
   static const int env_fused = [] { const char* e = getenv("TGS_SSIM_FUSED"); return e ? atoi(e) : 0; }();
   if (v_img && env_fused && y1 > y0 && count_inside(y0, y1, c0, c1)) {
