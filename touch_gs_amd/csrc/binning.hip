@@ -402,7 +402,7 @@ __device__ __forceinline__ void xcd_order_regs(int T, int x, int c, int chunk,
   }
 }
 
-// common classes: lists <= 512 (8 keys per lane) and <= 1024 (16 keys per lane); one wave per tile
+// common classes: lists <= 64 / 128 / 256 / 512 / 1024 entries with 1 / 2 / 4 / 8 / 16 keys per lane; one wave per tile
 // `sorted_up_to`: the longest list some launch of this frame sorts (1024 / 4096 / INT_MAX by the caller's
 // max_list_hint).  A longer list means the caller's hint was wrong: the wave copies the ids UNSORTED -- valid indices,
 // so the compositing kernels run on without faulting -- and raises the overflow flag and the sticky word: the frame
@@ -434,7 +434,13 @@ __global__ __launch_bounds__(TGS_WAVE) void k_sort_tiles_wave(
     if (lane == 0) sorted_gid[s] = (int)(pairs[s] & 0xffffffffull);
     return;
   }
-  if (n <= 512) sort_tile_regs<8, 1>(pairs, sorted_gid, s, n, lane, nullptr);
+  // keys per lane by list length: the network's work is (stages x keys per lane) = 21 / 56 / 144 / 360 / 864 for
+  // 1 / 2 / 4 / 8 / 16 keys, so a list of 200 entries costs 0.4 of what it cost padded to 512 (round 5; the short lists are
+  // the periphery of every frame and most of an object-centric one)
+  if (n <= 64) sort_tile_regs<1, 1>(pairs, sorted_gid, s, n, lane, nullptr);
+  else if (n <= 128) sort_tile_regs<2, 1>(pairs, sorted_gid, s, n, lane, nullptr);
+  else if (n <= 256) sort_tile_regs<4, 1>(pairs, sorted_gid, s, n, lane, nullptr);
+  else if (n <= 512) sort_tile_regs<8, 1>(pairs, sorted_gid, s, n, lane, nullptr);
   else sort_tile_regs<16, 1>(pairs, sorted_gid, s, n, lane, nullptr);
 }
 
