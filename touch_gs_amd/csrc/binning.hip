@@ -103,7 +103,12 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int T, int NB, int32_t* __r
     int mg = 0;
     // (a frame voided by its front tag has no records: the K1 that would have written them never ran -- the buffers hold
     // whatever the allocator left, and a garbage "sufficient capacity" would make the caller grow to it)
+#if TGS_MG_ATOMIC
+    if (!voided && tid < TGS_XCC) mg = tile_count[TGS_MAXG_OFF(T) + tid * TGS_ALLOC_STRIDE];   // folded in by every K1 group
+    const int G = 0;
+#else
     const int G = voided ? 0 : (N + TGS_GROUP - 1) / TGS_GROUP;
+#endif
     for (int g = tid; g < G; g += 1024) {
       const float* rec = splats + (size_t)min(g * TGS_GROUP + TGS_GROUP - 1, N - 1) * TGS_SPLAT_FLOATS;
       int x0, y0, w, h;

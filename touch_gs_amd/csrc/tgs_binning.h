@@ -50,7 +50,16 @@ int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* gro
 // serialise at ~13 ns each).
 #define TGS_ALLOC_STRIDE 32
 #define TGS_ALLOC_OFF(T) ((2 * TGS_XCC * (T) + TGS_SCAN_WGS + 4 + 31) / 32 * 32)
-static inline int tgs_counter_len(int T) { return TGS_ALLOC_OFF(T) + TGS_XCC * TGS_ALLOC_STRIDE; }
+// ... | largest group total: one word per XCD, each in a 128-B line of its own behind the allocator lines (round 5).  Every
+// K1 / count workgroup folds its group's pair total in with a fire-and-forget atomicMax; k_scan_tiles takes the maximum of
+// the 8 words for status[2] = #pairs + 8 x the largest group.  (The scan's status workgroup used to read the total off the
+// last record of each of the N / 256 groups: four dependent scattered loads per thread on the scan launch's critical path.
+// On lines of their own the 3906 atomics of a cfg3 frame do not sit behind the allocators' returning atomics.)
+#ifndef TGS_MG_ATOMIC
+#define TGS_MG_ATOMIC 1
+#endif
+#define TGS_MAXG_OFF(T) (TGS_ALLOC_OFF(T) + TGS_XCC * TGS_ALLOC_STRIDE)
+static inline int tgs_counter_len(int T) { return TGS_MAXG_OFF(T) + TGS_XCC * TGS_ALLOC_STRIDE; }
 
 // Aggregated counting (spatially ordered parameter buffers): when the tile bounding box of a group's
 // 256 Gaussians holds at most TGS_AGG_TILES tiles, its pairs are first counted per tile in an LDS
@@ -146,6 +155,7 @@ __device__ __forceinline__ void clear_counters_elem(int i, int32_t* __restrict__
   if (i < TGS_XCC * T) tile_cursor[i] = 0;
   if (i < TGS_SCAN_WGS + 4) tile_cursor[2 * TGS_XCC * T + i] = 0;   // look-back flags of k_scan_tiles, longest list
   if (i < 4 * TGS_XCC) tile_cursor[TGS_ALLOC_OFF(T) + (i >> 2) * TGS_ALLOC_STRIDE + (i & 3)] = 0;   // pair allocator lines
+  if (i < TGS_XCC) tile_cursor[TGS_MAXG_OFF(T) + i * TGS_ALLOC_STRIDE] = 0;                           // largest group total
   if (i == 0) status[0] = 0;
   if (i == 1) status[1] = sticky ? (*sticky != 0) : 0;
 }
@@ -185,7 +195,12 @@ __device__ __forceinline__ void group_count_tiles(GroupScan& S, int TW, int T, i
   // last (publication below), so its round trip to the memory side overlaps the counting.
   int local = 0;
   int32_t* __restrict__ alloc = tile_count + TGS_ALLOC_OFF(T);
-  if (tid == 0 && total > 0) local = atomicAdd(&alloc[x * TGS_ALLOC_STRIDE], total);
+  if (tid == 0 && total > 0) {
+    local = atomicAdd(&alloc[x * TGS_ALLOC_STRIDE], total);
+#if TGS_MG_ATOMIC
+    atomicMax(&tile_count[TGS_MAXG_OFF(T) + x * TGS_ALLOC_STRIDE], total);   // result unused: no return, no wait
+#endif
+  }
   int32_t* __restrict__ my_count = tile_count + (size_t)x * T;
   int bx0 = 1 << 30, by0 = 1 << 30, bx1 = 0, by1 = 0;   // tile bounding box of the group's rects
 #pragma unroll
