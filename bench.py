@@ -474,11 +474,11 @@ def _main():
         n_isect.append(b.last_n)
         n_need.append(b.last_need)   # capacity under the per-XCD split of the pair index space (tgs.h)
         n_longest.append(b.last_longest)
-    # ... and bound the longest tile list the same way (1.25 x the longest list of any view + 64: the capacity's margin; the
+    # ... and bound the longest tile list the same way (1.25 x the longest list of any view + 32: the capacity's margin; the
     # trainer's speculative budget learns its bound from the frames it has settled): the sort launches for longer list classes
     # are not issued; a frame that broke the bound would be void and budget.check() after the timed region would raise
     model.budget = ops.IntersectBudget(capacity=int(max(n_need) * 1.25) + 4096, sync=False,
-                                       max_list_hint=-1 if args.no_list_hint else int(1.25 * max(n_longest)) + 64)
+                                       max_list_hint=-1 if args.no_list_hint else int(1.25 * max(n_longest)) + 32)
     del sp
     torch.cuda.empty_cache()
 

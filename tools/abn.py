@@ -40,7 +40,7 @@ for v in views:
     need = max(need, b.last_need)
     longest = max(longest, b.last_longest)
 budget = ops.IntersectBudget(capacity=int(need * 1.25) + 4096, sync=False,
-                             max_list_hint=-1 if os.environ.get("TGS_AB_NO_LIST_HINT") else int(1.25 * longest) + 64)
+                             max_list_hint=-1 if os.environ.get("TGS_AB_NO_LIST_HINT") else int(1.25 * longest) + 32)
 ev = lambda: torch.cuda.Event(enable_timing=True)
 names = ["front", "k6", "ssim", "k7", "k8"]
 per_view = []
