@@ -106,7 +106,10 @@ struct RowBlock {
   static __device__ __forceinline__ void stage2(const float* __restrict__ src_a, const float* __restrict__ src_b,
                                                 float* __restrict__ lds_a, float* __restrict__ lds_b,
                                                 int W, int H, int x0, int r0, int tid) {
-    constexpr int B = 7;
+#ifndef TGS_SSIM_FWD_B
+#define TGS_SSIM_FWD_B 13   // all 13 + 13 loads of a block in flight at once (round 5: 128 VGPRs, still 4 waves per SIMD); 7 = two rounds
+#endif
+    constexpr int B = TGS_SSIM_FWD_B;
 #pragma unroll 1
     for (int it0 = 0; it0 < NIT; it0 += B) {
       float va[B], vb[B];
@@ -277,7 +280,10 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     __syncthreads();
     {
       // 38 loads per thread and block: three rounds of 13 in flight (the kernel has registers to spare)
-      RowBlock<9>::stage<13>(adj, sadj, W, H, x0, r0, tid);
+#ifndef TGS_SSIM_BWD_B
+#define TGS_SSIM_BWD_B 20   // two rounds of 20 instead of three of 13 (66 VGPRs); all 39 at once spills.  Both: 99.4 -> 97.7 us (r5_ab_runs.txt)
+#endif
+      RowBlock<9>::stage<TGS_SSIM_BWD_B>(adj, sadj, W, H, x0, r0, tid);
     }
     __syncthreads();
 #endif
