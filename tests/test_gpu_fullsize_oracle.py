@@ -37,6 +37,26 @@ TOL = 1e-4
 CLEAR_MEASURED = {"cfg2_100k_800x800": 0.987, "cfg3_1M_1080p": 0.960, "cfg5_5M_4K": 0.91}
 
 
+# Not BASELINE configs: scenes that put one code path under the same oracle machinery (their own tests below).
+#   huge_720p: the reference's image size with a dozen SCREEN-FILLING Gaussians (a table / background Gaussian of a
+#   converged object-centric model covers 1000 - 3600 tiles): K8's workgroup-shared segmented sum of long runs, the
+#   direct counting path and k_fill_bins on groups of tens of thousands of pairs (round 6).
+EXTRA_CONFIGS = {"huge_720p": (30_000, 1280, 720, 3, 77, 1)}
+HUGE_EVERY = 2500     # rows 0, 2500, 5000, ... of huge_720p are blown up
+
+
+def _mutate_huge(P):
+    idx = torch.arange(0, P["means"].shape[0], HUGE_EVERY)
+    # x 150, sigma ~ 1000 px on every axis (not isotropic: the quaternion gradient of three equal scales vanishes
+    # analytically and K8's fp32 chain then rounds at the size of its intermediates -- max_over(), exception (b))
+    P["log_scales"][idx] = P["log_scales"][idx].mean(1, keepdim=True) + 5.0 + torch.tensor([0.0, 0.3, -0.3]).to(P["log_scales"])
+    P["opac_logit"][idx] = -2.0            # faint (0.12), so that the scene behind them still contributes
+    P["means"][idx, 2] = P["means"][idx, 2].clamp(min=3.0)
+
+
+EXTRA_MUTATE = {"huge_720p": _mutate_huge}
+
+
 def order_ambiguous_tiles(sg_hip, ts_hip, g_ref, ts_ref, N):
     """Tiles in which the product's list orders some pair of Gaussians differently from the fp64 oracle's.
     The lists are sorted by the fp32 depth bits (as the CUDA rasterizers behind the reference sort fp32 depth
@@ -86,8 +106,10 @@ def build_case(name, dev):
     """HIP path and fp64 C oracle on one BASELINE config (also used by tools/grad_offenders.py)."""
     from touch_gs_amd import ops
     from touch_gs_amd.scene import make_camera, synthetic_gaussians
-    N, W, H, deg, seed, view = CONFIGS[name]
+    N, W, H, deg, seed, view = (CONFIGS.get(name) or EXTRA_CONFIGS[name])[:6]
     P, intr = synthetic_gaussians(N, W, H, deg, seed)
+    if name in EXTRA_MUTATE:
+        EXTRA_MUTATE[name](P)
     cam = make_camera(intr, view, 8, bg=(0.1, 0.2, 0.3))
     D = {k: v.to(dev).contiguous() for k, v in P.items()}
     # ---- HIP ----
@@ -436,3 +458,38 @@ def test_train_step_matches_oracle_fullsize(both, dev):
             cos = (ref * got[name]).sum() / np.sqrt((ref * ref).sum() * (got[name] * got[name]).sum())
             rel_l2 = np.sqrt(((got[name] - ref) ** 2).sum() / (ref * ref).sum())
             assert cos > 0.9999 and rel_l2 < 1e-2, (b["name"], tag, name, cos, rel_l2)
+
+
+
+def test_gradients_with_screen_filling_gaussians(dev):
+    """K8's segmented sum on LONG runs (round 6) and the front half on huge rects, against the fp64 oracle: a 720p frame
+    with a dozen Gaussians that cover 2000 - 3600 tiles each (what the table / background Gaussians of a converged
+    object-centric model do -- profiles/r6_before_ckpt_loop_*.json: max_hits 2695 - 3600).  Until round 6 one thread
+    added such a run record by record; now the workgroup's 16-lane teams sum it in 64-record segments (project.hip,
+    group_sum_partials).  Same bar as the full-size test for everything decision-clear; the huge Gaussians reach every
+    pixel of the image, so some pixel of theirs is always decision-ambiguous and the clear / unclear classification says
+    nothing about them -- but a flipped 1/255 contribution is nothing against the sum over 900 k pixels, so THEIR ten
+    screen-space gradients and five parameter gradients are asserted directly, at 1e-4 of the un-cancelled magnitude."""
+    from tests.util import K7_KEYS, PARAM_KEYS, err_over_mass, k7_outputs, param_mass
+    b = build_case("huge_720p", dev)
+    N = b["N"]
+    f = splat_fields(b["sp"], b["radii"])
+    hits = f["hits"].numpy()
+    huge = np.zeros(N, bool)
+    huge[::HUGE_EVERY] = True
+    assert (hits[huge] >= 2000).sum() >= 8, hits[huge]
+    pm, reach, clear = classify_gaussians(b)
+    report = [f"huge_720p: {int(huge.sum())} blown-up Gaussians with {hits[huge].min()} - {hits[huge].max()} tiles, "
+              f"{b['n_hip']} pairs; clear Gaussians {clear.sum() / max(reach.sum(), 1):.4f} of the reaching ones"]
+    ref7 = {k: np.asarray(b["bb"][k], np.float64).reshape(N, -1) for k in K7_KEYS}
+    got7 = k7_outputs(b["v_splats"])
+    assert_gradients("huge_720p", got7, ref7, b["m7"], reach, clear, K7_KEYS, report)
+    pmass = param_mass(b["R"], b["Pn"], b["deg"], b["cb"], b["W"], b["H"], b["pc"]["radius"], b["m7"])
+    got = dict(zip(PARAM_KEYS, b["grads"]))
+    assert_gradients("huge_720p", got, b["pb"], pmass, reach, clear, PARAM_KEYS, report)
+    for keys, g_, r_, m_ in ((K7_KEYS, got7, ref7, b["m7"]), (PARAM_KEYS, got, b["pb"], pmass)):
+        for key in keys:
+            e = err_over_mass(g_[key], r_[key], m_[key])[huge & (hits >= 2000)]
+            report.append(f"{key}: the huge Gaussians' error / mass: max {e.max():.1e}")
+            assert e.max() < GTOL, (key, e)
+    print("\n".join(report))

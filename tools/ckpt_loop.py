@@ -103,14 +103,22 @@ def main():
     ap.add_argument("--breakdown", action="store_true")
     ap.add_argument("--no-freeze", action="store_true", help="keep the learning rates (the model then drifts from its optimum)")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--layout", default="balanced", choices=("balanced", "morton"),
+                    help="row order: Morton with the long-run Gaussians dealt over the groups (the trainer's) or plain Morton")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     m, views = load(a.ckpt, dev, a.views, freeze=not a.no_freeze)
     out = {"ckpt": os.path.basename(a.ckpt), "N": m.params.N, "views": len(views), "W": views[0].cam.W, "H": views[0].cam.H}
+    m.config.spatial_sort = True
+    m.config.balance_long_runs = a.layout == "balanced"
+    if a.layout == "balanced":     # the trainer re-sorts with steps behind it (it keeps their cameras): learning rates are frozen
+        for v in views[:16]:
+            m.train_step(v)
+        torch.cuda.synchronize()
+    m.spatial_sort()
+    out["layout"] = a.layout
     if a.breakdown:
         out["breakdown"] = breakdown(m, views[:3])
-    m.config.spatial_sort = True
-    m.spatial_sort()
     m.enable_speculative_budget()
     n = len(views)
     for s in range(a.warmup):

@@ -454,19 +454,8 @@ __global__ __launch_bounds__(256) void k_adam_geom_project_next(
 // ---------------------------------------------------------------------------------------------
 // K8a: partials -> one gradient record per Gaussian
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void sum_partials(const CamK& cam, const float* __restrict__ splats,
-                                             const int32_t* __restrict__ group_base,
-                                             const float* __restrict__ partials, int g, float* v) {
-#pragma unroll
-  for (int i = 0; i < 10; i++) v[i] = 0.f;
-  const float* rec = splats + (size_t)g * TGS_SPLAT_FLOATS;
-  const float4 r2 = ld4(rec + 8);
-  int x0, y0, w, h;
-  unpack_rect(__float_as_uint(r2.z), x0, y0, w, h);
-  const int hits = w * h;
-  if (hits == 0) return;
-  const size_t off = (size_t)group_base[g / TGS_GROUP] + (size_t)__float_as_int(r2.w);
-  const float* p = partials + off * TGS_PARTIAL_FLOATS;
+// One Gaussian's run of `hits` partial records, summed by its owner thread in the order k = 0, 1, 2, ...
+__device__ __forceinline__ void sum_run_serial(const float* __restrict__ p, int hits, float* v) {
   // 4 records (12 independent 16-B loads) in flight per round: the loop is latency-bound
   // otherwise.  Accumulation order is still k = 0, 1, 2, ... (bit-identical to a serial loop).
   for (int k0 = 0; k0 < hits; k0 += 4, p += 4 * TGS_PARTIAL_FLOATS) {
@@ -491,13 +480,154 @@ __device__ __forceinline__ void sum_partials(const CamK& cam, const float* __res
   }
 }
 
+// Segmented sum of the partial records of a workgroup's 256 Gaussians (round 6).
+//
+// A Gaussian's records are contiguous (one per tile of its rect) and until round 5 its owner thread added them
+// one after the other.  That is a latency chain of hits / 4 dependent round trips: fine for the ~4 records of a
+// cfg3 Gaussian, but a converged object-centric model (the reference's kind of scene: an object on a table at
+// 1280 x 720) has table / background Gaussians that cover 1000 - 3600 tiles, and ONE thread's chain of 900 round
+// trips then IS the kernel: K8 150 - 400 us for 79 k Gaussians against 120 us for cfg3's 1 M
+// (profiles/r5_train_quality.json, r6_before_kernel_stats_*_720p.csv).  Now runs longer than TGS_LONG_RUN are cut
+// into segments of TGS_RUN_SEG records and the workgroup's sixteen 16-lane teams take 16 segments per round:
+// lane q of a team adds records q, q + 16, q + 32, q + 48 of its segment (all twelve loads in flight), a DPP tree
+// over the team's 16 lanes forms the segment's sum, and the owner thread adds its segments' sums in order.  The
+// shape of every sum depends on `hits` alone -- not on which Gaussians share the group, nor on scheduling -- so the
+// result is bit-reproducible and independent of the row order, as before.  Groups without a long run (all of a
+// uniform scene's) leave through one __syncthreads_or.
+#define TGS_RUN_SEG 64     // (TGS_LONG_RUN: tgs_binning.h)
+struct RunScan {
+  int seg_off[TGS_GROUP + 1];   // exclusive scan of the Gaussians' segment counts (0 for short runs)
+  int base[TGS_GROUP];          // first pair index of the Gaussian's run (capacity < 2^31)
+  int hits[TGS_GROUP];
+  int wave_tot[TGS_GROUP / TGS_WAVE];
+  float seg_sum[2][16][12];     // the teams' results of a round, double buffered (10 of 12 used)
+};
+
+template <int CTRL>
+__device__ __forceinline__ float row_dpp_add(float v) {
+  const int s = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
+  return v + __builtin_bit_cast(float, s);
+}
+// sum over the 16 lanes of a DPP row, in every lane of the row
+__device__ __forceinline__ float row_sum16(float v) {
+  v = row_dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+  v = row_dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+  v = row_dpp_add<0x141>(v);   // row_half_mirror
+  v = row_dpp_add<0x140>(v);   // row_mirror
+  return v;
+}
+
+// Must be called by all TGS_GROUP threads of the workgroup (g >= N: no Gaussian); S may alias LDS that is reused
+// afterwards (the function ends with a barrier whenever it has touched S).
+__device__ __forceinline__ void group_sum_partials(const float* __restrict__ splats,
+                                                   const int32_t* __restrict__ group_base,
+                                                   const float* __restrict__ partials, int g, int N, float* v,
+                                                   RunScan& S) {
+#pragma unroll
+  for (int i = 0; i < 10; i++) v[i] = 0.f;
+  const int tid = threadIdx.x;
+  int hits = 0, base = 0;
+  if (g < N) {
+    const float4 r2 = ld4(splats + (size_t)g * TGS_SPLAT_FLOATS + 8);
+    int x0, y0, w, h;
+    unpack_rect(__float_as_uint(r2.z), x0, y0, w, h);
+    hits = w * h;
+    if (hits) base = group_base[g / TGS_GROUP] + __float_as_int(r2.w);
+  }
+  const bool big = hits > TGS_LONG_RUN;
+  if (!__syncthreads_or(big)) {        // nothing long in this group
+    sum_run_serial(partials + (size_t)base * TGS_PARTIAL_FLOATS, hits, v);
+    return;
+  }
+  const int nseg = big ? (hits + TGS_RUN_SEG - 1) / TGS_RUN_SEG : 0;
+  int incl = nseg;
+#pragma unroll
+  for (int o = 1; o < TGS_WAVE; o <<= 1) {
+    const int t = __shfl_up(incl, o);
+    if ((tid & (TGS_WAVE - 1)) >= o) incl += t;
+  }
+  if ((tid & (TGS_WAVE - 1)) == TGS_WAVE - 1) S.wave_tot[tid / TGS_WAVE] = incl;
+  S.base[tid] = base;
+  S.hits[tid] = hits;
+  __syncthreads();
+  int my_off = incl - nseg, total = 0;
+#pragma unroll
+  for (int i = 0; i < TGS_GROUP / TGS_WAVE; i++) {
+    if (i < tid / TGS_WAVE) my_off += S.wave_tot[i];
+    total += S.wave_tot[i];
+  }
+  S.seg_off[tid] = my_off;
+  if (tid == 0) S.seg_off[TGS_GROUP] = total;
+  if (!big) sum_run_serial(partials + (size_t)base * TGS_PARTIAL_FLOATS, hits, v);   // the short runs, as ever
+  __syncthreads();
+  const int team = tid >> 4, q = tid & 15;
+  for (int s0 = 0, buf = 0; s0 < total; s0 += 16, buf ^= 1) {
+    const int s = s0 + team;
+    if (s < total) {                   // uniform over the team's DPP row
+      // owner of segment s: the last j with seg_off[j] <= s (entries without segments repeat their successor's offset)
+      int lo = 0, hi = TGS_GROUP;
+#pragma unroll
+      for (int it = 0; it < 8; it++) {
+        const int mid = (lo + hi) >> 1;
+        if (S.seg_off[mid] <= s) lo = mid; else hi = mid;
+      }
+      const int k0 = (s - S.seg_off[lo]) * TGS_RUN_SEG;
+      const int cnt = min(TGS_RUN_SEG, S.hits[lo] - k0);
+      const float* p = partials + ((size_t)S.base[lo] + (size_t)(k0 + q)) * TGS_PARTIAL_FLOATS;
+      float4 a[4], b[4];
+      float2 c[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (q + 16 * u < cnt) {
+          a[u] = ld4_nt(p + 16 * u * TGS_PARTIAL_FLOATS);
+          b[u] = ld4_nt(p + 16 * u * TGS_PARTIAL_FLOATS + 4);
+          c[u] = *reinterpret_cast<const float2*>(p + 16 * u * TGS_PARTIAL_FLOATS + 8);
+        }
+      }
+      float t[10];
+#pragma unroll
+      for (int i = 0; i < 10; i++) t[i] = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (q + 16 * u < cnt) {
+          t[0] += a[u].x; t[1] += a[u].y; t[2] += a[u].z; t[3] += a[u].w;
+          t[4] += b[u].x; t[5] += b[u].y; t[6] += b[u].z; t[7] += b[u].w;
+          t[8] += c[u].x; t[9] += c[u].y;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 10; i++) t[i] = row_sum16(t[i]);
+      if (q == 0) {
+        float* o = S.seg_sum[buf][team];
+        st4(o, make_float4(t[0], t[1], t[2], t[3]));
+        st4(o + 4, make_float4(t[4], t[5], t[6], t[7]));
+        *reinterpret_cast<float2*>(o + 8) = make_float2(t[8], t[9]);
+      }
+    }
+    __syncthreads();
+    if (big) {                          // my segments of this round, in order
+      const int e = min(my_off + nseg, s0 + 16);
+      for (int sg = max(my_off, s0); sg < e; sg++) {
+        const float* o = S.seg_sum[buf][sg - s0];
+        const float4 x = ld4(o), y = ld4(o + 4);
+        const float2 z = *reinterpret_cast<const float2*>(o + 8);
+        v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
+        v[4] += y.x; v[5] += y.y; v[6] += y.z; v[7] += y.w;
+        v[8] += z.x; v[9] += z.y;
+      }
+    }
+  }
+  __syncthreads();   // S may be reused by the caller
+}
+
 __global__ __launch_bounds__(256) void k_reduce_partials(
     CamK cam, int N, const float* __restrict__ splats, const int32_t* __restrict__ group_base,
     const float* __restrict__ partials, float* __restrict__ v_splats) {
+  __shared__ RunScan S;
   const int g = blockIdx.x * 256 + threadIdx.x;
-  if (g >= N) return;
   float v[10];
-  sum_partials(cam, splats, group_base, partials, g, v);
+  group_sum_partials(splats, group_base, partials, g, N, v, S);
+  if (g >= N) return;
   float* o = v_splats + (size_t)g * TGS_SPLAT_FLOATS;
   st4(o, make_float4(v[0], v[1], v[2], v[3]));
   st4(o + 4, make_float4(v[4], v[5], v[6], v[7]));
@@ -595,8 +725,8 @@ __global__ __launch_bounds__(256) void k_project_bwd(
     float* __restrict__ v_log_scales, float* __restrict__ v_quats,
     float* __restrict__ v_opac_logit, float* __restrict__ v_sh, float* __restrict__ v_color,
     float* __restrict__ v_xy, const int32_t* __restrict__ guard) {
+  __shared__ RunScan S;
   const int g = blockIdx.x * 256 + threadIdx.x;
-  if (g >= N) return;
   if (guard && guard[1]) {  // overflowed frame: the pair index space is not backed by memory
     if (v_color && g == 0) v_color[3 * (size_t)N + 3] = 1.f;   // tell the other ranks (tgs_dp_agree_overflow)
     return;
@@ -607,9 +737,9 @@ __global__ __launch_bounds__(256) void k_project_bwd(
   }
   // per-Gaussian upstream gradient: {v_x, v_y, v_depth, v_opac, v_a, v_b, v_c, v_r, v_g, v_b}
   float v[10];
-  if (partials) {
-    sum_partials(cam, splats, group_base, partials, g, v);
-  } else {
+  if (partials) group_sum_partials(splats, group_base, partials, g, N, v, S);   // (workgroup-uniform: every thread calls)
+  if (g >= N) return;
+  if (!partials) {
     const float* p = v_splats + (size_t)g * TGS_SPLAT_FLOATS;
     const float4 a = ld4(p), b = ld4(p + 4);
     const float2 c = *reinterpret_cast<const float2*>(p + 8);
@@ -734,6 +864,11 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
   const int nrows = min(256, N - g0);
   const size_t blk = (size_t)g0 * ROW;
 
+  // per-Gaussian upstream gradient {v_x, v_y, v_depth, v_opac, v_a, v_b, v_c, v_r, v_g, v_b}: the segmented sum of the
+  // group's partial records, long runs shared by the whole workgroup.  Its scratch aliases the (not yet loaded) SH image.
+  static_assert(256 * (3 * KS + 4) * sizeof(float) >= sizeof(RunScan), "the run scan reuses the SH image");
+  float v[10];
+  group_sum_partials(splats, group_base, partials, g, N, v, *reinterpret_cast<RunScan*>(lds4));
   {
     const int nf = nrows * F4;
     for (int f0 = tid; f0 < nf; f0 += 256 * 4) {
@@ -765,8 +900,6 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
     }
   }
   if (g < N) {
-    float v[10];
-    sum_partials(cam, splats, group_base, partials, g, v);
     m[0] = means[3 * g]; m[1] = means[3 * g + 1]; m[2] = means[3 * g + 2];
     ol = opac_logit[g];
     const float o = 1.0f / (1.0f + expf(-ol));

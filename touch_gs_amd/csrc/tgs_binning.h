@@ -69,6 +69,10 @@ static inline int tgs_counter_len(int T) { return TGS_MAXG_OFF(T) + TGS_XCC * TG
 // ordered buffer spans the whole image and takes the direct path.
 #define TGS_AGG_TILES 1024
 #define TGS_AGG_U 4            // pairs per thread kept in registers by the aggregated path (256 * 4 per group)
+#define TGS_LONG_RUN 32        // runs of more tiles than this: outside the group's box (here), summed by the workgroup (K8)
+#ifndef TGS_DIRECT_U
+#define TGS_DIRECT_U 4         // pairs per thread and round of the direct counting path and of k_fill_bins
+#endif
 
 #ifdef __HIPCC__
 // binning group of this workgroup in K1 / k_tile_count
@@ -103,7 +107,8 @@ __device__ __forceinline__ int group_scan_store(GroupScan& S, int hits, int x0, 
   }
   if ((tid & (TGS_WAVE - 1)) == TGS_WAVE - 1) S.wave_tot[tid / TGS_WAVE] = incl;
   {   // tile bounding box of the wave's rects (DPP reductions; same-address LDS atomics would serialise)
-    const bool any = hits > 0;
+    // (Gaussians with long runs of tiles stay outside the box: their pairs are counted directly, group_count_tiles)
+    const bool any = hits > 0 && hits <= TGS_LONG_RUN;
     const int bx0 = wave_minmax_i<false>(any ? x0 : (1 << 30)), by0 = wave_minmax_i<false>(any ? y0 : (1 << 30));
     const int bx1 = wave_minmax_i<true>(any ? x0 + w : 0), by1 = wave_minmax_i<true>(any ? y0 + hits / max(w, 1) : 0);
     if ((tid & (TGS_WAVE - 1)) == 0) {
@@ -180,6 +185,44 @@ __device__ __forceinline__ void group_pair(const GroupScan& S, int TW, int i, in
   tile = (S.y0[lo] + ky) * TW + S.x0[lo] + (k - ky * w);
 }
 
+// U pairs of the group -> (local Gaussian, tile x, tile y), their binary searches in LOCK STEP: eight rounds of U
+// independent LDS reads instead of 8 U dependent ones (a pair per branch made every read wait for the one before:
+// ~1.6 us per round of four pairs on a CU that runs one workgroup -- the cost of k_fill_bins and of the counting loop
+// on a group of thousands of pairs, round 6).  Indices beyond `total` are clamped (the caller masks them).
+template <int U>
+__device__ __forceinline__ void group_pairs_xy(const GroupScan& S, int i0, int stride, int total, int (&j)[U], int (&tx)[U],
+                                               int (&ty)[U], bool (&valid)[U]) {
+  int lo[U], hi[U], ii[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    valid[u] = i0 + u * stride < total;
+    ii[u] = min(i0 + u * stride, total - 1);
+    lo[u] = 0; hi[u] = TGS_GROUP;
+  }
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    int o[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) o[u] = S.off[(lo[u] + hi[u]) >> 1];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int mid = (lo[u] + hi[u]) >> 1;
+      if (o[u] <= ii[u]) lo[u] = mid; else hi[u] = mid;
+    }
+  }
+  int of[U], w[U], x0[U], y0[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) { of[u] = S.off[lo[u]]; w[u] = S.w[lo[u]]; x0[u] = S.x0[lo[u]]; y0[u] = S.y0[lo[u]]; }
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int k = ii[u] - of[u];
+    const int ky = k / w[u];
+    j[u] = lo[u];
+    tx[u] = x0[u] + (k - ky * w[u]);
+    ty[u] = y0[u] + ky;
+  }
+}
+
 // Allocates the group's contiguous pair range and counts its intersections per tile; every pair
 // remembers its arrival rank inside its tile.  Call after group_scan_store + __syncthreads-free
 // (this function synchronises internally).
@@ -208,23 +251,36 @@ __device__ __forceinline__ void group_count_tiles(GroupScan& S, int TW, int T, i
     bx0 = min(bx0, S.wave_bbox[wv][0]); by0 = min(by0, S.wave_bbox[wv][1]);
     bx1 = max(bx1, S.wave_bbox[wv][2]); by1 = max(by1, S.wave_bbox[wv][3]);
   }
-  const int bw = bx1 - bx0, bh = by1 - by0;
+  const int bw = max(bx1 - bx0, 0), bh = max(by1 - by0, 0);
   const int area = bw * bh;
-  const bool agg = total > 0 && area <= TGS_AGG_TILES;   // workgroup-uniform
+  // The box holds the group's SHORT runs only (<= TGS_LONG_RUN tiles, round 6).  A Gaussian that covers hundreds of tiles
+  // would stretch it over the image and send all of the group's pairs down the direct path; its own pairs go there
+  // anyway (every tile once: nothing to aggregate), the others keep the histogram.  The trainer's row order deals such
+  // Gaussians evenly over the groups (optim.balanced_order), so nearly every group of an object-centric scene holds some.
+  const bool agg = total > 0 && area > 0 && area <= TGS_AGG_TILES;   // workgroup-uniform
   if (agg)
     for (int b = tid; b < area; b += TGS_GROUP) S.hist[b] = 0;
   __syncthreads();                                            // the group scan (and the cleared histogram) is visible
   int lr[TGS_AGG_U], lb[TGS_AGG_U];
   if (agg) {
+    {
+      int j[TGS_AGG_U], tx[TGS_AGG_U], ty[TGS_AGG_U];
+      bool valid[TGS_AGG_U], lng[TGS_AGG_U];
+      group_pairs_xy<TGS_AGG_U>(S, tid, TGS_GROUP, total, j, tx, ty, valid);
 #pragma unroll
-    for (int u = 0; u < TGS_AGG_U; u++) {
-      const int i = tid + u * TGS_GROUP;
-      lb[u] = -1; lr[u] = 0;
-      if (i < total) {
-        int j, tx, ty;
-        group_pair_xy(S, i, j, tx, ty);
-        lb[u] = (ty - by0) * bw + (tx - bx0);
-        lr[u] = atomicAdd(&S.hist[lb[u]], 1);                 // LDS: rank among the group's pairs of this tile
+      for (int u = 0; u < TGS_AGG_U; u++) lng[u] = S.off[j[u] + 1] - S.off[j[u]] > TGS_LONG_RUN;
+#pragma unroll
+      for (int u = 0; u < TGS_AGG_U; u++) {
+        lb[u] = -1; lr[u] = 0;
+        if (valid[u]) {
+          if (lng[u]) {                                         // a long run's pair: counted directly (outside the box)
+            lb[u] = -2;
+            lr[u] = atomicAdd(&my_count[ty[u] * TW + tx[u]], 1);
+          } else {
+            lb[u] = (ty[u] - by0) * bw + (tx[u] - bx0);
+            lr[u] = atomicAdd(&S.hist[lb[u]], 1);               // LDS: rank among the group's pairs of this tile
+          }
+        }
       }
     }
     __syncthreads();
@@ -280,15 +336,28 @@ __device__ __forceinline__ void group_count_tiles(GroupScan& S, int TW, int T, i
 #pragma unroll
     for (int u = 0; u < TGS_AGG_U; u++) {
       const int i = tid + u * TGS_GROUP;
-      if (lb[u] >= 0 && fits) rank[base + i] = (int32_t)((unsigned)(S.hist[lb[u]] + lr[u]) | ((unsigned)x << 29));
+      if (lb[u] != -1 && fits) rank[base + i] = (int32_t)((unsigned)((lb[u] >= 0 ? S.hist[lb[u]] : 0) + lr[u]) | ((unsigned)x << 29));
     }
     first_direct = TGS_AGG_U * TGS_GROUP;                     // pairs beyond 1024 per group (huge footprints)
   }
-  for (int i = tid + first_direct; i < total; i += TGS_GROUP) {
-    int j, tile;
-    group_pair(S, TW, i, j, tile);
-    const int r = atomicAdd(&my_count[tile], 1);
-    if (fits) rank[base + i] = (int32_t)((unsigned)r | ((unsigned)x << 29));   // rank inside sub-list x of the tile (capacity < 2^29 pairs per sub-list)
+  // Direct path, TGS_DIRECT_U pairs per thread and round with their returning atomics in flight together (round 6): a
+  // group of table / background Gaussians that cover a thousand tiles each holds 20 - 30 k pairs (mean of an
+  // object-centric 720p frame: 2.6 k), and one returning atomic per round made its ~110 dependent round trips the
+  // duration of the whole launch (K1 + count 104 us for 79 k Gaussians, profiles/r6_before_*).
+  for (int i0 = tid + first_direct; i0 < total; i0 += TGS_DIRECT_U * TGS_GROUP) {
+    int tile[TGS_DIRECT_U], r[TGS_DIRECT_U];
+    {
+      int j[TGS_DIRECT_U], tx[TGS_DIRECT_U], ty[TGS_DIRECT_U];
+      bool valid[TGS_DIRECT_U];
+      group_pairs_xy<TGS_DIRECT_U>(S, i0, TGS_GROUP, total, j, tx, ty, valid);
+#pragma unroll
+      for (int u = 0; u < TGS_DIRECT_U; u++) tile[u] = valid[u] ? ty[u] * TW + tx[u] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < TGS_DIRECT_U; u++) r[u] = tile[u] >= 0 ? atomicAdd(&my_count[tile[u]], 1) : 0;
+#pragma unroll
+    for (int u = 0; u < TGS_DIRECT_U; u++)   // rank inside sub-list x of the tile (capacity < 2^29 pairs per sub-list)
+      if (tile[u] >= 0 && fits) rank[base + i0 + u * TGS_GROUP] = (int32_t)((unsigned)r[u] | ((unsigned)x << 29));
   }
 }
 #endif  // __HIPCC__

@@ -70,6 +70,9 @@ class ModelConfig:
     spatial_sort: bool = False
     # full Morton re-sort every this many refinements (in between, refine() keeps children next to parents)
     resort_every_refines: int = 10
+    # spatial_sort deals the Gaussians that covered more than 32 tiles in the last frame evenly over the binning groups
+    # (optim.balanced_order): a layout choice like the Morton order itself, results unchanged
+    balance_long_runs: bool = True
 
     def downscale_factor(self, step: int) -> int:
         """2 ** max(num_downscales - step // resolution_schedule, 0)  (Splatfacto._get_downscale_factor)."""
@@ -317,14 +320,28 @@ class DepthGaussianSplattingModel:
 
     def spatial_sort(self) -> torch.Tensor:
         """Put the Gaussians (parameters, gradients, Adam moments, densification statistics) in 3-D
-        Morton order.  Purely a memory-layout choice -- the scene and every result are the same up to
+        Morton order (long-run Gaussians dealt over the groups once a frame has been rendered: ``balance_long_runs``).  Purely a memory-layout choice -- the scene and every result are the same up to
         the permutation -- that makes a binning group of 256 consecutive Gaussians project onto a few
         dozen tiles: K1 then counts per (group, tile) in LDS and issues one global atomic per touched
         tile instead of one per pair, and `k_fill_bins` writes runs instead of single 8-byte pairs.
         Call at start-up and after densification (the trainer and bench.py do).  Returns the
         permutation (new row i = old row perm[i])."""
-        from .optim import morton_order
-        perm = morton_order(self.params.means)
+        from .optim import balanced_order
+        # the last frame's tile count per Gaussian (the packed rect of its record): Gaussians with LONG runs of tiles are
+        # dealt evenly over the binning groups instead of sitting next to their spatial neighbours (optim.balanced_order)
+        hits = None
+        cams = list(getattr(self, "_recent_cams", {}).values()) if self.config.balance_long_runs else []
+        if cams:
+            # tiles per Gaussian summed over the cameras of the last steps (K1 alone, once per camera: the sort runs every
+            # few hundred steps): a Gaussian that is long in one view of a few-view orbit is short in another, and a
+            # layout balanced for ONE view left groups of 22 000 pairs in the next (profiles/r6_b_ckpt_loop_bunny.json)
+            p, hits = self.params, 0
+            for cam in cams:
+                sp = ops.project_fwd(cam, p.means, p.log_scales, p.quats, p.opac_logit, None, -1)
+                rect = sp[:, 10].contiguous().view(torch.int32)
+                hits = hits + ((rect >> 16) & 255) * ((rect >> 24) & 255)
+            hits = (hits + len(cams) - 1) // len(cams)        # mean tiles per view (rounded up)
+        perm = balanced_order(self.params.means, hits)
         self.params.permute_(perm, self.optimizer.exp_avg, self.optimizer.exp_avg_sq)
         density = getattr(self, "density", None)
         if density is not None:
@@ -478,6 +495,13 @@ class DepthGaussianSplattingModel:
         between the two calls except through this class."""
         distributed = dp is not None and dp.active
         opt = self.optimizer
+        if self.config.balance_long_runs and self.config.spatial_sort:
+            # the cameras of the last steps (full resolution), for the next spatial_sort (host-side bookkeeping only)
+            rc = self.__dict__.setdefault("_recent_cams", collections.OrderedDict())
+            rc[id(view.cam)] = view.cam
+            rc.move_to_end(id(view.cam))
+            if len(rc) > 16:
+                rc.popitem(last=False)
         opt.lrs["means"] = self.config.lr_means_at(self.step)   # scheduled position learning rate
         full_view = view    # what the speculative budget replays (the schedule is applied again on the replay)
         if self.config.num_downscales > 0:   # coarse-to-fine: this step (and the announced next one) at their resolutions
