@@ -88,6 +88,12 @@ typedef struct TgsAdamSpec {
 int tgs_version(void);
 const char* tgs_last_error(void);
 
+/* Box calibration (bench.py): enqueues a plain v_fma_f32 stream (16 independent accumulators per lane, 4 waves per SIMD
+ * on every CU) of n_iter iterations; *n_wave_instr (host, may be NULL) = wave instructions issued.  Time it with events on
+ * `stream`: wave instructions / second = what the vector pipes sustain on this box under its power governor.  `sink`:
+ * one device float (never written in practice). */
+int tgs_calib_fma_stream(int n_iter, float* sink, int64_t* n_wave_instr /*[host]*/, void* stream);
+
 /* Number of binning groups / tiles for sizing the caller's buffers. */
 int tgs_num_groups(int N);                 /* ceil(N/TGS_GROUP) */
 int tgs_num_tiles(int W, int H);           /* ceil(W/16)*ceil(H/16) */

@@ -354,6 +354,40 @@ def test_densify_screen_size_rules_cpu():
     assert not info["opacity_reset"] and info["culled"] == 2 and info["cloned"] == info["split"] == 0
 
 
+def test_unseen_cull_needs_a_complete_window_cpu():
+    """DensifyConfig.cull_unseen (off by default: not in Splatfacto) removes Gaussians no training view has had in its
+    frustum -- but only at refinements that cull at all (not in the pause after an opacity reset) and only when the
+    window is KNOWN to have shown every training view: ``num_train_data`` different view identities passed to
+    ``accumulate``, or, for callers that pass none (nerfstudio's datamanager shuffles per epoch), a window of at least
+    2 n - 1 steps (``refine_every >= n`` only covers every view for a round-robin order)."""
+    import dataclasses as _dc
+    from touch_gs_amd.densify import DensifyConfig, DensityController
+    from touch_gs_amd.optim import FusedAdam, GaussianParams
+    N, n_views = 6, 4
+    def population():
+        gp = GaussianParams.allocate(N, 1, "cpu")
+        gp.quats[:, 0] = 1.0
+        gp.log_scales[:] = math.log(0.001)
+        gp.opac_logit[:] = 2.0
+        return gp, FusedAdam(gp, dict(means=1e-4, log_scales=1e-3, quats=1e-3, opac_logit=1e-2, sh_dc=1e-3, sh_rest=1e-4))
+    radii = torch.tensor([3, 3, 3, 3, 0, 0], dtype=torch.int32)       # rows 4, 5 are outside every frustum
+    def run(cfg, keys, step=20):
+        gp, opt = population()
+        dc = DensityController(cfg, N, "cpu")
+        for k in keys:
+            dc.accumulate(torch.zeros(N, 2), radii, 64, 64, view_key=k)
+        return dc.refine(gp, opt, step)[2]["culled"]
+    base = DensifyConfig(warmup_length=0, refine_every=10, reset_alpha_every=0, num_train_data=n_views)
+    assert DensifyConfig().cull_unseen is False and run(base, [0, 1, 2, 3]) == 0       # the default never does it
+    on = _dc.replace(base, cull_unseen=True)
+    assert run(on, [0, 1, 2, 3]) == 2                                                   # every view seen: 4, 5 go
+    assert run(on, [0, 1, 2, 2, 1, 0, 1, 2, 0, 1]) == 0                                 # ten steps, view 3 never shown
+    assert run(on, [None] * 10) == 2                                                    # anonymous, 10 >= 2 * 4 - 1
+    assert run(_dc.replace(on, refine_every=6), [None] * 6, step=18) == 0               # anonymous, 6 < 7: could have missed one
+    paused = _dc.replace(on, reset_alpha_every=3)                                       # reset interval 30: steps 30 .. 44 pause
+    assert run(paused, [0, 1, 2, 3], step=40) == 0 and run(paused, [0, 1, 2, 3], step=50) == 2
+
+
 def test_refine_places_children_behind_their_parents_cpu():
     """DensityController.refine builds the refined store with one gather: survivors keep their relative
     order (values and Adam moments bit for bit), a clone sits directly behind its source, the
@@ -419,6 +453,37 @@ def test_refine_places_children_behind_their_parents_cpu():
     assert not dc.vis_count.any() and not dc.grad_norm_sum.any() and not dc.max_radius.any()
     dc.accumulate(torch.ones(new_p.N, 2), torch.ones(new_p.N, dtype=torch.int32), 64, 64, guard=torch.tensor([5, 0], dtype=torch.int32))
     assert dc.vis_count.sum() == new_p.N
+
+
+def test_balanced_order_deals_long_runs_over_the_groups_cpu():
+    """optim.balanced_order: a permutation; rows whose `hits` exceed 32 sit at the END of the 256-row groups, dealt by size
+    rank round robin (every group gets the same number +- 1 and a similar sum); the other rows keep their Morton order
+    among themselves; without hits (or without long runs) it IS the Morton order."""
+    from touch_gs_amd.optim import balanced_order, morton_order
+    g = torch.Generator().manual_seed(5)
+    N = 256 * 37 + 91
+    means = torch.randn(N, 3, generator=g)
+    hits = (torch.rand(N, generator=g) ** 10 * 3600).long()              # ~7 % above 32, a heavy tail
+    assert torch.equal(balanced_order(means, None), morton_order(means))
+    assert torch.equal(balanced_order(means, torch.zeros(N, dtype=torch.long)), morton_order(means))
+    perm = balanced_order(means, hits)
+    assert torch.equal(torch.sort(perm).values, torch.arange(N))
+    h = hits[perm]
+    big = h > 32
+    G = N // 256
+    per_group = big[:G * 256].view(G, 256)
+    cnt = per_group.sum(1)
+    assert int(cnt.max()) - int(cnt.min()) <= 1 and not big[G * 256:].any()        # dealt evenly; the partial group takes none
+    for gi in range(G):                                                           # ... at the end of every group
+        assert per_group[gi, 256 - int(cnt[gi]):].all() and not per_group[gi, :256 - int(cnt[gi])].any()
+    sums = torch.where(big, h, torch.zeros_like(h))[:G * 256].view(G, 256).sum(1).float()
+    plain = hits[morton_order(means)]
+    plain_sums = torch.where(plain > 32, plain, torch.zeros_like(plain))[:G * 256].view(G, 256).sum(1).float()
+    assert sums.max() / sums.mean() < 1.25 < plain_sums.max() / plain_sums.mean()   # measured 1.08 against 2.3
+    inv = torch.empty(N, dtype=torch.long)
+    inv[morton_order(means)] = torch.arange(N)
+    small_rows = perm[~big]
+    assert (inv[small_rows][1:] > inv[small_rows][:-1]).all()                      # Morton order among the short-run rows
 
 
 def test_morton_order_and_permute_cpu():

@@ -1371,6 +1371,8 @@ def test_nerfstudio_plugin_trains_with_touch_supervision_from_disk(dev, tmp_path
         dmc = spec.config.pipeline.datamanager
         dmc.dataparser.data = str(root)
         dmc.dataparser.train_split_fraction = 0.8
+        assert dmc.dataparser.uncertainty_floor == 0.0     # reference parity by default; the few-view preset's value:
+        dmc.dataparser.uncertainty_floor = 0.05
         dm = dmc.setup()
         assert type(dm.train_dataset).__name__ == "TactileDepthDataset" and len(dm.train_dataset) == 5
         outs = dm.train_dataparser_outputs
@@ -1380,7 +1382,7 @@ def test_nerfstudio_plugin_trains_with_touch_supervision_from_disk(dev, tmp_path
         v0 = make_view(N, W, H, deg, 11, dev, view=0, n_views=6)
         sc = outs.dataparser_scale
         assert torch.allclose(batch0["depth_image"][..., 0], v0.depth.cpu() * sc, atol=1e-3 * sc + 1e-6)   # mm quantisation
-        # (the dataparser's uncertainty floor -- default 0.05 in the map's own units, DESIGN 10 item 6 -- bounds the touch : vision
+        # (the dataparser's uncertainty floor -- 0.05 in the map's own units under the few-view preset, DESIGN 10 item 6 -- bounds the touch : vision
         # weight ratio of the depth loss; the map the model sees is the floored one)
         floor = dmc.dataparser.uncertainty_floor
         assert floor == 0.05 and (v0.uncertainty < floor).any()

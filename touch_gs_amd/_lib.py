@@ -47,6 +47,7 @@ _I = C.c_int
 SIGNATURES = {
     "tgs_version": (C.c_int, []),
     "tgs_last_error": (C.c_char_p, []),
+    "tgs_calib_fma_stream": (C.c_int, [_I, _P, C.POINTER(C.c_int64), _P]),
     "tgs_num_groups": (C.c_int, [_I]),
     "tgs_num_tiles": (C.c_int, [_I, _I]),
     "tgs_tile_order_len": (C.c_int, [_I, _I]),

@@ -363,7 +363,7 @@ FLAG_SETS = {
 
 def train_and_eval(root: str, flags: str, with_depth: bool, iters: int = 30000, out_dir: Optional[str] = None,
                    num_gaussians: int = 100000, extra_args: Sequence[str] = (), seed: int = 0, device="cuda",
-                   split: Optional[float] = None, percent_take: Optional[float] = None) -> dict:
+                   split: Optional[float] = None, percent_take: Optional[float] = None, preset: str = "few-view") -> dict:
     """``ns-train depth-gaussian-splatting`` + ``run_eval`` of one reference flag set on a prepared capture:
     seeds for the flag set's split (create_point_cloud_from_touches), ``touch_gs_amd.train`` for ``iters`` iterations
     with or without the depth term, ``touch_gs_amd.run_eval`` under IS_REAL_WORLD (scripts/train_bunny_real.sh:54), and
@@ -385,7 +385,7 @@ def train_and_eval(root: str, flags: str, with_depth: bool, iters: int = 30000, 
             "--depth-loss-mult", str(fs["depth_loss_mult"] if with_depth else 0.0), "--depth-loss-type", fs["depth_loss_type"],
             "--uncertainty-weight", str(fs["uncertainty_weight"]), "--num-gaussians", str(num_gaussians),
             "--steps-per-save", str(iters), "--steps-per-eval", str(max(iters // 10, 1)), "--output-dir", out_dir,
-            "--seed", str(seed), *extra_args]
+            "--seed", str(seed), "--preset", preset, *extra_args]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run_dir = train.main(argv)

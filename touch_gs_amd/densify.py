@@ -50,13 +50,17 @@ class DensifyConfig:
     # removes Gaussians the scene needs.  The trainer sets this to its number of training views.
     num_train_data: int = 0
     continue_cull_post_densification: bool = True
-    # Cull Gaussians that NO training view has had in its frustum during a whole refinement window (applied only when
-    # the window covers every training view at least once: refine_every >= num_train_data > 0).  Not in Splatfacto,
+    # Cull Gaussians that NO training view has had in its frustum during a whole refinement window.  Not in Splatfacto,
     # whose seeds are SfM points the cameras see by construction: here the seeds are a touch cloud + a random fill of
     # the scene cube, and in the reference's few-view regime (8 - 13 views) a large part of that fill lies in space
     # no training camera covers -- it can never be supervised or culled by opacity (it keeps its initial 0.1), and
-    # shows up as haze right in front of the held-out cameras.
-    cull_unseen: bool = True
+    # shows up as haze right in front of the held-out cameras.  OFF by default (reference
+    # parity; the trainer's ``--preset few-view`` switches it on).  Applied only at refinements that cull at all (not in
+    # the pause after an opacity reset) and only when the window is KNOWN to have shown every training view: the
+    # callers pass the view's identity to ``accumulate`` and the window must have collected ``num_train_data``
+    # different ones; a caller that passes no identities (random view order, e.g. nerfstudio's datamanager) needs
+    # refine_every >= 2 num_train_data - 1, the length after which a per-epoch shuffle has shown every view.
+    cull_unseen: bool = False
 
 
 def quat_to_rotmat(q: torch.Tensor) -> torch.Tensor:
@@ -76,9 +80,12 @@ class DensityController:
         self.grad_norm_sum = torch.zeros(n, device=device)
         self.vis_count = torch.zeros(n, device=device)
         self.max_radius = torch.zeros(n, device=device)
+        self.views_seen = set()        # identities of the views accumulated since the last refinement (host side)
+        self.anonymous_views = 0       # ... and the number of accumulations that came without one
 
     @torch.no_grad()
-    def accumulate(self, v_xy: torch.Tensor, radii: torch.Tensor, W: int, H: int, guard: Optional[torch.Tensor] = None):
+    def accumulate(self, v_xy: torch.Tensor, radii: torch.Tensor, W: int, H: int, guard: Optional[torch.Tensor] = None,
+                   view_key=None):
         """Per-step statistics: |screen gradient| in NDC-like units (x 0.5 max(W,H), as Splatfacto
         does), visibility count and the largest normalised screen radius.  ``guard``: the frame's
         binning status word (device int32[2]); a frame whose overflow flag is set contributes nothing
@@ -87,6 +94,10 @@ class DensityController:
         vis = radii > 0
         if guard is not None:
             vis = vis & (guard[1] == 0)
+        if view_key is None:
+            self.anonymous_views += 1
+        else:       # (a voided frame is replayed before the next refinement -- refinements are barriers -- and counts then)
+            self.views_seen.add(view_key)
         g = v_xy.norm(dim=-1) * (0.5 * max(W, H))
         self.grad_norm_sum += torch.where(vis, g, torch.zeros_like(g))
         self.vis_count += vis.float()
@@ -137,8 +148,13 @@ class DensityController:
             cull = cull | too_big
         if not do_cull:
             cull &= False
-        if c.cull_unseen and c.num_train_data > 0 and c.refine_every >= c.num_train_data:
-            cull = cull | (self.vis_count == 0)
+        if c.cull_unseen and do_cull and c.num_train_data > 0:
+            if self.anonymous_views == 0:
+                window_complete = len(self.views_seen) >= c.num_train_data
+            else:
+                window_complete = c.refine_every >= 2 * c.num_train_data - 1
+            if window_complete:
+                cull = cull | (self.vis_count == 0)
         keep = ~cull & ~split  # split parents are replaced by their samples
         clone = clone & ~cull
         split = split & ~cull

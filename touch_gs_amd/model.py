@@ -331,6 +331,8 @@ class DepthGaussianSplattingModel:
         # dealt evenly over the binning groups instead of sitting next to their spatial neighbours (optim.balanced_order)
         hits = None
         cams = list(getattr(self, "_recent_cams", {}).values()) if self.config.balance_long_runs else []
+        if os.environ.get("TGS_BALANCE_LONG_RUNS", "1") == "0":     # A/B switch
+            cams = []
         if cams:
             # tiles per Gaussian summed over the cameras of the last steps (K1 alone, once per camera: the sort runs every
             # few hundred steps): a Gaussian that is long in one view of a few-view orbit is short in another, and a
@@ -418,7 +420,12 @@ class DepthGaussianSplattingModel:
                 self._seen_need = max(getattr(self, "_seen_need", 0), int(host[2]), int(host[0]))
                 self._seen_longest = max(self._seen_longest, int(host[3]))
                 self._good_frames += 1
-                if self.list_hint and self._good_frames >= self.LIST_HINT_AFTER:
+                # armed once every training view of the current resolution level can have been seen (with more
+                # than 16 views the bound came from a subset, and a later view beyond 1.5 x + 64 voided its frame)
+                dens = getattr(self, "density", None)
+                need_frames = max(self.LIST_HINT_AFTER, dens.cfg.num_train_data if dens is not None else 0,
+                                  len(getattr(self, "_recent_cams", ())))
+                if self.list_hint and self._good_frames >= need_frames:
                     self.budget.max_list_hint = max(self.budget.max_list_hint, int(1.5 * self._seen_longest) + 64)
                 self._pinned.append(host)
                 if only_one:
@@ -505,7 +512,13 @@ class DepthGaussianSplattingModel:
         opt.lrs["means"] = self.config.lr_means_at(self.step)   # scheduled position learning rate
         full_view = view    # what the speculative budget replays (the schedule is applied again on the replay)
         if self.config.num_downscales > 0:   # coarse-to-fine: this step (and the announced next one) at their resolutions
-            view = view.downscaled(self.config.downscale_factor(self.step))
+            d = self.config.downscale_factor(self.step)
+            if d != getattr(self, "_last_downscale", d) and getattr(self, "_pending", None) is not None:
+                # a new resolution level: the lists get ~4x longer -- learn the list bound again instead of voiding a frame
+                self._seen_longest, self._good_frames = 0, 0
+                self.budget.max_list_hint = -1
+            self._last_downscale = d
+            view = view.downscaled(d)
             if next_view is not None:
                 next_view = next_view.downscaled(self.config.downscale_factor(self.step + 1))
         deg = self.active_sh_degree()
@@ -580,7 +593,8 @@ class DepthGaussianSplattingModel:
         if density is not None and not factored:
             # a frame that overflowed its intersection buffer (sync-free budget) rendered nothing and will be
             # replayed: it must not count as a view (guard = its status word, evaluated on the device)
-            density.accumulate(self.last["v_xy"], self.last["radii"], view.cam.W, view.cam.H, guard=self.last["guard"])
+            density.accumulate(self.last["v_xy"], self.last["radii"], view.cam.W, view.cam.H, guard=self.last["guard"],
+                               view_key=id(full_view))
         if factored:
             dguard = None
             if self.budget.speculative:   # agree the overflow verdict across ranks before anything touches the model
@@ -610,6 +624,8 @@ class DepthGaussianSplattingModel:
                 # guarded by the AGREED verdict (written by chunk 0's dp_agree_overflow, enqueued above), not by this
                 # rank's own status word: if another rank's frame overflowed, the step is voided on every rank and
                 # replayed, and this rank's (valid) frame must not be counted twice
+                # (data parallel: every rank sees its own views; the statistics are summed over the ranks at the
+                # refinement, the identities are not -- the window counts as complete by its length, as for anonymous views)
                 density.accumulate(self.last["v_xy"], self.last["radii"], view.cam.W, view.cam.H,
                                    guard=dguard if dguard is not None else self.last["guard"])
         elif distributed:

@@ -344,7 +344,9 @@ if available:  # pragma: no cover
         ``uncertainty_file_path`` in the same (split-filtered) order."""
         _target: Type = field(default_factory=lambda: TactileDataParser)
         uncertainty_scaling: str = "linear"
-        uncertainty_floor: float = 0.05    # dataset.py: bounds the touch : vision weight ratio of the depth loss at 100
+        # dataset.py: a floor of 0.05 bounds the touch : vision weight ratio of the depth loss at 100 (the few-view preset of
+        # touch_gs_amd.train, DESIGN.md section 10); 0 = off = the reference's loss for the reference's flags (default)
+        uncertainty_floor: float = 0.0
 
     class TactileDataParser(Nerfstudio):
         config: TactileDataParserConfig
@@ -433,6 +435,9 @@ if available:  # pragma: no cover
         cull_scale_thresh: float = 0.5
         reset_alpha_every: int = 30
         stop_split_at: int = 15000
+        # densify.py: cull Gaussians unseen for a whole refinement window.  nerfstudio's datamanager draws the views at
+        # random per epoch, so the window only counts as complete from refine_every >= 2 num_train_data - 1
+        cull_unseen: bool = False
 
     class DepthGSNerfstudioModel(Model):
         """Thin shell: nerfstudio Model API -> AutogradGaussians / ParamGroupRefiner (above).  Parameters
@@ -464,7 +469,8 @@ if available:  # pragma: no cover
                     warmup_length=c.warmup_length, refine_every=c.refine_every, densify_grad_thresh=c.densify_grad_thresh,
                     densify_size_thresh=c.densify_size_thresh, cull_alpha_thresh=c.cull_alpha_thresh,
                     cull_scale_thresh=c.cull_scale_thresh, reset_alpha_every=c.reset_alpha_every,
-                    stop_split_at=c.stop_split_at, num_train_data=int(getattr(self, "num_train_data", 0) or 0)))
+                    stop_split_at=c.stop_split_at, num_train_data=int(getattr(self, "num_train_data", 0) or 0),
+                    cull_unseen=c.cull_unseen))
                 self.refiner.on_replace = lambda name, p: self.gauss_params.__setitem__(name, p)
 
         def get_param_groups(self):

@@ -116,8 +116,12 @@ class IntersectBudget:
         if self.sticky is not None and int(self.sticky.item()) != 0:
             ovf = 1
         if ovf:
-            raise RuntimeError(f"intersection capacity {self.capacity} too small: a frame needed more "
-                               f"(last frame: {n}); every frame since the overflow was dropped")
+            # the sticky word remembers ANY earlier frame: with a list hint in force the cause may have been a list longer
+            # than the hint in a frame whose status words are gone, not the capacity
+            why = (f"intersection capacity {self.capacity} too small" if self.max_list_hint < 0 else
+                   f"intersection capacity {self.capacity} too small, or a tile list broke max_list_hint = {self.max_list_hint} in an earlier frame")
+            raise RuntimeError(f"{why}: a frame needed more (last frame: {n} intersections, longest list "
+                               f"{getattr(self, 'last_longest', '?')}); every frame since was dropped")
         return n
 
 

@@ -61,11 +61,13 @@ def init_params(n: int, K: int, device, seed_points=None, extent: float = 1.0, s
     N = means.shape[0]
     # mean distance to the 3 nearest neighbours, exact, in blocks (the cloud mixes a dense object with a sparse fill:
     # a subsampled estimate would give the object's points the fill's spacing)
-    knn = torch.empty(N)
     md = means.to(device)
-    for b in range(0, N, 4096):
-        d = torch.cdist(md[b:b + 4096], md)
-        knn[b:b + 4096] = d.topk(4, largest=False).values[:, 1:].mean(1).clamp_min(1e-5).cpu()
+    blk = max(64, min(4096, (1 << 28) // max(N, 1)))   # <= 1 GiB of distances per block whatever N is
+    kd = torch.empty(N, device=md.device)
+    for b in range(0, N, blk):
+        d = torch.cdist(md[b:b + blk], md)
+        kd[b:b + blk] = d.topk(4, largest=False).values[:, 1:].mean(1).clamp_min(1e-5)
+    knn = kd.cpu()
     scale = knn
     sh = torch.zeros(N, K, 3)
     sh[:, 0] = (colors - 0.5) / SH_C0
@@ -113,9 +115,17 @@ def main(argv=None):
     ap.add_argument("--train-split-fraction", type=float, default=0.9)
     ap.add_argument("--uncertainty-scaling", type=str, default="linear", choices=("linear", "variance", "none"),
                     help="units of the uncertainty map in the scaled scene (dataset.py docstring; UNVERIFIED-PRIOR)")
-    ap.add_argument("--uncertainty-floor", type=float, default=0.05,
+    ap.add_argument("--uncertainty-floor", type=float, default=None,
                     help="lower bound of the uncertainty map, in the map's own units (dataset.py docstring: without it "
-                         "the touched pixels pile the refinement onto the object); 0 = off")
+                         "the touched pixels pile the refinement onto the object); default 0 = off = the reference's loss "
+                         "for the reference's flags (0.05 under --preset few-view)")
+    ap.add_argument("--cull-unseen", dest="cull_unseen", action="store_true", default=None,
+                    help="cull Gaussians no training view has had in its frustum for a whole refinement window "
+                         "(densify.py; not in Splatfacto; on under --preset few-view)")
+    ap.add_argument("--preset", type=str, default="reference", choices=("reference", "few-view"),
+                    help="reference: the reference's flags mean what they mean there (uncertainty floor 0, no unseen cull). "
+                         "few-view: the two additions that make touch-cloud seeds + a random fill train in the 8-13 view "
+                         "regime (DESIGN.md section 10: --uncertainty-floor 0.05, --cull-unseen); explicit flags win")
     ap.add_argument("--max-num-iterations", type=int, default=30000)
     ap.add_argument("--steps-per-save", type=int, default=2000)
     ap.add_argument("--steps-per-eval", type=int, default=500)
@@ -147,6 +157,11 @@ def main(argv=None):
     ap.add_argument("--densify-grad-thresh", type=float, default=0.0002)
     args = ap.parse_args(argv)
 
+    few = args.preset == "few-view"
+    if args.uncertainty_floor is None:
+        args.uncertainty_floor = 0.05 if few else 0.0
+    if args.cull_unseen is None:
+        args.cull_unseen = few
     dp = parallel.init_from_env()
     dev = torch.device("cuda", dp.local_rank)
     torch.cuda.set_device(dev)
@@ -177,9 +192,14 @@ def main(argv=None):
     if args.densify:
         from .densify import DensifyConfig
         model.enable_densification(DensifyConfig(refine_every=args.refine_every, warmup_length=args.warmup_length,
-                                                 num_train_data=len(i_train), densify_grad_thresh=args.densify_grad_thresh))
+                                                 num_train_data=len(i_train), densify_grad_thresh=args.densify_grad_thresh,
+                                                 cull_unseen=bool(args.cull_unseen)))
     trainer_state = dict(uncertainty_scaling=args.uncertainty_scaling, uncertainty_floor=args.uncertainty_floor, densify=bool(args.densify),
-                         num_downscales=args.num_downscales)
+                         num_downscales=args.num_downscales, cull_unseen=bool(args.cull_unseen))
+    if dp.rank == 0 and (args.uncertainty_floor > 0 or args.cull_unseen):
+        print(f"note: this run deviates from the reference's objective / Splatfacto's refinement: uncertainty floor "
+              f"{args.uncertainty_floor} (no depth weight above 1 / (uncertainty_weight * floor)), cull_unseen={bool(args.cull_unseen)} "
+              f"(--preset {args.preset}; DESIGN.md section 10)", flush=True)
     if args.load_checkpoint:
         sd = torch.load(args.load_checkpoint, map_location=dev)
         model.load_state_dict(sd)
