@@ -217,6 +217,7 @@ typedef struct TgsRasterOpts {
   int32_t k7_front_to_back;  /* 1: backward in the front-to-back form of TGS_VERSION 100                 [TGS_K7_F2B, 0]    */
   int32_t k7_quad;           /* chain-bound factor of the backward, 0 = one wave per tile (tgs_set_k7_quad) [TGS_K7_QUAD, 8] */
   int32_t k7_quad_min_walk;  /* walks up to this many entries stay with the one-wave kernel              [TGS_K7_QUAD_MIN, 48] */
+  int32_t k7_blocks;         /* 1: backward in 4x4-block form (TGS_VERSION 310; measured, not the default) [TGS_K7_BLOCKS, 0] */
 } TgsRasterOpts;
 
 /* K6  per-tile front-to-back compositing of RGB + depth in ONE pass  (stands behind gsplat

@@ -85,7 +85,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.TgsCamera) == 16 * 4 + 4 * 4 + 2 * 4 + 2 * 4 + 3 * 4 + 4
     assert C.sizeof(_lib.TgsAdamSpec) == 11 * 4 + 4 + 8   # 11 floats, pad, device pointer
     assert C.sizeof(_lib.TgsLossSpec) == 3 * 8 + 4 * 4
-    assert C.sizeof(_lib.TgsRasterOpts) == 5 * 4
+    assert C.sizeof(_lib.TgsRasterOpts) == 6 * 4
     # field order of the header (a per-call option read from the wrong slot would silently select another kernel form)
     txt = open(os.path.join(ROOT, "include", "tgs.h")).read()
     body = re.search(r"typedef struct TgsRasterOpts \{(.*?)\} TgsRasterOpts;", txt, flags=re.S).group(1)

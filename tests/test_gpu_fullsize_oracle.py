@@ -35,6 +35,20 @@ TOL = 1e-4
 # fraction of the pixels with every threshold decision further than 1e-3 (relative) from its threshold and an
 # fp32 depth order equal to the fp64 one -- where RGB / depth / T are asserted at 1e-4 (r4 measurements)
 CLEAR_MEASURED = {"cfg2_100k_800x800": 0.987, "cfg3_1M_1080p": 0.960, "cfg5_5M_4K": 0.91}
+# share of the REACHING Gaussians that are decision-clear -- the population the gradient bar (max <= 1e-4) is asserted on
+# -- as measured (profiles/r4_gradient_parity_fullsize.txt, r6_gradient_parity_fullsize.txt); asserted within +- 0.02 so
+# that a drift of the classification fails instead of silently shrinking the asserted population (VERDICT r5 next #4b).
+# "train": the fused train step's classification (pixels whose L1 sign is within the forward's tolerance count as ambiguous)
+CLEAR_GAUSSIANS_MEASURED = {"cfg2_100k_800x800": 0.7755, "cfg3_1M_1080p": 0.5170, "cfg5_5M_4K": 0.61}
+CLEAR_GAUSSIANS_MEASURED_TRAIN = {"cfg2_100k_800x800": 0.5425, "cfg3_1M_1080p": 0.3802, "cfg5_5M_4K": None}
+REPORT_FILE = "gpurun_out/r6_gradient_parity_fullsize.txt"     # the grad_report lines, for the next reader (VERDICT r5 next #4d)
+
+
+def _write_report(lines):
+    import os
+    os.makedirs(os.path.dirname(REPORT_FILE), exist_ok=True)
+    with open(REPORT_FILE, "a") as f:
+        f.write("\n".join(lines) + "\n")
 
 
 # Not BASELINE configs: scenes that put one code path under the same oracle machinery (their own tests below).
@@ -318,7 +332,8 @@ def test_gradients_match_oracle_fullsize(both):
     report = [f"{b['name']}: decision-clear pixels {np.mean(pm > GMARGIN):.5f} (forward test, margin 1e-3: "
               f"{np.mean((b['margin'] > 1e-3) & b['order_ok']):.4f}); Gaussians reaching a pixel {reach.mean():.4f}, "
               f"of which clear {clear.sum() / max(reach.sum(), 1):.4f}"]
-    assert clear.sum() > 0.3 * reach.sum(), report
+    frac = clear.sum() / max(reach.sum(), 1)
+    assert abs(frac - CLEAR_GAUSSIANS_MEASURED[b["name"]]) < 0.02, report
     N = b["N"]
     ref7 = {k: np.asarray(b["bb"][k], np.float64).reshape(N, -1) for k in K7_KEYS}
     assert_gradients(b["name"], k7_outputs(b["v_splats"]), ref7, b["m7"], reach, clear, K7_KEYS, report)
@@ -326,6 +341,7 @@ def test_gradients_match_oracle_fullsize(both):
     got = dict(zip(PARAM_KEYS, b["grads"]))
     assert_gradients(b["name"], got, b["pb"], pmass, reach, clear, PARAM_KEYS, report)
     print("\n".join(report))
+    _write_report(report)
     b["cache"]["grad_report"] = report
     # whole-tensor agreement (dominated by the unclear Gaussians)
     for key in PARAM_KEYS:
@@ -397,14 +413,14 @@ def test_train_step_matches_oracle_fullsize(both, dev):
     from touch_gs_amd.scene import make_view
     from tests.util import PARAM_KEYS, param_mass
     b = both
-    if b["W"] > 2048:
-        pytest.skip("train-step parity runs at configs[1] and configs[2]")
     N, W, H, deg = b["N"], b["W"], b["H"], b["deg"]
+    # the per-GPU part of configs[4] (5 M, 4K) runs ONE flag set (round 6; rounds 3-5 skipped it: the budget is there)
+    flag_sets = FLAG_SETS if W <= 2048 else {"block": FLAG_SETS["block"]}
     mv = make_view(N, W, H, deg, b["seed"], dev, view=b["view"], n_views=8)
     view = View(cam=b["cam"], rgb=mv.rgb, depth=mv.depth, uncertainty=mv.uncertainty)
     gt64, dgt64, unc64 = (t.cpu().double() for t in (mv.rgb, mv.depth, mv.uncertainty))
     R, cb, pc, bf, Pn = b["R"], b["cb"], b["pc"], b["bf"], b["Pn"]
-    for tag, (ltype, mult, uw) in FLAG_SETS.items():
+    for tag, (ltype, mult, uw) in flag_sets.items():
         # ---- HIP: the fused step's forward + backward ----
         D = b["D"]
         params = GaussianParams.from_tensors(*[D[k].clone() for k in GaussianParams.NAMES])
@@ -445,6 +461,9 @@ def test_train_step_matches_oracle_fullsize(both, dev):
         pmass = param_mass(R, Pn, deg, cb, W, H, pc["radius"], m7)
         report = [f"{b['name']} / {tag}: decision-clear pixels {np.mean(pm > GMARGIN):.5f}, clear Gaussians "
                   f"{clear.sum() / max(reach.sum(), 1):.4f} of the reaching ones"]
+        want = CLEAR_GAUSSIANS_MEASURED_TRAIN[b["name"]]
+        frac = clear.sum() / max(reach.sum(), 1)
+        assert want is None or abs(frac - want) < 0.02, report
         gotk = {"v_" + k: got[k] for k in GaussianParams.NAMES}
         # Here the upstream gradient images are themselves computed twice -- fp32 kernels on the HIP image, fp64
         # torch on the oracle's image -- and the loss curvature (SSIM: 1 / (sigma^2 + C2), C2 = 9e-4) amplifies the
@@ -452,6 +471,7 @@ def test_train_step_matches_oracle_fullsize(both, dev):
         # bar proper (max <= 1e-4 with the upstream gradients given) is test_gradients_match_oracle_fullsize.
         assert_gradients(f"{b['name']}/{tag}", gotk, pb, pmass, reach, clear, PARAM_KEYS, report, tol_max=1e-3, tol_q=GTOL)
         print("\n".join(report))
+        _write_report(report)
         for name, key in (("means", "v_means"), ("log_scales", "v_log_scales"), ("quats", "v_quats"),
                           ("opac_logit", "v_opac_logit"), ("sh", "v_sh")):
             ref = pb[key].reshape(got[name].shape)

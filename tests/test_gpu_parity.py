@@ -267,6 +267,117 @@ def test_k7_quad_form_on_an_object_centric_scene(dev, rule):
         assert float(rel.max()) < 3e-4 and q99 < 1e-5, (float(rel.max()), q99)
 
 
+@pytest.mark.parametrize("N,W,H,deg,seed,clamp", [(20000, 320, 208, 1, 51, False), (3000, 100, 70, 0, 52, True), (30000, 256, 256, 3, 53, False)])
+def test_k7_block_form_matches_the_one_wave_form_and_the_oracle(dev, N, W, H, deg, seed, clamp):
+    """k_raster_bwd_blocks (TgsRasterOpts.k7_blocks = 1; round 6, measured and NOT the default -- DESIGN 5.1e): the
+    backward with a different Gaussian in every 16-lane DPP row.  Same decisions as the forward, sums formed in another
+    order: every (tile, Gaussian) record within rounding of the one-wave form's record (its own magnitude as the scale),
+    NaN-poisoned buffers show that exactly the listed pairs are written, tile losses bit for bit, and the ten
+    screen-space gradients hold the statistical bar of test_rasterize_bwd against the fp64 oracle."""
+    from touch_gs_amd import ops
+    P, cam, acam, D, sp, gb, ts, sg, n = _blend_inputs(dev, N, W, H, deg, seed, clamp=clamp)
+    rgb, depth, fT, _ = ops.rasterize_fwd(acam, sp, sg, ts)
+    g = torch.Generator().manual_seed(seed)
+    v_rgb = torch.randn(H, W, 3, generator=g, dtype=torch.float64)
+    v_d = torch.randn(H, W, generator=g, dtype=torch.float64)
+    v_a = torch.randn(H, W, generator=g, dtype=torch.float64)
+    gt = torch.rand(H, W, 3, generator=g).to(dev)
+    loss = dict(gt_rgb=gt, l1_weight=0.8 / (3 * H * W))
+    out = {}
+    for name, opts in (("one", ops.raster_opts(k7_quad=0, k7_blocks=0)), ("blocks", ops.raster_opts(k7_blocks=1))):
+        buf = torch.full((sg.shape[0], 12), float("nan"), device=dev)
+        partials, tl = ops.rasterize_bwd(acam, sp, gb, sg, ts, rgb, depth, fT, v_rgb.float().to(dev), v_d.float().to(dev),
+                                         v_a.float().to(dev), loss=loss, want_tile_loss=True, partials=buf, opts=opts)
+        out[name] = (partials[:, :10].clone(), tl.clone(),
+                     ops.reduce_partials(acam, sp, gb, torch.nan_to_num(partials)).cpu().double())
+    (a, ta, _), (b, tb, v) = out["one"], out["blocks"]
+    wa, wb = ~torch.isnan(a).any(dim=1), ~torch.isnan(b).any(dim=1)
+    assert torch.equal(wa, wb) and int(wa.sum()) == n and torch.equal(ta, tb)
+    a, b = a[wa], b[wa]
+    mag = a.abs().amax(dim=1, keepdim=True).clamp(min=1e-30)
+    rel = ((a - b).abs() / mag).amax(dim=1)
+    print(f"k7 block form vs one wave: max {float(rel.max()):.2e}, q99 {float(torch.quantile(rel[:: max(1, rel.numel() // 1_000_000)], 0.99)):.2e}")
+    assert float(rel.max()) < 1e-3 and float(torch.quantile(rel[:: max(1, rel.numel() // 1_000_000)], 0.99)) < 2e-5, float(rel.max())
+    f = splat_fields(sp)
+    leaves = {k: f[k].clone().requires_grad_(True) for k in ("xy", "conic", "opac", "rgb", "depth")}
+    o = O.blend(leaves["xy"], leaves["conic"], leaves["opac"], leaves["rgb"], leaves["depth"],
+                sg[:n].cpu().numpy().astype(np.int64), ts.cpu().numpy().astype(np.int64), cam, want_margin=True)
+    l1 = (0.8 / (3 * H * W)) * (o["rgb"] - gt.cpu().double()).abs().sum()
+    ((o["rgb"] * v_rgb).sum() + (o["depth_acc"] * v_d).sum() + (o["alpha"] * v_a).sum() + l1).backward()
+    frac_clear = (o["margin"] > 1e-3).double().mean().item()
+    ref = dict(xy=leaves["xy"].grad, depth=leaves["depth"].grad, opac=leaves["opac"].grad, conic=leaves["conic"].grad, rgb=leaves["rgb"].grad)
+    got = dict(xy=v[:, 0:2], depth=v[:, 2], opac=v[:, 3], conic=v[:, 4:7], rgb=v[:, 7:10])
+    for k in ref:
+        scale = ref[k].abs().max().item()
+        bad = ((got[k] - ref[k]).abs() > 1e-3 * scale + 1e-4 * ref[k].abs()).double().mean().item()
+        assert bad < 0.02 + 5 * (1 - frac_clear), (k, bad, frac_clear)
+        assert np.median(relerr(got[k].numpy(), ref[k].numpy(), floor=1e-3 * scale)) < 3e-5, k
+
+
+def test_k7_quad_form_without_a_schedule_with_an_empty_first_tile_and_dirty_slot_counters(dev):
+    """ADVICE r4 (medium) regression: the four-wave launch draws its tiles from 8 slot counters behind the tile starts.
+    They are zeroed by block 0 of the one-wave launch that precedes it -- BEFORE that block's early returns: with no
+    tile_order (spatial schedule) block 0 owns tile 0, which is EMPTY in most object-centric frames, and a return above
+    the store left whatever the allocator had put there (the four-wave workgroups then drew slots beyond the schedule:
+    no tile of theirs was ever composited).  Here: tile 0 is empty by construction, no tile_order, the eight counter
+    words hold 0x7fffffff before every backward, every tile walking more than 8 entries is the four-wave launch's.
+    Against the one-wave form: every listed pair's record written exactly once (NaN-poisoned buffers), equal up to the
+    rounding of the four-term quadrant sum; and the ten screen-space gradients against the fp64 oracle."""
+    from touch_gs_amd import ops
+    from touch_gs_amd.scene import make_camera, synthetic_gaussians
+    N, W, H, deg = 30_000, 480, 320, 1
+    P, intr = synthetic_gaussians(N, W, H, deg, 9, clustered=True)
+    D = {k: v.to(dev).float().contiguous() for k, v in P.items()}
+    cam = make_camera(intr, 1, 8, bg=(0.1, 0.2, 0.3))
+    T = cam.num_tiles
+    for _ in range(2):       # make tile 0 empty: whoever reaches it becomes invisible (opacity <= 1/255 emits no pairs)
+        sp, radii, gb, ts, sg, st = ops.project_bin_sort(cam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], deg)
+        first = sg[int(ts[0]):int(ts[1])].long()
+        D["opac_logit"][first] = -20.0
+    assert int(ts[1]) - int(ts[0]) == 0 and int(ts[T]) > 50_000
+    rgb, depth, fT, _ = ops.rasterize_fwd(cam, sp, sg, ts)
+    # the same buffer (starts + the rasterizer's scratch words) WITHOUT the schedule that rides on the tensor object
+    ts_plain = ts[:]
+    assert getattr(ts_plain, "tile_order", None) is None and ops._tile_start_len(ts_plain) == ops._tile_start_len(ts)
+    whole = torch.empty(0, dtype=torch.int32, device=dev).set_(ts.untyped_storage(), ts.storage_offset(), (T + 513,))
+    slot_words = [T + 1 + 64 * x + 32 for x in range(8)]          # TGS_SLOTCTR_AT(T, x), tgs_common.h
+    g = torch.Generator().manual_seed(4)
+    v_rgb = torch.randn(H, W, 3, generator=g, dtype=torch.float64)
+    v_d, v_a = torch.randn(H, W, generator=g, dtype=torch.float64), torch.randn(H, W, generator=g, dtype=torch.float64)
+    out = {}
+    for name, opts in (("one", ops.raster_opts(k7_quad=0)), ("quad", ops.raster_opts(k7_quad=1, k7_quad_min_walk=8))):
+        whole[slot_words] = 0x7fffffff
+        buf = torch.full((sg.shape[0], 12), float("nan"), device=dev)
+        partials, _ = ops.rasterize_bwd(cam, sp, gb, sg, ts_plain, rgb, depth, fT, v_rgb.float().to(dev), v_d.float().to(dev),
+                                        v_a.float().to(dev), partials=buf, opts=opts)
+        out[name] = partials[:, :10].clone()
+        out[name + "_v"] = ops.reduce_partials(cam, sp, gb, torch.nan_to_num(partials)).cpu().double()
+    a, b = out["one"], out["quad"]
+    wa, wb = ~torch.isnan(a).any(dim=1), ~torch.isnan(b).any(dim=1)
+    assert torch.equal(wa, wb) and int(wa.sum()) == int(ts[T])            # every listed pair written, by either form
+    assert not torch.equal(a[wa], b[wa])                                    # the long tiles did take the four-wave kernel
+    mag = a[wa].abs().amax(dim=1, keepdim=True).clamp(min=1e-30)
+    rel = ((a[wa] - b[wa]).abs() / mag).amax(dim=1)
+    assert float(rel.max()) < 3e-4 and float(torch.quantile(rel[:: max(1, rel.numel() // 1_000_000)], 0.99)) < 1e-5, float(rel.max())
+    # ... and against the oracle (same statistical bar as test_rasterize_bwd)
+    f = splat_fields(sp)
+    n = int(ts[T])
+    leaves = {k: f[k].clone().requires_grad_(True) for k in ("xy", "conic", "opac", "rgb", "depth")}
+    ocam = O.Camera(viewmat=torch.from_numpy(np.asarray(cam.viewmat, np.float64)), fx=cam.fx, fy=cam.fy, cx=cam.cx, cy=cam.cy,
+                    W=W, H=H, bg=cam.bg)
+    o = O.blend(leaves["xy"], leaves["conic"], leaves["opac"], leaves["rgb"], leaves["depth"],
+                sg[:n].cpu().numpy().astype(np.int64), ts.cpu().numpy().astype(np.int64), ocam, want_margin=True)
+    ((o["rgb"] * v_rgb).sum() + (o["depth_acc"] * v_d).sum() + (o["alpha"] * v_a).sum()).backward()
+    frac_clear = (o["margin"] > 1e-3).double().mean().item()
+    v = out["quad_v"]
+    ref = dict(xy=leaves["xy"].grad, depth=leaves["depth"].grad, opac=leaves["opac"].grad, conic=leaves["conic"].grad, rgb=leaves["rgb"].grad)
+    got = dict(xy=v[:, 0:2], depth=v[:, 2], opac=v[:, 3], conic=v[:, 4:7], rgb=v[:, 7:10])
+    for k in ref:
+        scale = ref[k].abs().max().item()
+        bad = ((got[k] - ref[k]).abs() > 1e-3 * scale + 1e-4 * ref[k].abs()).double().mean().item()
+        assert bad < 0.02 + 5 * (1 - frac_clear), (k, bad, frac_clear)
+
+
 @pytest.mark.parametrize("N,W,H,deg,seed", [(1500, 128, 80, 3, 31), (400, 64, 48, 2, 32), (400, 64, 48, 0, 33)])
 def test_project_bwd(dev, N, W, H, deg, seed):
     from touch_gs_amd import ops

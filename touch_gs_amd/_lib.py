@@ -31,7 +31,7 @@ class TgsLossSpec(C.Structure):
 class TgsRasterOpts(C.Structure):
     """Per-call choice of the compositing kernels' forms (tgs.h); -1 = the process-wide default."""
     _fields_ = [("k6_blocks", C.c_int32), ("k6_split", C.c_int32), ("k7_front_to_back", C.c_int32),
-                ("k7_quad", C.c_int32), ("k7_quad_min_walk", C.c_int32)]
+                ("k7_quad", C.c_int32), ("k7_quad_min_walk", C.c_int32), ("k7_blocks", C.c_int32)]
 
 
 class TgsAdamSpec(C.Structure):

@@ -1363,6 +1363,269 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
 
 
 // ---------------------------------------------------------------------------------------------
+// K7 in 4x4-block form (round 6: built and measured -- VERDICT r5 next #2; NOT the default)
+// ---------------------------------------------------------------------------------------------
+// The forward's block form (k_raster_fwd_blocks) carried over to the backward: the four 16-lane DPP rows of the
+// wave own the four 4x4 blocks of the current quadrant and every row walks ITS block's list (back to front), so one
+// wave instruction works on four different Gaussians and the lanes that evaluate a pixel the Gaussian does not touch
+// drop from 63 % to ~50 %.  What the forward does not have is the per-Gaussian accumulation: here
+// every iteration ends with a reduction of ten values over the row's 16 lanes (DPP: 4 steps each) and lane 0 of the
+// row adds the row's totals to a ROW-PRIVATE accumulator acc[row][j][12] in LDS (two rows may meet the same Gaussian
+// in one iteration, and a float LDS atomic costs 3 cycles per active lane, profiles/r4_lds_atomic_lanes.txt); at the end
+// of the batch lane j adds the four rows' accumulators in row order and converts the moments as k_raster_bwd does.
+// Same decisions as the forward (eval_s on the same pixel constants, `s <= log2 255` below the pixel's stop position);
+// the sums are formed in a different order than k_raster_bwd's, so the two differ by rounding only.
+// Cost model and measurement: DESIGN.md section 5.1e.
+template <int CTRL>
+__device__ __forceinline__ float row_dpp_addf(float v) {
+  const int s = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
+  return v + __builtin_bit_cast(float, s);
+}
+__device__ __forceinline__ float row_sum16f(float v) {      // sum over the 16 lanes of a DPP row, in every lane
+  v = row_dpp_addf<0xB1>(v);    // quad_perm [1,0,3,2]
+  v = row_dpp_addf<0x4E>(v);    // quad_perm [2,3,0,1]
+  v = row_dpp_addf<0x141>(v);   // row_half_mirror
+  v = row_dpp_addf<0x140>(v);   // row_mirror
+  return v;
+}
+template <int CTRL>
+__device__ __forceinline__ int row_dpp_maxi(int v) {
+  const int s = __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+  return max(v, s);
+}
+__device__ __forceinline__ int row_max16i(int v) {
+  v = row_dpp_maxi<0xB1>(v); v = row_dpp_maxi<0x4E>(v); v = row_dpp_maxi<0x141>(v); v = row_dpp_maxi<0x140>(v);
+  return v;
+}
+
+__global__ __launch_bounds__(64) void k_raster_bwd_blocks(
+    CamK cam, int T_total, const float* __restrict__ splats, const int32_t* __restrict__ group_base,
+    const int32_t* __restrict__ sorted_gid, const int32_t* __restrict__ tile_start,
+    const float* __restrict__ out_rgb, const float* __restrict__ out_depth,
+    const float* __restrict__ final_T, const int32_t* __restrict__ stop_pos, const float* __restrict__ v_rgb,
+    const float* __restrict__ v_depth, const float* __restrict__ v_alpha, LossK loss,
+    float* __restrict__ partials, float* __restrict__ tile_loss, const int32_t* __restrict__ tile_order) {
+  const int tile = tile_order ? tile_order[blockIdx.x] : xcd_tile(blockIdx.x, T_total);
+  if (tile >= T_total) return;
+  const int lane = threadIdx.x;
+  const int ty = tile / cam.TW, tx = tile - ty * cam.TW;
+  // lane -> pixel as in k_raster_fwd_blocks: DPP row g owns block (g & 1, g >> 1) of every quadrant
+  const int g = lane >> 4, lx = 4 * (g & 1) + (lane & 3), ly = 4 * (g >> 1) + ((lane >> 2) & 3);
+  PixConst pc;
+  pc.u[0] = (float)lx - 7.5f; pc.u[1] = pc.u[0] + 8.f;
+  pc.v[0] = (float)ly - 7.5f; pc.v[1] = pc.v[0] + 8.f;
+#pragma unroll
+  for (int i = 0; i < 2; i++) { pc.uu[i] = pc.u[i] * pc.u[i]; pc.vv[i] = pc.v[i] * pc.v[i]; }
+#pragma unroll
+  for (int k = 0; k < 4; k++) pc.uv[k] = pc.u[k & 1] * pc.v[k >> 1];
+  const int start = tile_start[tile], end = tile_start[tile + 1];
+  const int n = end - start;
+
+  float T[4] = {1.f, 1.f, 1.f, 1.f};
+  float vCr[4], vCg[4], vCb[4], vD[4], SX[4];
+  int lim[4];
+  float l_l1 = 0.f, l_dep = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int px = tx * TGS_BLOCK + 8 * (k & 1) + lx;
+    const int py = ty * TGS_BLOCK + 8 * (k >> 1) + ly;
+    lim[k] = 0; vCr[k] = vCg[k] = vCb[k] = vD[k] = SX[k] = 0.f;
+    if (px < cam.W && py < cam.H) {
+      const size_t p = (size_t)py * cam.W + px;
+      const float Tf = final_T[p];
+      T[k] = Tf;
+      lim[k] = min(stop_pos[p], n);
+      float vA = v_alpha ? v_alpha[p] : 0.f;
+      if (v_rgb) { vCr[k] = v_rgb[3 * p]; vCg[k] = v_rgb[3 * p + 1]; vCb[k] = v_rgb[3 * p + 2]; }
+      if (v_depth) vD[k] = v_depth[p];
+      if (loss.on) {
+        if (loss.gt_rgb) {
+          const float d0 = out_rgb[3 * p] - loss.gt_rgb[3 * p];
+          const float d1 = out_rgb[3 * p + 1] - loss.gt_rgb[3 * p + 1];
+          const float d2 = out_rgb[3 * p + 2] - loss.gt_rgb[3 * p + 2];
+          vCr[k] += loss.l1w * ((d0 > 0.f) - (d0 < 0.f));
+          vCg[k] += loss.l1w * ((d1 > 0.f) - (d1 < 0.f));
+          vCb[k] += loss.l1w * ((d2 > 0.f) - (d2 < 0.f));
+          l_l1 += loss.l1w * (fabsf(d0) + fabsf(d1) + fabsf(d2));
+        }
+        if (loss.gt_depth) {
+          const float gd = loss.gt_depth[p];
+          if (gd > 0.f) {
+            const float alpha = fmaxf(1.f - Tf, 1e-10f);
+            const float ia = 1.0f / alpha;
+            const float dhat = out_depth[p] * ia;
+            const float r = dhat - gd;
+            float wgt = loss.dw;
+            if (loss.unc) wgt = wgt / (loss.uw * loss.unc[p] + loss.eps);
+            l_dep += wgt * r * r;
+            const float gdh = 2.f * wgt * r;
+            vD[k] += gdh * ia;
+            if (1.f - Tf > 1e-10f) vA += -gdh * dhat * ia;
+          }
+        }
+      }
+      const float bgdot = cam.bg[0] * vCr[k] + cam.bg[1] * vCg[k] + cam.bg[2] * vCb[k];
+      SX[k] = -Tf * (vA - bgdot);
+    }
+  }
+  if (tile_loss) {
+    const float a = wave_sum(l_l1), b = wave_sum(l_dep);
+    if (lane == 0) { tile_loss[2 * tile] = a; tile_loss[2 * tile + 1] = b; }
+  }
+  if (n == 0) return;
+  // how far into the list each of the 16 blocks reaches (wave-uniform: SGPRs), block of (row gg, quadrant k) = 4 (2 (k >> 1) + (gg >> 1)) + 2 (k & 1) + (gg & 1)
+  int blim[16];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int r = row_max16i(lim[k]);
+#pragma unroll
+    for (int gg = 0; gg < 4; gg++)
+      blim[4 * (2 * (k >> 1) + (gg >> 1)) + 2 * (k & 1) + (gg & 1)] = __builtin_amdgcn_readlane(r, 16 * gg);
+  }
+  int tmax = 0;
+#pragma unroll
+  for (int b = 0; b < 16; b++) tmax = max(tmax, blim[b]);
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = start + tmax + lane; i < end; i += 64) {       // behind the last stop position nothing received a gradient
+    const int gid = sorted_gid[i];
+    const size_t P = pair_index(group_base, gid, ld4(splats + (size_t)gid * TGS_SPLAT_FLOATS + 8), tx, ty);
+    float* o = partials + P * TGS_PARTIAL_FLOATS;
+    st4(o, z4); st4(o + 4, z4); st4(o + 8, z4);
+  }
+  if (tmax == 0) return;
+
+  __shared__ float4 recs[65 * 3];                 // 64 staged Gaussians + the null record (alpha = 0)
+  __shared__ unsigned int lists4[16 * 16];        // 16 lists of 64 one-byte indices, padded with 64 = null
+  __shared__ float4 acc4[4 * 64 * 3];             // [row][Gaussian j][12]: v_rgb 3, v_depth, Q0, Qu, Qv, Quu, Quv, Qvv, -, -
+  unsigned char* lists = reinterpret_cast<unsigned char*>(lists4);
+  float* acc = reinterpret_cast<float*>(acc4);
+  if (lane == 0) {
+    recs[64 * 3] = make_float4(3.0e38f, 0.f, 0.f, 0.f);
+    recs[64 * 3 + 1] = z4;
+    recs[64 * 3 + 2] = z4;
+  }
+  int myblock[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) myblock[k] = 4 * (2 * (k >> 1) + (g >> 1)) + 2 * (k & 1) + (g & 1);
+  const bool row_head = (lane & 15) == 0;
+
+  for (int base = start + ((tmax - 1) & ~63); base >= start; base -= 64) {
+    const int rel = base - start;
+    const int cnt_b = min(64, tmax - rel);
+    size_t P = 0;
+    float4 a0 = z4, a1 = z4;
+    unsigned my_mask = 0u;
+    __syncthreads();
+    if (lane < cnt_b) {
+      const int gid = sorted_gid[base + lane];
+      const float* r = splats + (size_t)gid * TGS_SPLAT_FLOATS;
+      a0 = ld4(r); a1 = ld4(r + 4);
+      const float4 a2 = ld4(r + 8);
+      float gx, gy;
+      centre_rel(a0, a2, tx, ty, cam.pix_center, gx, gy);
+      my_mask = block_mask16(gx, gy, a1.x, a1.y, a1.z, -__log2f(a0.w));
+      a0.x = gx; a0.y = gy;                       // kept for the conversion of the moments below
+      const TileRec t = make_tile_rec<false>(a0, a1, a2, gx, gy);
+      recs[lane * 3] = t.a; recs[lane * 3 + 1] = t.b; recs[lane * 3 + 2] = t.c;
+      P = pair_index(group_base, gid, a2, tx, ty);
+      // a block only needs the entries below its own furthest stop position
+      unsigned reach = 0u;
+#pragma unroll
+      for (int b = 0; b < 16; b++) reach |= (rel + lane < blim[b]) ? (1u << b) : 0u;
+      my_mask &= reach;
+    }
+    const bool clampy = __ballot(lane < cnt_b && a0.w > CLAMP_FREE_OPACITY) != 0ull;
+    reinterpret_cast<uint4*>(lists4)[lane] = make_uint4(0x40404040u, 0x40404040u, 0x40404040u, 0x40404040u);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      acc4[(r * 64 + lane) * 3] = z4; acc4[(r * 64 + lane) * 3 + 1] = z4; acc4[(r * 64 + lane) * 3 + 2] = z4;
+    }
+    __syncthreads();
+    int cnt[16];
+#pragma unroll
+    for (int b = 0; b < 16; b++) {     // lists in REVERSE list order: entry 0 = the block's deepest Gaussian of this batch
+      const bool in = (my_mask >> b) & 1u;
+      const unsigned long long bal = __ballot(in);
+      cnt[b] = __popcll(bal);
+      if (in) lists[b * 64 + cnt[b] - 1 - (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (unsigned char)lane;
+    }
+    __syncthreads();
+    auto walk = [&](auto mayclamp) {
+      constexpr bool MAYCLAMP = decltype(mayclamp)::value;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int b0 = 8 * (k >> 1) + 2 * (k & 1);                 // blocks b0, b0 + 1, b0 + 4, b0 + 5
+        const int nit = max(max(cnt[b0], cnt[b0 + 1]), max(cnt[b0 + 4], cnt[b0 + 5]));
+        const BLK_T* mylist = reinterpret_cast<const BLK_T*>(lists4) + myblock[k] * (64 / BLK_U);
+        for (int i4 = 0; BLK_U * i4 < nit; i4++) {
+          const unsigned idx4 = mylist[i4];
+#pragma unroll
+          for (int e = 0; e < BLK_U; e++) {
+            const int j = (idx4 >> (8 * e)) & 0xffu;               // 64 = null record: s = 3e38, alpha = 0
+            const float4 qa = recs[j * 3], qb = recs[j * 3 + 1], qc = recs[j * 3 + 2];
+            const float s = eval_s(qa, qb, pc, k);
+            const float ex = __builtin_amdgcn_exp2f(-s);
+            const float al0 = MAYCLAMP ? fminf(ALPHA_MAX, ex) : ex;
+            const bool go = (s <= LOG2_255) & (rel + j < lim[k]);   // the forward's alpha test below the pixel's stop position
+            const float al = go ? al0 : 0.f;
+            const float ra = __builtin_amdgcn_rcpf(1.0f - al);
+            const float Tp = T[k] * ra;
+            const float w = al * Tp;
+            float cv = qb.w * vCr[k];
+            cv = fmaf(qc.x, vCg[k], cv); cv = fmaf(qc.y, vCb[k], cv); cv = fmaf(qb.z, vD[k], cv);
+            const float z = w * cv;
+            float q = fmaf(-(al * ra), SX[k], z);
+            if constexpr (MAYCLAMP) q *= fmaxf(ex * (1.0f / ALPHA_MAX), 1.0f);
+            SX[k] += z;
+            T[k] = Tp;
+            // the row's ten sums for ITS Gaussian (tile-centred moments, converted at the end of the batch)
+            float c[10];
+            c[0] = w * vCr[k]; c[1] = w * vCg[k]; c[2] = w * vCb[k]; c[3] = w * vD[k];
+            c[4] = q; c[5] = q * pc.u[k & 1]; c[6] = q * pc.v[k >> 1];
+            c[7] = q * pc.uu[k & 1]; c[8] = q * pc.uv[k]; c[9] = q * pc.vv[k >> 1];
+#pragma unroll
+            for (int i = 0; i < 10; i++) c[i] = row_sum16f(c[i]);
+            if (row_head && j < 64) {
+              float* ac = acc + (g * 64 + j) * 12;
+              float4 x = ld4(ac), y = ld4(ac + 4);
+              float2 t2 = *reinterpret_cast<const float2*>(ac + 8);
+              x.x += c[0]; x.y += c[1]; x.z += c[2]; x.w += c[3];
+              y.x += c[4]; y.y += c[5]; y.z += c[6]; y.w += c[7];
+              t2.x += c[8]; t2.y += c[9];
+              st4(ac, x); st4(ac + 4, y);
+              *reinterpret_cast<float2*>(ac + 8) = t2;
+            }
+          }
+        }
+      }
+    };
+    if (clampy) walk(std::true_type{}); else walk(std::false_type{});
+    __syncthreads();
+    if (lane < cnt_b) {
+      float4 s0 = acc4[lane * 3], s1 = acc4[lane * 3 + 1], s2 = acc4[lane * 3 + 2];
+#pragma unroll
+      for (int r = 1; r < 4; r++) {        // the four rows' totals in row order
+        const float4 t0 = acc4[(r * 64 + lane) * 3], t1 = acc4[(r * 64 + lane) * 3 + 1], t2 = acc4[(r * 64 + lane) * 3 + 2];
+        s0.x += t0.x; s0.y += t0.y; s0.z += t0.z; s0.w += t0.w;
+        s1.x += t1.x; s1.y += t1.y; s1.z += t1.z; s1.w += t1.w;
+        s2.x += t2.x; s2.y += t2.y;
+      }
+      const float gx = a0.x, gy = a0.y;
+      const float A = a1.x, B = a1.y, Cc = a1.z;
+      const float Q0 = s1.x, Qu = s1.y, Qv = s1.z, Quu = s1.w, Quv = s2.x, Qvv = s2.y;
+      const float Mx = -(gx * Q0 - Qu), My = -(gy * Q0 - Qv);
+      const float Mxx = -(gx * gx * Q0 - 2.f * gx * Qu + Quu);
+      const float Mxy = -(gx * gy * Q0 - gx * Qv - gy * Qu + Quv);
+      const float Myy = -(gy * gy * Q0 - 2.f * gy * Qv + Qvv);
+      float* o = partials + P * TGS_PARTIAL_FLOATS;
+      st4(o, make_float4(A * Mx + B * My, B * Mx + Cc * My, s0.w, Q0 / a0.w));
+      st4(o + 4, make_float4(0.5f * Mxx, Mxy, 0.5f * Myy, s0.x));
+      st4(o + 8, make_float4(s0.y, s0.z, 0.f, 0.f));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K7 for LONG tiles: four waves per tile, one per 8x8 quadrant
 // ---------------------------------------------------------------------------------------------
 // k_raster_bwd gives a tile to ONE wave, which walks the list entry by entry (~750 - 1000 cycles each when the wave is
@@ -1644,6 +1907,8 @@ static RasterDefault g_k7_quad{"TGS_K7_QUAD", 8, false};
 static RasterDefault g_k7_quad_min{"TGS_K7_QUAD_MIN", 48, false};
 // TGS_K6_SPLIT: tile_is_split()'s factor (default 4: lists beyond 4x the balanced per-slot load, and 256); 0 = never
 static RasterDefault g_k6_split{"TGS_K6_SPLIT", 4, false};
+// TGS_K7_BLOCKS: 1 = the backward in 4x4-block form (k_raster_bwd_blocks); default 0 (measured slower)
+static RasterDefault g_k7_blocks{"TGS_K7_BLOCKS", 0, true};
 static inline int opt_or(const TgsRasterOpts* o, int32_t TgsRasterOpts::*f, RasterDefault& d) {
   return (o && o->*f >= 0) ? (int)(o->*f) : d.get();
 }
@@ -1744,6 +2009,11 @@ static int rasterize_bwd_impl(const TgsCamera* cam, const float* splats,
                        group_base, sorted_gid, tile_start, out_rgb, out_depth, final_T,
                        v_rgb, v_depth, v_alpha, lk, partials, tile_loss, tile_order,
                        (const unsigned long long*)slot_ok);
+  } else if (opt_or(opts, &TgsRasterOpts::k7_blocks, g_k7_blocks)) {   // 4x4-block form (round 6: measured, not the default)
+    TGS_CHECK_ARG(stop_pos, "stop_pos (written by tgs_rasterize_fwd) is required");
+    hipLaunchKernelGGL(k_raster_bwd_blocks, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T, splats,
+                       group_base, sorted_gid, tile_start, out_rgb, out_depth, final_T, stop_pos,
+                       v_rgb, v_depth, v_alpha, lk, partials, tile_loss, tile_order);
   } else {
     TGS_CHECK_ARG(stop_pos, "stop_pos (written by tgs_rasterize_fwd) is required");
     QuadRule qf;

@@ -329,11 +329,11 @@ def _tile_start_len(tile_start) -> int:
     return tile_start.untyped_storage().nbytes() // 4 - tile_start.storage_offset()
 
 
-def raster_opts(k6_blocks=None, k6_split=None, k7_front_to_back=None, k7_quad=None, k7_quad_min_walk=None):
+def raster_opts(k6_blocks=None, k6_split=None, k7_front_to_back=None, k7_quad=None, k7_quad_min_walk=None, k7_blocks=None):
     """Per-call TgsRasterOpts (tgs.h): the forms of the compositing kernels for ONE rasterize_fwd / rasterize_bwd call,
     independent of the process-wide ``set_raster_variant`` / ``set_k6_split`` / ``set_k7_quad`` defaults.  None = default."""
     f = lambda v: -1 if v is None else int(v)
-    return _lib.TgsRasterOpts(f(k6_blocks), f(k6_split), f(k7_front_to_back), f(k7_quad), f(k7_quad_min_walk))
+    return _lib.TgsRasterOpts(f(k6_blocks), f(k6_split), f(k7_front_to_back), f(k7_quad), f(k7_quad_min_walk), f(k7_blocks))
 
 
 def _check_tile_start(tile_start, T: int) -> None:
