@@ -272,7 +272,7 @@ def test_k7_block_form_matches_the_one_wave_form_and_the_oracle(dev, N, W, H, de
     """k_raster_bwd_blocks (TgsRasterOpts.k7_blocks = 1; round 6, measured and NOT the default -- DESIGN 5.1e): the
     backward with a different Gaussian in every 16-lane DPP row.  Same decisions as the forward, sums formed in another
     order: every (tile, Gaussian) record within rounding of the one-wave form's record (its own magnitude as the scale),
-    NaN-poisoned buffers show that exactly the listed pairs are written, tile losses bit for bit, and the ten
+    NaN-poisoned buffers show that exactly the listed pairs are written, tile losses equal up to rounding, and the ten
     screen-space gradients hold the statistical bar of test_rasterize_bwd against the fp64 oracle."""
     from touch_gs_amd import ops
     P, cam, acam, D, sp, gb, ts, sg, n = _blend_inputs(dev, N, W, H, deg, seed, clamp=clamp)
@@ -292,7 +292,8 @@ def test_k7_block_form_matches_the_one_wave_form_and_the_oracle(dev, N, W, H, de
                      ops.reduce_partials(acam, sp, gb, torch.nan_to_num(partials)).cpu().double())
     (a, ta, _), (b, tb, v) = out["one"], out["blocks"]
     wa, wb = ~torch.isnan(a).any(dim=1), ~torch.isnan(b).any(dim=1)
-    assert torch.equal(wa, wb) and int(wa.sum()) == n and torch.equal(ta, tb)
+    # (tile losses: the same 256 pixel terms per tile, summed over another lane -> pixel mapping: equal up to rounding)
+    assert torch.equal(wa, wb) and int(wa.sum()) == n and torch.allclose(ta, tb, rtol=1e-5, atol=1e-9)
     a, b = a[wa], b[wa]
     mag = a.abs().amax(dim=1, keepdim=True).clamp(min=1e-30)
     rel = ((a - b).abs() / mag).amax(dim=1)

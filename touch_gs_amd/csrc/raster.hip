@@ -1376,18 +1376,26 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
 // Same decisions as the forward (eval_s on the same pixel constants, `s <= log2 255` below the pixel's stop position);
 // the sums are formed in a different order than k_raster_bwd's, so the two differ by rounding only.
 // Cost model and measurement: DESIGN.md section 5.1e.
-template <int CTRL>
-__device__ __forceinline__ float row_dpp_addf(float v) {
-  const int s = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
-  return v + __builtin_bit_cast(float, s);
+// sum over the 16 lanes of a DPP row, in every lane: four v_add_f32_dpp.  (Written as inline asm: from
+// __builtin_amdgcn_update_dpp(0, v, ..) + add the compiler emits v_mov_b32_dpp + v_add_f32 -- 8 instead of 4 VALU per
+// value, 80 instead of 40 per iteration of this kernel: the first build issued 462 M VALU instructions per cfg3 frame
+// against the one-wave form's 233 M, profiles/r6_pmc_k7_forms_cfg3.json.)
+// Ten values at once, stage by stage: a DPP operand must have been written at least two VALU slots earlier (the
+// compiler's hazard recogniser does not look inside asm), which the nine other values of a stage provide; one s_nop
+// covers the first stage's first operands.
+#define TGS_DPP_STAGE(MOD)                                                                      \
+  _Pragma("unroll") for (int i = 0; i < 10; i++)                                                 \
+      asm volatile("v_add_f32_dpp %0, %1, %1 " MOD " row_mask:0xf bank_mask:0xf" : "=v"(t[i]) : "v"(c[i]));  \
+  _Pragma("unroll") for (int i = 0; i < 10; i++) c[i] = t[i];
+__device__ __forceinline__ void row_sum16x10(float (&c)[10]) {
+  float t[10];
+  asm volatile("s_nop 1");
+  TGS_DPP_STAGE("quad_perm:[1,0,3,2]")
+  TGS_DPP_STAGE("quad_perm:[2,3,0,1]")
+  TGS_DPP_STAGE("row_half_mirror")
+  TGS_DPP_STAGE("row_mirror")
 }
-__device__ __forceinline__ float row_sum16f(float v) {      // sum over the 16 lanes of a DPP row, in every lane
-  v = row_dpp_addf<0xB1>(v);    // quad_perm [1,0,3,2]
-  v = row_dpp_addf<0x4E>(v);    // quad_perm [2,3,0,1]
-  v = row_dpp_addf<0x141>(v);   // row_half_mirror
-  v = row_dpp_addf<0x140>(v);   // row_mirror
-  return v;
-}
+#undef TGS_DPP_STAGE
 template <int CTRL>
 __device__ __forceinline__ int row_dpp_maxi(int v) {
   const int s = __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
@@ -1583,8 +1591,7 @@ __global__ __launch_bounds__(64) void k_raster_bwd_blocks(
             c[0] = w * vCr[k]; c[1] = w * vCg[k]; c[2] = w * vCb[k]; c[3] = w * vD[k];
             c[4] = q; c[5] = q * pc.u[k & 1]; c[6] = q * pc.v[k >> 1];
             c[7] = q * pc.uu[k & 1]; c[8] = q * pc.uv[k]; c[9] = q * pc.vv[k >> 1];
-#pragma unroll
-            for (int i = 0; i < 10; i++) c[i] = row_sum16f(c[i]);
+            row_sum16x10(c);
             if (row_head && j < 64) {
               float* ac = acc + (g * 64 + j) * 12;
               float4 x = ld4(ac), y = ld4(ac + 4);
