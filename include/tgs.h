@@ -25,7 +25,9 @@
 extern "C" {
 #endif
 
-#define TGS_VERSION 300         /* 0.3.0 -- 300: every entry point that takes `tile_start` takes its length next to it (validated against
+#define TGS_VERSION 310         /* 0.3.1 -- 310 (additions only, nothing of 300 changed meaning): TgsRasterOpts gains a sixth field k7_blocks
+                                   (callers that pass the struct must pass the new size), tgs_adam_sh_gathered_geom_project_next,
+                                   tgs_calib_fma_stream.  300: every entry point that takes `tile_start` takes its length next to it (validated against
                                    tgs_tile_start_len: the rasterizer keeps 512 scratch ints behind the starts) and the rasterize calls declare it
                                    non-const (they write that scratch); tgs_rasterize_fwd / _bwd / _bwd_band take a per-call TgsRasterOpts.
                                    201: tile_start buffers are T+513 ints; adds tgs_set_k7_quad, tgs_set_k6_split.  200 broke the ABI of 100:
@@ -387,6 +389,22 @@ int tgs_adam_geom_project_next(const TgsCamera* next_cam /*[host]*/, int N, int 
                                float* splats_next, int32_t* radii_next, int32_t* group_base_next,
                                int32_t* tile_cursor_next, int64_t capacity_next, void* scratch_next,
                                int32_t* status_next, int32_t* sticky_overflow, int counters_cleared, void* stream);
+/* The whole tail of a data-parallel step in one launch (TGS_VERSION 310): tgs_adam_step_sh_gathered_rows for every row
+ *     chunk of the pipelined exchange + tgs_adam_geom_project_next -- the updated SH rows stay on chip for the next
+ *     camera's colours, the geometry gradients are read once.  chunk_begin[n_chunks + 1] (host; consecutive ranges from 0 to N,
+ *     every begin a multiple of TGS_GROUP, n_chunks <= 8), chunk_blocks[n_chunks] (host array of DEVICE pointers to the
+ *     all-gathered colour blocks [world][3 rows + 4] of each chunk).  Bit-identical to the unfused sequence.  It can
+ *     only start once the geometry all-reduce has landed; callers with real links keep the chunked SH Adam, which hides
+ *     under it (parallel.GradSync.fused_tail). */
+int tgs_adam_sh_gathered_geom_project_next(const TgsCamera* next_cam /*[host]*/, int world, int N, int sh_stride, int sh_deg,
+                                           float* params, const float* grads, int n_chunks,
+                                           const int32_t* chunk_begin /*[host]*/, const float* const* chunk_blocks /*[host]*/,
+                                           float* exp_avg, float* exp_avg_sq, const TgsAdamSpec* spec /*[host]*/,
+                                           float grad_scale, const int32_t* skip_if_overflow, int32_t* tag_word,
+                                           int32_t tag_value, float* splats_next, int32_t* radii_next,
+                                           int32_t* group_base_next, int32_t* tile_cursor_next, int64_t capacity_next,
+                                           void* scratch_next, int32_t* status_next, int32_t* sticky_overflow,
+                                           int counters_cleared, void* stream);
 int tgs_project_bin_sort_front(const TgsCamera* cam /*[host]*/, int N, const float* means,
                                const float* log_scales, const float* quats, const float* opac_logit,
                                const float* sh, int sh_stride, int sh_deg, float* splats, int32_t* radii,

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"{s} declared in include/tgs.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in touch_gs_amd/_lib.py"
     assert set(_lib.SIGNATURES) == set(syms)
-    assert lib.tgs_version() == 300
+    assert lib.tgs_version() == 310
 
 
 def _declared_prototypes():
@@ -603,7 +603,7 @@ def test_raster_defaults_are_process_wide_and_opts_override_them():
         lib.tgs_set_k6_split(before[1])
         lib.tgs_set_k7_quad(before[2] & 255, before[2] >> 8)
     o = ops.raster_opts()
-    assert [getattr(o, f[0]) for f in o._fields_] == [-1] * 5
+    assert [getattr(o, f[0]) for f in o._fields_] == [-1] * 6
     o = ops.raster_opts(k6_blocks=False, k7_quad=0)
     assert (o.k6_blocks, o.k6_split, o.k7_front_to_back, o.k7_quad, o.k7_quad_min_walk) == (0, -1, -1, 0, -1)
 

@@ -956,6 +956,69 @@ def test_rccl_single_rank_process_group(dev, tmp_path):
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+_FUSED_TAIL_WORKER = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from touch_gs_amd import parallel
+from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
+from touch_gs_amd.optim import GaussianParams
+from touch_gs_amd.scene import make_view, synthetic_gaussians
+dp = parallel.init_from_env()
+dev = torch.device("cuda", dp.local_rank)
+N, W, H, deg = 20_000, 320, 208, 3
+P, _ = synthetic_gaussians(N, W, H, deg, 17)
+params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
+m = DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=0), params)
+m.spatial_sort()
+views = [make_view(N, W, H, deg, 17, dev, view=v, n_views=4) for v in range(4)]
+for v in views: v.valid_count()
+for i in range(6):
+    m.train_step(views[dp.views_for_step(i, 4)], dp, next_view=views[dp.views_for_step(i + 1, 4)])
+torch.cuda.synchronize()
+dp.assert_replicas_identical(m.params.flat)
+if dp.rank == 0:
+    torch.save(dict(flat=m.params.flat.cpu(), m=m.optimizer.exp_avg.cpu(), v=m.optimizer.exp_avg_sq.cpu(),
+                    splats=m._prefetch_ready.front.splats.cpu(), issued=bool(m._prefetch_ready.front_issued)), sys.argv[2])
+dp.barrier()
+import torch.distributed as dist
+dist.destroy_process_group()
+print("TAIL_OK")
+'''
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_fused_data_parallel_tail_is_bit_identical_to_the_chunked_one(dev, tmp_path, world):
+    """tgs_adam_sh_gathered_geom_project_next (round 6): the tail of a data-parallel step -- SH Adam of every row chunk from
+    the gathered colour blocks, geometry Adam from the all-reduced gradients, the next view's colours and K1 -- as ONE
+    launch (TGS_DP_FUSED_TAIL=1; the default only for one-rank groups) against the chunk-by-chunk sequence (=0), three row
+    chunks, six steps with the next view announced: parameters, both Adam moments and the prefetched records of the next
+    frame bit for bit.  world 1: a one-rank RCCL group (TGS_DP_FORCE_COLLECTIVES); world 2: two ranks share the GPU over gloo."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "tail_worker.py"
+    script.write_text(_FUSED_TAIL_WORKER)
+    out = {}
+    for mode in ("0", "1"):
+        f = tmp_path / f"tail_{mode}.pt"
+        env = dict(os.environ, TGS_DP_FUSED_TAIL=mode, TGS_DP_COLOR_CHUNKS="3", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if world == 1:
+            env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=free_port(), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                       TGS_DP_FORCE_COLLECTIVES="1")
+            env.pop("TGS_DIST_BACKEND", None)
+            cmd = [sys.executable, str(script), root, str(f)]
+        else:
+            env["TGS_DIST_BACKEND"] = "gloo"
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+                   "127.0.0.1", "--master-port", free_port(), str(script), root, str(f)]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "TAIL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+        out[mode] = torch.load(f)
+    a, b = out["0"], out["1"]
+    assert a["issued"] and b["issued"]
+    for k in ("flat", "m", "v", "splats"):
+        assert torch.equal(a[k], b[k]), k
+
+
 def test_bench_two_gpus_rccl(dev, tmp_path):
     """First multi-GPU evidence wherever >= 2 GPUs are visible: bench.py --gpus 2 through
     torch.distributed.run over RCCL; the JSON line carries the exchange's bus bandwidth and the

@@ -81,6 +81,9 @@ SIGNATURES = {
                                                   _P, _P, _P, _I, _P]),
     "tgs_adam_geom_project_next": (C.c_int, [C.POINTER(TgsCamera), _I, _I, _I, _P, _P, _P, _P, C.POINTER(TgsAdamSpec), C.c_float,
                                              _P, _P, C.c_int32, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _I, _P]),
+    "tgs_adam_sh_gathered_geom_project_next": (C.c_int, [C.POINTER(TgsCamera), _I, _I, _I, _I, _P, _P, _I, C.POINTER(C.c_int32),
+                                                         C.POINTER(C.c_void_p), _P, _P, C.POINTER(TgsAdamSpec), C.c_float, _P, _P,
+                                                         C.c_int32, _P, _P, _P, _P, C.c_int64, _P, _P, _P, _I, _P]),
     "tgs_project_bin_sort_front": (C.c_int, [C.POINTER(TgsCamera), _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, C.c_int64, _P,
                                              _P, _P, C.c_int64, _P, _P, _P, C.c_int32, _P, C.c_int32, C.POINTER(TgsCamera), _P, _P, _P]),
     "tgs_front_can_clear_next": (C.c_int, [_I, _I, _I]),

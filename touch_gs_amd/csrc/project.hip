@@ -1161,6 +1161,154 @@ __global__ __launch_bounds__(256) void k_adam_sh_gathered(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Data-parallel step, fused tail (round 6): SH Adam from the gathered colour blocks + geometry Adam from the
+// all-reduced gradients + the next view's colours and K1 in ONE launch over the whole model
+// ---------------------------------------------------------------------------------------------
+// = k_adam_sh_gathered (per row chunk) followed by k_adam_geom_project_next, for a workgroup's 256 rows: the updated
+// SH rows stay in the LDS image the Adam stream has just produced, so the next camera's colour is evaluated there
+// instead of from rows re-read from HBM, the gradients of the 11 geometry parameters are read once, and four to five
+// launches become one.  Same adam1 / sh_color / project_fwd_core on the same values: bit-identical to the unfused
+// sequence.  It can only start when the geometry all-reduce has landed -- which on a node is exactly what the chunked
+// SH Adam hides under -- so the host selects it by world size (parallel.GradSync.fused_tail).
+struct ChunkTable {
+  int n;
+  int begin[9];              // row chunk c = [begin[c], begin[c + 1]); multiples of 256 except the last end
+  const float* blk[8];       // all-gathered colour blocks of the chunk: [world][3 rows + 4]
+};
+
+template <int DEG>
+__global__ __launch_bounds__(256) void k_adam_sh_geom_next(
+    CamK cam, int world, int N, int sh_stride, float* __restrict__ means, float* __restrict__ log_scales,
+    float* __restrict__ quats, float* __restrict__ opac_logit, float* __restrict__ sh, const float* __restrict__ grads,
+    ChunkTable ct, AdamK ad_in, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
+    float* __restrict__ splats, int32_t* __restrict__ radii, int32_t* __restrict__ group_base,
+    int32_t* __restrict__ tile_count, int32_t* __restrict__ rank, int32_t* __restrict__ status,
+    long long capacity, int32_t* __restrict__ sticky, int32_t* __restrict__ tag, int32_t tag_value) {
+  if (ad_in.guard && ad_in.guard[1]) return;   // a rank's frame overflowed: no update, the tag keeps its old value
+  const AdamK ad = adam_resolve(ad_in);
+  constexpr int K = (DEG + 1) * (DEG + 1);
+  const int ROW = 3 * sh_stride, RS = ROW + 4, F4 = ROW / 4;
+  extern __shared__ float4 lds4[];
+  float* lds = reinterpret_cast<float*>(lds4);
+  const int tid = threadIdx.x;
+  const int g0 = blockIdx.x * 256;
+  const int g = g0 + tid;
+  const int nrows = min(256, N - g0);
+  const size_t blk = (size_t)g0 * ROW;
+  int row0 = 0, rows_c = N;
+  const float* v_color_all = ct.blk[0];
+#pragma unroll
+  for (int c = 0; c < 8; c++)
+    if (c < ct.n && g0 >= ct.begin[c] && g0 < ct.begin[c + 1]) { row0 = ct.begin[c]; rows_c = ct.begin[c + 1] - ct.begin[c]; v_color_all = ct.blk[c]; }
+  float m[3] = {0.f, 0.f, 0.f}, ls[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, rgb[3] = {0.f, 0.f, 0.f};
+  float ol = 0.f;
+  // ---- the SH gradient sum_r Y(dir_r) (x) v_color_r of this row, in rank order, into the LDS image (k_adam_sh_gathered) ----
+  if (g < N) {
+    m[0] = means[3 * g]; m[1] = means[3 * g + 1]; m[2] = means[3 * g + 2];   // the means the forward pass used
+    float acc[3 * K];
+#pragma unroll
+    for (int i = 0; i < 3 * K; i++) acc[i] = 0.f;
+    const size_t nb = (size_t)rows_c;
+    const size_t blk_r = 3 * nb + 4;
+    for (int r = 0; r < world; r++) {
+      const float* vc = v_color_all + r * blk_r + 3 * (size_t)(g - row0);
+      const float* cp = v_color_all + r * blk_r + 3 * nb;
+      const float v0 = vc[0], v1 = vc[1], v2 = vc[2];
+      const float dx = m[0] - cp[0], dy = m[1] - cp[1], dz = m[2] - cp[2];
+      const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+      float Y[16];
+      sh_basis<DEG>(dx * inv, dy * inv, dz * inv, Y);
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        acc[3 * k] = fmaf(Y[k], v0, acc[3 * k]);
+        acc[3 * k + 1] = fmaf(Y[k], v1, acc[3 * k + 1]);
+        acc[3 * k + 2] = fmaf(Y[k], v2, acc[3 * k + 2]);
+      }
+    }
+    float* row = lds + tid * RS;
+#pragma unroll
+    for (int i = 0; i < 3 * K / 4; i++) st4(row + 4 * i, make_float4(acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]));
+    if constexpr ((3 * K) % 4 != 0) {
+      float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < (3 * K) % 4; i++) t[i] = acc[(3 * K / 4) * 4 + i];
+      st4(row + (3 * K / 4) * 4, make_float4(t[0], t[1], t[2], t[3]));
+    }
+    for (int i = (3 * K + 3) / 4; i < F4; i++) st4(row + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
+  }
+  __syncthreads();
+  // ---- Adam over the block's SH rows; the updated coefficients replace the consumed gradient in the image ----
+  const int nf = nrows * F4;
+  for (int f0 = tid; f0 < nf; f0 += 256 * 2) {
+    float4 P[2], M[2], V[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int f = f0 + 256 * u;
+      if (f < nf) {
+        const size_t e = blk + 4 * (size_t)f;
+        P[u] = ld4_nt(sh + e); M[u] = ld4_nt(exp_avg + ad.e_opac + e); V[u] = ld4_nt(exp_avg_sq + ad.e_opac + e);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int f = f0 + 256 * u;
+      if (f < nf) {
+        const int row = f / F4, c4 = f - row * F4;
+        const float4 G = ld4(lds + row * RS + 4 * c4);
+        const size_t e = blk + 4 * (size_t)f;
+        const int c = 4 * c4;
+        adam1(ad, c < 3 ? ad.lr_dc : ad.lr_rest, P[u].x, G.x, M[u].x, V[u].x);
+        adam1(ad, c + 1 < 3 ? ad.lr_dc : ad.lr_rest, P[u].y, G.y, M[u].y, V[u].y);
+        adam1(ad, c + 2 < 3 ? ad.lr_dc : ad.lr_rest, P[u].z, G.z, M[u].z, V[u].z);
+        adam1(ad, ad.lr_rest, P[u].w, G.w, M[u].w, V[u].w);
+        st4_nt(sh + e, P[u]); st4_nt(exp_avg + ad.e_opac + e, M[u]); st4_nt(exp_avg_sq + ad.e_opac + e, V[u]);
+        st4(lds + row * RS + 4 * c4, P[u]);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- Adam on the 11 geometry parameters (k_adam_geom_project_next), then the next camera's colour from the LDS row ----
+  if (g < N) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const long long e = 3ll * g + j;
+      float P = m[j], M = exp_avg[e], V = exp_avg_sq[e];
+      adam1(ad, ad.lr_means, P, grads[e], M, V);
+      means[3 * g + j] = P; exp_avg[e] = M; exp_avg_sq[e] = V;
+      m[j] = P;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const long long e = ad.e_means + 3ll * g + j;
+      float P = log_scales[3 * g + j], M = exp_avg[e], V = exp_avg_sq[e];
+      adam1(ad, ad.lr_scales, P, grads[e], M, V);
+      log_scales[3 * g + j] = P; exp_avg[e] = M; exp_avg_sq[e] = V;
+      ls[j] = P;
+    }
+    {
+      const long long e = ad.e_scales + 4ll * g;
+      float4 Q = ld4(quats + 4 * (size_t)g), G = ld4_nt(grads + e), M = ld4_nt(exp_avg + e), V = ld4_nt(exp_avg_sq + e);
+      adam1(ad, ad.lr_quats, Q.x, G.x, M.x, V.x); adam1(ad, ad.lr_quats, Q.y, G.y, M.y, V.y);
+      adam1(ad, ad.lr_quats, Q.z, G.z, M.z, V.z); adam1(ad, ad.lr_quats, Q.w, G.w, M.w, V.w);
+      st4(quats + 4 * (size_t)g, Q); st4_nt(exp_avg + e, M); st4_nt(exp_avg_sq + e, V);
+      q[0] = Q.x; q[1] = Q.y; q[2] = Q.z; q[3] = Q.w;
+    }
+    {
+      const long long e = ad.e_quats + g;
+      float P = opac_logit[g], M = exp_avg[e], V = exp_avg_sq[e];
+      adam1(ad, ad.lr_opac, P, grads[e], M, V);
+      opac_logit[g] = P; exp_avg[e] = M; exp_avg_sq[e] = V;
+      ol = P;
+    }
+    sh_color<DEG>(m, cam.campos, lds + tid * RS, rgb);
+  }
+  __syncthreads();     // the group scan of K1 takes over the SH image
+  project_fwd_core<true>(cam, N, g, m, ls, q, ol, rgb, splats, radii, group_base, tile_count, rank, status,
+                         capacity, sticky, reinterpret_cast<GroupScan*>(lds4));
+  if (g == 0) *tag = tag_value;
+}
+
+// ---------------------------------------------------------------------------------------------
 // stand-alone SH evaluation (gsplat `spherical_harmonics` op: no +0.5, no clamp; coefficients only
 // receive gradient, view directions are treated as constants)
 // ---------------------------------------------------------------------------------------------
@@ -1748,4 +1896,62 @@ extern "C" int tgs_adam_step_sh_gathered(int world, int N, int sh_stride, int sh
   TGS_CHECK_ARG(world >= 1 && N >= 0, "bad size");
   return tgs_adam_step_sh_gathered_rows(world, N, 0, N, sh_stride, sh_deg, params, v_color_all, exp_avg,
                                         exp_avg_sq, spec, grad_scale, skip_if_overflow, stream);
+}
+
+// The fused tail of a data-parallel step (k_adam_sh_geom_next): tgs_adam_step_sh_gathered_rows for every row chunk +
+// tgs_adam_geom_project_next, in one launch.  chunk_begin[n_chunks + 1] (host): the chunks' row ranges, consecutive from
+// 0 to N, every begin a multiple of TGS_GROUP; chunk_blocks[n_chunks] (host array of DEVICE pointers): the all-gathered
+// colour blocks [world][3 rows + 4] of each chunk.
+extern "C" int tgs_adam_sh_gathered_geom_project_next(
+    const TgsCamera* next_cam, int world, int N, int sh_stride, int sh_deg, float* params, const float* grads,
+    int n_chunks, const int32_t* chunk_begin, const float* const* chunk_blocks, float* exp_avg, float* exp_avg_sq,
+    const TgsAdamSpec* spec, float grad_scale, const int32_t* skip_if_overflow, int32_t* tag_word, int32_t tag_value,
+    float* splats_next, int32_t* radii_next, int32_t* group_base_next, int32_t* tile_cursor_next,
+    int64_t capacity_next, void* scratch_next, int32_t* status_next, int32_t* sticky_overflow, int counters_cleared,
+    void* stream) {
+  TGS_CHECK_ARG(camera_ok(next_cam), "bad next camera");
+  TGS_CHECK_ARG(next_cam->W <= 4080 && next_cam->H <= 4080, "image side > 4080 px (255 tiles)");
+  TGS_CHECK_ARG(world >= 1 && N >= 0 && capacity_next >= 0 && capacity_next < (1ll << 31), "bad size");
+  if (N == 0) return TGS_OK;
+  TGS_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && spec && tag_word, "null pointer");
+  TGS_CHECK_ARG(splats_next && group_base_next && tile_cursor_next && scratch_next && status_next, "null front buffer");
+  TGS_CHECK_ARG(sh_deg >= 0 && sh_deg <= 3 && sh_stride >= (sh_deg + 1) * (sh_deg + 1), "bad SH degree / stride");
+  TGS_CHECK_ARG((3 * sh_stride) % 4 == 0, "SH row (3*sh_stride floats) must be a multiple of 16 bytes");
+  TGS_CHECK_ARG(256 * (size_t)(3 * sh_stride + 4) * sizeof(float) >= sizeof(GroupScan), "SH storage too small for the fused tail (needs >= 4 bases)");
+  TGS_CHECK_ARG(n_chunks >= 1 && n_chunks <= 8 && chunk_begin && chunk_blocks, "1 .. 8 row chunks");
+  ChunkTable ct;
+  ct.n = n_chunks;
+  for (int c = 0; c <= 8; c++) ct.begin[c] = c <= n_chunks ? chunk_begin[c] : N;
+  for (int c = 0; c < 8; c++) ct.blk[c] = c < n_chunks ? chunk_blocks[c] : nullptr;
+  TGS_CHECK_ARG(ct.begin[0] == 0 && ct.begin[n_chunks] == N, "the chunks must cover rows [0, N)");
+  for (int c = 0; c < n_chunks; c++) {
+    TGS_CHECK_ARG(ct.begin[c] % TGS_GROUP == 0 && ct.begin[c] < ct.begin[c + 1] && ct.blk[c], "bad row chunk");
+  }
+  const CamK kn = make_camk(next_cam);
+  const int T = kn.TW * kn.TH;
+  hipStream_t s = (hipStream_t)stream;
+  const BinScratch sc = carve_scratch(scratch_next, capacity_next);
+  if (!counters_cleared) {
+    hipLaunchKernelGGL(k_clear_counters, dim3((max(TGS_XCC * T, 2) + 255) / 256), dim3(256), 0, s, tile_cursor_next, T,
+                       status_next, sticky_overflow);
+    TGS_CHECK_LAUNCH();
+  }
+  AdamK a = make_adamk(N, sh_stride, spec, grad_scale);
+  a.guard = skip_if_overflow;
+  const dim3 grid((N + 255) / 256), block(256);
+  const size_t lds_bytes = 256 * (size_t)(3 * sh_stride + 4) * sizeof(float);
+#define LAUNCH_T(D)                                                                                            \
+  hipLaunchKernelGGL((k_adam_sh_geom_next<D>), grid, block, lds_bytes, s, kn, world, N, sh_stride, params,       \
+                     params + a.e_means, params + a.e_scales, params + a.e_quats, params + a.e_opac, grads, ct, a, \
+                     exp_avg, exp_avg_sq, splats_next, radii_next, group_base_next, tile_cursor_next, sc.rank,     \
+                     status_next, (long long)capacity_next, sticky_overflow, tag_word, tag_value)
+  switch (sh_deg) {
+    case 0: LAUNCH_T(0); break;
+    case 1: LAUNCH_T(1); break;
+    case 2: LAUNCH_T(2); break;
+    default: LAUNCH_T(3); break;
+  }
+#undef LAUNCH_T
+  TGS_CHECK_LAUNCH();
+  return TGS_OK;
 }

@@ -607,12 +607,21 @@ class DepthGaussianSplattingModel:
 
             rows = self._color_rows
 
+            # the whole tail (SH Adam of every chunk + geometry Adam + the next view's K1) as ONE launch behind the
+            # geometry all-reduce, where that is a gain (GradSync.fused_tail: by world size -- on a node the chunked SH
+            # Adam hides under the transfers, which the fused launch cannot)
+            fused_tail = (arm is not None and not fuse and len(rows) <= 8 and opt.p.K >= 4 and self.params.N > 0 and dp.fused_tail())
+
             def step_sh_chunk(c, allc, scale):
                 if c == 0 and dguard is not None:   # every chunk block of a rank carries the frame's flag
                     ops.dp_agree_overflow(dp.world, rows[0][1] - rows[0][0], allc, dguard, self.budget.sticky)
-                opt.step_sh_gathered(dp.world, deg, allc, scale, guard=dguard, rows=rows[c])
+                if not fused_tail:
+                    opt.step_sh_gathered(dp.world, deg, allc, scale, guard=dguard, rows=rows[c])
 
-            if arm is not None and not fuse:
+            if fused_tail:
+                step_geom = lambda b, e, scale: opt.step_sh_gathered_geom_and_project_next(
+                    dp.world, deg, rows, self._color_blocks_all, scale, dguard, arm)
+            elif arm is not None and not fuse:
                 step_geom = lambda b, e, scale: opt.step_geom_and_project_next(deg, scale, dguard, arm)
             else:
                 step_geom = lambda b, e, scale: opt.step_range(b, e, scale, guard=dguard)

@@ -225,6 +225,28 @@ class FusedAdam:
               "tgs_adam_geom_project_next")
         prefetch.front_issued = True
 
+    def step_sh_gathered_geom_and_project_next(self, world: int, sh_deg: int, rows, blocks_all, grad_scale: float, guard,
+                                               prefetch):
+        """The whole tail of a data-parallel step in ONE launch (tgs_adam_sh_gathered_geom_project_next): Adam on the SH
+        rows of every chunk ``rows[c] = (begin, end)`` from its all-gathered colour blocks ``blocks_all[c]`` [world, 3 rows
+        + 4], Adam on the geometry segments from ``params.grad`` (all-reduced), the next view's colours from the updated
+        rows while they are on chip, and its K1 into ``prefetch.front``.  Bit-identical to ``step_sh_gathered`` per chunk
+        followed by ``step_geom_and_project_next``."""
+        lib = _lib.load()
+        s = self._spec()
+        n = len(rows)
+        begins = (C.c_int32 * (n + 1))(*([r[0] for r in rows] + [rows[-1][1]]))
+        blks = (C.c_void_p * n)(*[b.data_ptr() for b in blocks_all])
+        ncs, fb, budget = prefetch.cam.c_struct(), prefetch.front, prefetch.front_budget
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.tgs_adam_sh_gathered_geom_project_next(
+            C.byref(ncs), world, self.p.N, self.p.K, sh_deg, ptr(self.p.flat), ptr(self.p.grad), n, begins, blks,
+            ptr(self.exp_avg), ptr(self.exp_avg_sq), C.byref(s), C.c_float(grad_scale), ptr(guard), ptr(prefetch.tag_word),
+            prefetch.tag, ptr(fb.splats), ptr(fb.radii), ptr(fb.group_base), ptr(fb.tile_cursor), fb.cap, ptr(fb.scratch),
+            ptr(fb.status), ptr(budget.sticky_word(self.p.flat.device)), int(fb.cleared), stream),
+              "tgs_adam_sh_gathered_geom_project_next")
+        prefetch.front_issued = True
+
     def step(self, grad_scale: float = 1.0, guard=None):
         self.begin_step()
         self.step_range(0, -1, grad_scale, guard)

@@ -381,6 +381,18 @@ class GradSync:
         comp.wait_event(reduced)
         step_geom(0, geom_grad.numel(), scale)
 
+    def fused_tail(self) -> bool:
+        """Run the tail of a data-parallel step (SH Adam of every chunk + geometry Adam + the next view's K1) as ONE launch
+        behind the geometry all-reduce (optim.step_sh_gathered_geom_and_project_next) instead of chunk by chunk?
+        ``TGS_DP_FUSED_TAIL`` = 1 / 0 forces it; default (auto): only for a one-rank group, where no transfer exists for
+        the chunked SH Adam to hide under -- measured with 1, 2 and 4 ranks on one GPU (profiles/r6_dp_fused_tail.json:
+        the fused launch saves launches and one pass over the SH rows, but every rank then waits for the whole exchange
+        before it touches the SH rows)."""
+        mode = os.environ.get("TGS_DP_FUSED_TAIL", "auto")
+        if mode in ("0", "1"):
+            return mode == "1"
+        return self.world == 1
+
     def color_chunk_rows(self, N: int, align: int = 256):
         """Row ranges [begin, end) of the pipelined exchange: at most ``color_chunks`` ranges covering [0, N),
         every boundary a multiple of ``align`` (K8's workgroup / the binning group: 256 rows)."""
