@@ -291,7 +291,7 @@ def train_quality_run(full: bool = False):
     import tempfile
     from touch_gs_amd import analytic_scene as A
     root = tempfile.mkdtemp(prefix="tq_")
-    keys = ("psnr", "ssim", "depth_mse", "gt_depth_mse", "gt_object_depth_mse", "exact_depth_mse", "exact_object_depth_mse",
+    keys = ("psnr", "ssim", "depth_mse", "gt_depth_mse", "gt_object_depth_mse", "gt_depth_mse_true_object_mask", "exact_depth_mse", "exact_object_depth_mse",
             "exact_object_depth_median_abs_m", "gaussian_count", "iters", "split", "train_wall_s", "iters_per_s_wall")
     if full:
         t0 = time.perf_counter()

@@ -18,7 +18,7 @@ def test_pipeline_reaches_usable_quality_and_touch_supervision_improves_depth(tm
     from touch_gs_amd import analytic_scene as A
     r = A.quick_quality(str(tmp_path / "capture"), n_views=24, W=640, iters=4000)
     print(json.dumps({k: ({m: v[m] for m in ("psnr", "ssim", "depth_mse", "gt_depth_mse", "gt_object_depth_mse",
-                                               "exact_depth_mse", "exact_object_depth_mse", "gaussian_count", "train_wall_s")
+                                               "exact_depth_mse", "exact_object_depth_mse", "gt_depth_mse_true_object_mask", "gaussian_count", "train_wall_s")
                            if m in v}) for k, v in r["runs"].items()}), r["capture_s"], r["prepare_s"], r["total_s"])
     # the touch maps cover a good part of the object and follow the analytic surface
     assert r["capture"]["gpis_object_cover"] > 0.3 and r["capture"]["gpis_rmse_m"] < 0.03
@@ -31,5 +31,10 @@ def test_pipeline_reaches_usable_quality_and_touch_supervision_improves_depth(tm
     # maps (depth_mse, experiment_utils/get_results.py:41), the depth sensor (gt_depth_mse, :47) and the exact geometry
     assert few["depth_mse"] < 0.75 * few_rgb["depth_mse"], (few, few_rgb)
     assert few["gt_depth_mse"] < 0.75 * few_rgb["gt_depth_mse"], (few, few_rgb)
-    assert few["exact_object_depth_mse"] < few_rgb["exact_object_depth_mse"], (few, few_rgb)
+    # ... and ON THE OBJECT (true silhouette, exact geometry), by a stated margin: the touch term more than halves the
+    # object's depth error of the RGB-only run (measured 0.0127 against 0.0395, profiles/r6_c_bench_cfg3.json; 0.6 x asserted)
+    # -- the scene-level ratios above are dominated by the table
+    assert few["exact_object_depth_mse"] < 0.6 * few_rgb["exact_object_depth_mse"], (few, few_rgb)
+    if "gt_depth_mse_true_object_mask" in few:      # the depth sensor's reading over the same true silhouette
+        assert few["gt_depth_mse_true_object_mask"] < 0.75 * few_rgb["gt_depth_mse_true_object_mask"], (few, few_rgb)
     assert few["psnr"] >= few_rgb["psnr"] - 0.5
