@@ -159,7 +159,7 @@ def traffic_in_run(kernel_key, timeout_s=240):
         d = tempfile.mkdtemp(prefix="tgs_pmc_", dir="/tmp")
         try:
             subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, tool, "3", "separate"],
-                           cwd="/tmp", env=env, capture_output=True, timeout=timeout_s, check=True)
+                           cwd=ROOT, env=env, capture_output=True, timeout=timeout_s, check=True)
             acc = []
             for f in glob.glob(d + "/*/*counter_collection.csv"):
                 for r in csv.DictReader(open(f)):

@@ -1,6 +1,6 @@
 """Developer tool: a few full train steps on cfg3 (fused or separate Adam) for rocprofv3 passes."""
-import sys, torch
-sys.path.insert(0, '.')
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from touch_gs_amd import ops
 from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
 from touch_gs_amd.optim import GaussianParams
