@@ -215,10 +215,10 @@ int tgs_project_bin_sort_colors(const TgsCamera* cam /*[host]*/, int N, const fl
  * the setters; the setters exist for A/B runs and tests and are process-wide by definition. */
 typedef struct TgsRasterOpts {
   int32_t k6_blocks;         /* 1 / 0: forward in 4x4-block / quadrant form (bit-identical images)      [TGS_K6_BLOCKS, 1] */
-  int32_t k6_split;          /* tile_is_split factor of the forward, 0 = never (tgs_set_k6_split)        [TGS_K6_SPLIT, 4]  */
+  int32_t k6_split;          /* tile_is_split factor of the forward, 0 = never (tgs_set_k6_split)        [TGS_K6_SPLIT, 2]  */
   int32_t k7_front_to_back;  /* 1: backward in the front-to-back form of TGS_VERSION 100                 [TGS_K7_F2B, 0]    */
   int32_t k7_quad;           /* chain-bound factor of the backward, 0 = one wave per tile (tgs_set_k7_quad) [TGS_K7_QUAD, 8] */
-  int32_t k7_quad_min_walk;  /* walks up to this many entries stay with the one-wave kernel              [TGS_K7_QUAD_MIN, 48] */
+  int32_t k7_quad_min_walk;  /* walks up to this many entries stay with the one-wave kernel              [TGS_K7_QUAD_MIN, 16] */
   int32_t k7_blocks;         /* 1: backward in 4x4-block form (TGS_VERSION 310; measured, not the default) [TGS_K7_BLOCKS, 0] */
 } TgsRasterOpts;
 
@@ -267,13 +267,13 @@ int tgs_set_raster_variant(int k6_blocks_on, int k7_front_to_back);
  * of all walks behind tile_start.  A frame is chain-bound if the deepest walk exceeds factor / 2 times the sum spread
  * evenly over K7's 4096 wave slots.  Defaults: factor 8 (object-centric scenes of 100 - 300 k Gaussians at 720p qualify:
  * K7 0.58 - 0.78 of its one-wave time; a uniform scene such as configs[2] or 1 M clustered Gaussians at 1080p do not),
- * min_walk 48; environment TGS_K7_QUAD / TGS_K7_QUAD_MIN.  factor 0 = always one wave per tile; a negative argument
+ * min_walk 16 (48 until TGS_VERSION 310); environment TGS_K7_QUAD / TGS_K7_QUAD_MIN.  factor 0 = always one wave per tile; a negative argument
  * leaves that setting.  Returns factor | min_walk << 8 in effect.  Results of the two forms differ by the rounding
  * of one four-term sum per (tile, Gaussian). */
 int tgs_set_k7_quad(int factor, int min_walk);
 
 /* The forward's counterpart for tiles with LONG lists: a tile whose list is longer than max(256, factor * I / 4096) --
- * factor (default 4, environment TGS_K6_SPLIT) times the per-slot load of an even spread -- among the first 512 entries
+ * factor (default 2 -- 4 until TGS_VERSION 310 --, environment TGS_K6_SPLIT) times the per-slot load of an even spread -- among the first 512 entries
  * of the tile_order schedule is composited by FOUR blocks of the same launch, one 8x8 quadrant each (pixels are
  * independent: nothing to exchange; same images, final_T and stop positions bit for bit).  Block-form forward with a
  * tile_order only.  factor 0 = never; negative leaves it.  Returns the factor in effect. */

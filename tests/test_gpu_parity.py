@@ -201,11 +201,11 @@ def test_rasterize_bwd(dev, N, W, H, deg, seed, clamp, quad, request):
         assert np.median(relerr(got[k].numpy(), ref[k].numpy(), floor=1e-3 * scale)) < 3e-5, k
 
 
-@pytest.mark.parametrize("rule", [(8, 48), (1, 8)])
+@pytest.mark.parametrize("rule", [(8, 16), (1, 8)])
 def test_k7_quad_form_on_an_object_centric_scene(dev, rule):
     """An object-centric scene (80 % of the Gaussians in the central tenth of the image) is chain-bound: a few tiles walk
     hundreds of entries while the frame's balanced load is a few dozen per wave slot.  K7 then gives every tile that walks
-    more than min_walk entries to k_raster_bwd_quad (default rule (8, 48); (1, 8): almost every tile).  Against one wave per tile: the same tile losses bit for
+    more than min_walk entries to k_raster_bwd_quad (default rule (8, 16); (1, 8): almost every tile).  Against one wave per tile: the same tile losses bit for
     bit (k_raster_bwd computes them for every tile), every (tile, Gaussian) partial record within rounding of the
     record's own magnitude -- the quadrant totals are added in a different order, nothing else differs -- with the fused
     loss of the train step (L1 + tactile depth / uncertainty) and with plain upstream gradients; poisoned partial

@@ -512,7 +512,7 @@ __device__ __forceinline__ void raster_fwd_quadrant(
   }
 }
 
-// Which tiles the forward splits into quadrant blocks: lists longer than max(256, factor x I / 4096) -- factor (default 4)
+// Which tiles the forward splits into quadrant blocks: lists longer than max(256, factor x I / 4096) -- factor (default 2)
 // times what a wave slot would hold if the frame's I intersections were spread evenly -- among the first `heads` entries
 // of the schedule (longest lists first: extra blocks are only launched for those).  cfg3 never qualifies.
 struct SplitRule { int factor, n_slots, heads; };
@@ -1911,9 +1911,12 @@ static RasterDefault g_k6_blocks{"TGS_K6_BLOCKS", 1, true};
 static RasterDefault g_k7_f2b{"TGS_K7_F2B", 0, true};
 // TGS_K7_QUAD: frame_is_chain_bound()'s factor (default 8: deepest walk beyond 4x the balanced per-slot load); 0 = one wave per tile always
 static RasterDefault g_k7_quad{"TGS_K7_QUAD", 8, false};
-static RasterDefault g_k7_quad_min{"TGS_K7_QUAD_MIN", 48, false};
-// TGS_K6_SPLIT: tile_is_split()'s factor (default 4: lists beyond 4x the balanced per-slot load, and 256); 0 = never
-static RasterDefault g_k6_split{"TGS_K6_SPLIT", 4, false};
+// (round 6, same-box sweep on the saved 720p checkpoints, profiles/r6_ab_runs.txt: min_walk 48 -> 16: K7 263 -> 240 / 253 -> 232 us; flat below)
+static RasterDefault g_k7_quad_min{"TGS_K7_QUAD_MIN", 16, false};
+// TGS_K6_SPLIT: tile_is_split()'s factor (default 2: lists beyond 2x the balanced per-slot load, and 256); 0 = never.  Round 6 sweep
+// (profiles/r6_ab_runs.txt): 4 -> 2: K6 147 -> 108 / 134 -> 100 us on the 720p checkpoints, cfg3 unchanged (no tile qualifies),
+// 1 M clustered +1 %; factor 1 costs cfg3 9 %
+static RasterDefault g_k6_split{"TGS_K6_SPLIT", 2, false};
 // TGS_K7_BLOCKS: 1 = the backward in 4x4-block form (k_raster_bwd_blocks); default 0 (measured slower)
 static RasterDefault g_k7_blocks{"TGS_K7_BLOCKS", 0, true};
 static inline int opt_or(const TgsRasterOpts* o, int32_t TgsRasterOpts::*f, RasterDefault& d) {
@@ -1959,7 +1962,8 @@ extern "C" int tgs_rasterize_fwd(const TgsCamera* cam, const float* splats,
     SplitRule sr;
     sr.factor = tile_order ? opt_or(opts, &TgsRasterOpts::k6_split, g_k6_split) : 0;
     sr.n_slots = grid;
-    sr.heads = sr.factor > 0 ? min(grid, 512) : 0;
+    static const int env_heads = [] { const char* e = getenv("TGS_K6_HEADS"); return e ? atoi(e) : 512; }();
+    sr.heads = sr.factor > 0 ? min(grid, env_heads) : 0;
     const int blocks = grid + 3 * sr.heads;
     if (final_idx)
       hipLaunchKernelGGL(k_raster_fwd_blocks<true>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, k, T, splats,

@@ -417,13 +417,13 @@ def set_raster_variant(k6_blocks: Optional[bool] = None, k7_front_to_back: Optio
 
 def set_k6_split(factor: Optional[int] = None) -> int:
     """The forward splits tiles whose list exceeds max(256, factor x the balanced per-slot load) into four quadrant blocks
-    of the same launch (tgs_set_k6_split; default 4, 0 = never, None = query).  Bit-identical outputs."""
+    of the same launch (tgs_set_k6_split; default 2, 0 = never, None = query).  Bit-identical outputs."""
     return _lib.load().tgs_set_k6_split(-1 if factor is None else int(factor))
 
 
 def set_k7_quad(factor: Optional[int] = None, min_walk: Optional[int] = None):
     """K7's four-waves-per-tile form for the tiles of chain-bound frames (deepest walk > factor / 2 x the balanced
-    per-slot load; tgs_set_k7_quad; defaults factor 8, min_walk 48; factor 0 = one wave per tile always; None leaves
+    per-slot load; tgs_set_k7_quad; defaults factor 8, min_walk 16; factor 0 = one wave per tile always; None leaves
     a setting).  Returns (factor, min_walk) in effect."""
     r = _lib.load().tgs_set_k7_quad(-1 if factor is None else int(factor), -1 if min_walk is None else int(min_walk))
     return r & 255, r >> 8
