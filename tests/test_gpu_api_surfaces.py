@@ -1019,6 +1019,60 @@ def test_fused_data_parallel_tail_is_bit_identical_to_the_chunked_one(dev, tmp_p
         assert torch.equal(a[k], b[k]), k
 
 
+_RESORT_WORKER = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from touch_gs_amd import parallel
+from touch_gs_amd.densify import DensifyConfig
+from touch_gs_amd.model import DepthGaussianSplattingModel, ModelConfig
+from touch_gs_amd.optim import GaussianParams
+from touch_gs_amd.scene import make_view, synthetic_gaussians
+dp = parallel.init_from_env()
+dev = torch.device("cuda", dp.local_rank)
+N, W, H, deg = 12_000, 320, 208, 3
+P, _ = synthetic_gaussians(N, W, H, deg, 23)
+P["log_scales"][::40] += 2.5          # a few hundred Gaussians that cover > 32 tiles: the re-sort deals them over the groups
+params = GaussianParams.from_tensors(*[P[k].to(dev) for k in GaussianParams.NAMES])
+m = DepthGaussianSplattingModel(ModelConfig(sh_degree=deg, sh_degree_interval=0, spatial_sort=True, resort_every_refines=1), params)
+m.spatial_sort()
+m.enable_densification(DensifyConfig(warmup_length=4, refine_every=4, reset_alpha_every=0, densify_grad_thresh=1e-7))
+views = [make_view(N, W, H, deg, 23, dev, view=v, n_views=6) for v in range(6)]
+for v in views: v.valid_count()
+sorts = []
+orig = m.spatial_sort
+def counted():
+    perm = orig()
+    sorts.append(int((perm != torch.sort(perm).values).sum()))
+    return perm
+m.spatial_sort = counted
+for i in range(13):
+    m.train_step(views[dp.views_for_step(i, 6)], dp, next_view=views[dp.views_for_step(i + 1, 6)])
+torch.cuda.synchronize()
+dp.assert_replicas_identical(m.params.flat)
+assert len(sorts) >= 2 and len(m._recent_cams) >= 2, (sorts, len(m._recent_cams))
+dp.barrier()
+import torch.distributed as dist
+dist.destroy_process_group()
+print("RESORT_OK", m.params.N, sorts)
+'''
+
+
+def test_balanced_resort_keeps_the_replicas_identical(dev, tmp_path):
+    """The re-sort deals the long-run Gaussians over the binning groups from the tile counts of the cameras of the last
+    steps (optim.balanced_order) -- and under data parallelism every rank has seen different cameras: the counts are summed
+    over the ranks, so every replica computes the same permutation.  Two ranks share the GPU over gloo, refinement every 4
+    steps with a full re-sort after each: the replicas stay bit-identical (they would not with per-rank counts)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "resort_worker.py"
+    script.write_text(_RESORT_WORKER)
+    env = dict(os.environ, TGS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", free_port(), str(script), root], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "RESORT_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_bench_two_gpus_rccl(dev, tmp_path):
     """First multi-GPU evidence wherever >= 2 GPUs are visible: bench.py --gpus 2 through
     torch.distributed.run over RCCL; the JSON line carries the exchange's bus bandwidth and the

@@ -342,7 +342,19 @@ class DepthGaussianSplattingModel:
                 sp = ops.project_fwd(cam, p.means, p.log_scales, p.quats, p.opac_logit, None, -1)
                 rect = sp[:, 10].contiguous().view(torch.int32)
                 hits = hits + ((rect >> 16) & 255) * ((rect >> 24) & 255)
-            hits = (hits + len(cams) - 1) // len(cams)        # mean tiles per view (rounded up)
+            dp = getattr(self, "_dp", None)
+            if dp is not None and dp.active:
+                # data parallel: every rank has seen ITS views only, and the replicas must agree on the row order -- sum the
+                # counts over the ranks (the same collective on every rank: re-sorts happen at refinements, which are
+                # barrier points) and divide by the rank-independent total
+                import torch.distributed as dist
+                n_cams = torch.tensor([len(cams)], dtype=torch.int64, device=hits.device)
+                hits = hits.to(torch.int64)
+                dist.all_reduce(hits, op=dist.ReduceOp.SUM)
+                dist.all_reduce(n_cams, op=dist.ReduceOp.SUM)
+                hits = (hits + int(n_cams) - 1) // int(n_cams)
+            else:
+                hits = (hits + len(cams) - 1) // len(cams)    # mean tiles per view (rounded up)
         perm = balanced_order(self.params.means, hits)
         self.params.permute_(perm, self.optimizer.exp_avg, self.optimizer.exp_avg_sq)
         density = getattr(self, "density", None)
