@@ -433,7 +433,7 @@ __device__ __forceinline__ void xcd_order_regs(int T, int x, int c, int chunk,
 __global__ __launch_bounds__(TGS_WAVE) void k_sort_tiles_wave(
     int T, const int32_t* __restrict__ tile_start, const u64* __restrict__ pairs,
     int32_t* __restrict__ sorted_gid, int32_t* __restrict__ tile_order, int n_order, int chunk,
-    int sorted_up_to, int32_t* __restrict__ status, int32_t* __restrict__ sticky) {
+    int sorted_up_to, int32_t* __restrict__ status, int32_t* __restrict__ sticky, int wave_up_to) {
   // the first n_order (0 or 8 x chunks per XCD) blocks build the K6 / K7 schedule of one chunk of one
   // XCD's slots each; they are the longest blocks of the launch, so they are dispatched first
   if ((int)blockIdx.x < n_order) {
@@ -452,7 +452,10 @@ __global__ __launch_bounds__(TGS_WAVE) void k_sort_tiles_wave(
     }
     return;
   }
-  if (n <= 0 || n > 1024) return;
+  // lists beyond wave_up_to (512 when the four-wave launch follows, else 1024) are that launch's: a 1024-key list costs one
+  // wave 864 stage x key units against 360 for 512 keys, and in an object-centric frame this launch lasts as long as its
+  // longest list (round 6: k_sort_tiles_wave 24.5 -> 13 us on the 720p checkpoints)
+  if (n <= 0 || n > wave_up_to) return;
   if (n == 1) {
     if (lane == 0) sorted_gid[s] = (int)(pairs[s] & 0xffffffffull);
     return;
@@ -477,14 +480,15 @@ __global__ __launch_bounds__(TGS_WAVE) void k_sort_tiles_wave(
 // (One merged 1024-thread launch was 26 us slower on the clustered scene: one workgroup per CU.)
 __global__ __launch_bounds__(TGS_WAVE * 4) void k_sort_tiles_wg4(
     int T, const int32_t* __restrict__ tile_start, const u64* __restrict__ pairs,
-    int32_t* __restrict__ sorted_gid, const int32_t* __restrict__ max_list) {
+    int32_t* __restrict__ sorted_gid, const int32_t* __restrict__ max_list, int lo) {
   __shared__ u64 wg_keys[TGS_WAVE * 4 * 16];   // 16 keys x 256 threads
-  if (*max_list <= 1024) return;
+  if (*max_list <= lo) return;
   for (int tile = blockIdx.x; tile < T; tile += gridDim.x) {
     const int s = tile_start[tile];
     const int n = tile_start[tile + 1] - s;
-    if (n <= 1024 || n > 4096) continue;
+    if (n <= lo || n > 4096) continue;
     __syncthreads();
+    if (n <= 1024) { sort_tile_regs<4, 4>(pairs, sorted_gid, s, n, threadIdx.x, wg_keys); continue; }
     // (1024, 2048]: 8 keys per lane -- half the network per thread; in an object-centric frame this launch lasts as long
     // as one tile's sort (a few hundred long lists, every workgroup resident at once)
     if (n <= 2048) sort_tile_regs<8, 4>(pairs, sorted_gid, s, n, threadIdx.x, wg_keys);
@@ -599,12 +603,13 @@ int tgs_bin_finish(const CamK& k, int N, const float* splats, const int32_t* gro
     const bool want_wg4 = max_list_hint < 0 || max_list_hint > 1024;
     const bool want_huge = max_list_hint < 0 || max_list_hint > 4096;
     const int sorted_up_to = want_huge ? 0x7fffffff : (want_wg4 ? 4096 : 1024);
+    const int wave_up_to = want_wg4 ? 512 : 1024;
     hipLaunchKernelGGL(k_sort_tiles_wave, dim3(T + n_order), dim3(TGS_WAVE), 0, s, T, tile_start,
-                       sc.pairs, sorted_gid, tile_order, n_order, chunk, sorted_up_to, status, sticky_overflow);
+                       sc.pairs, sorted_gid, tile_order, n_order, chunk, sorted_up_to, status, sticky_overflow, wave_up_to);
     TGS_CHECK_LAUNCH();
     if (want_wg4) {
       hipLaunchKernelGGL(k_sort_tiles_wg4, dim3(T < 2048 ? T : 2048), dim3(TGS_WAVE * 4), 0, s, T, tile_start,
-                         sc.pairs, sorted_gid, max_list);
+                         sc.pairs, sorted_gid, max_list, wave_up_to);
       TGS_CHECK_LAUNCH();
     }
     if (want_huge) {
