@@ -405,24 +405,34 @@ __device__ __forceinline__ void sort_tile_regs(const u64* __restrict__ pairs, in
 // list-length order, ties by tile id, by one wave -- the same register sort on (~length, tile) keys.
 // The XCD therefore visits chunk 0 longest first, then chunk 1, ...: the tail of the launch is made
 // of the last chunk's shortest lists.
+template <int E>
+__device__ __forceinline__ void xcd_order_regs_e(int T, int x, int i0, int len, const int32_t* __restrict__ tile_start,
+                                                 int32_t* __restrict__ tile_order, int lane) {
+  u64 k[E];
+#pragma unroll
+  for (int r = 0; r < E; r++) {
+    const int i = r * TGS_WAVE + lane;
+    const int tile = i < len ? tgs_xcd_slot_tile(T, x, i0 + i) : T;
+    k[r] = tile < T ? ((u64)(~(unsigned)(tile_start[tile + 1] - tile_start[tile])) << 32) | (unsigned)tile : ~0ull;
+  }
+  sort_regs<E, 1>(k, lane, nullptr);
+#pragma unroll
+  for (int r = 0; r < E; r++) {
+    const int e = lane * E + r;
+    if (e < len) tile_order[(i0 + e) * TGS_XCDS + x] = k[r] != ~0ull ? (int)(k[r] & 0xffffffffull) : T;   // T = no tile
+  }
+}
 __device__ __forceinline__ void xcd_order_regs(int T, int x, int c, int chunk,
                                                const int32_t* __restrict__ tile_start,
                                                int32_t* __restrict__ tile_order, int lane) {
   const int per = tgs_xcd_slots(T);
   const int i0 = c * chunk, len = max(0, min(chunk, per - i0));
-  u64 k[16];
-#pragma unroll
-  for (int r = 0; r < 16; r++) {
-    const int i = r * TGS_WAVE + lane;
-    const int tile = i < len ? tgs_xcd_slot_tile(T, x, i0 + i) : T;
-    k[r] = tile < T ? ((u64)(~(unsigned)(tile_start[tile + 1] - tile_start[tile])) << 32) | (unsigned)tile : ~0ull;
-  }
-  sort_regs<16, 1>(k, lane, nullptr);
-#pragma unroll
-  for (int r = 0; r < 16; r++) {
-    const int e = lane * 16 + r;
-    if (e < len) tile_order[(i0 + e) * TGS_XCDS + x] = k[r] != ~0ull ? (int)(k[r] & 0xffffffffull) : T;   // T = no tile
-  }
+  // keys per lane by chunk length, like the list classes: a 720p frame has 450 slots per XCD (8 keys per lane: 360 stage x key
+  // units instead of 864) -- these blocks are the longest of the wave-sort launch when the lists are short (round 6)
+  if (len <= 128) xcd_order_regs_e<2>(T, x, i0, len, tile_start, tile_order, lane);
+  else if (len <= 256) xcd_order_regs_e<4>(T, x, i0, len, tile_start, tile_order, lane);
+  else if (len <= 512) xcd_order_regs_e<8>(T, x, i0, len, tile_start, tile_order, lane);
+  else xcd_order_regs_e<16>(T, x, i0, len, tile_start, tile_order, lane);
 }
 
 // common classes: lists <= 64 / 128 / 256 / 512 / 1024 entries with 1 / 2 / 4 / 8 / 16 keys per lane; one wave per tile
