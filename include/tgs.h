@@ -272,6 +272,13 @@ int tgs_set_raster_variant(int k6_blocks_on, int k7_front_to_back);
  * of one four-term sum per (tile, Gaussian). */
 int tgs_set_k7_quad(int factor, int min_walk);
 
+/* The LONGEST tiles of a chain-bound frame (TGS_VERSION 310): the four-wave launch lasts as long as its deepest tile.  Tiles
+ * that walk more than min_walk entries, among the first `heads` entries of the tile_order schedule (longest lists first), are
+ * composited by tgs_rasterize_bwd's scan form instead -- the batch's 64 entries in the lanes of a wave, transmittance and the
+ * sum behind as DPP prefix scans, 16 waves per tile.  min_walk 0 = off; negative arguments leave a setting.  Environment
+ * TGS_K7_SCAN_MIN / TGS_K7_SCAN_HEADS.  Returns min_walk | heads << 16.  Same decisions; sums in scan order (rounding only). */
+int tgs_set_k7_scan(int min_walk, int heads);
+
 /* The forward's counterpart for tiles with LONG lists: a tile whose list is longer than max(256, factor * I / 4096) --
  * factor (default 2 -- 4 until TGS_VERSION 310 --, environment TGS_K6_SPLIT) times the per-slot load of an even spread -- among the first 512 entries
  * of the tile_order schedule is composited by FOUR blocks of the same launch, one 8x8 quadrant each (pixels are

@@ -379,6 +379,82 @@ def test_k7_quad_form_without_a_schedule_with_an_empty_first_tile_and_dirty_slot
         assert bad < 0.02 + 5 * (1 - frac_clear), (k, bad, frac_clear)
 
 
+def _records_in_list_order(cam, sp, gb, ts, sg, partials):
+    """K7's partial records gathered in (tile, list position) order.  A record's address is its pair index, and the pair
+    ranges of the binning groups are handed out in whatever order the workgroups arrive: two runs of the front half give
+    the same LISTS but different addresses."""
+    T = cam.num_tiles
+    n_t = (ts[1:T + 1] - ts[:T]).long()
+    tile = torch.repeat_interleave(torch.arange(T, device=sp.device), n_t)
+    spv = sp.view(-1, 12)
+    gid = sg[: int(ts[T])].long()
+    rect = spv[gid, 10].contiguous().view(torch.int32)
+    x0, y0, w_ = rect & 255, (rect >> 8) & 255, (rect >> 16) & 255
+    TW = cam.tiles[0]
+    P = gb.long()[gid // 256] + spv[gid, 11].contiguous().view(torch.int32).long() + (tile // TW - y0) * w_ + (tile % TW - x0)
+    assert P.unique().numel() == P.numel()
+    written = torch.zeros(partials.shape[0], dtype=torch.bool, device=sp.device)
+    written[P] = True
+    assert torch.equal(written, ~torch.isnan(partials[:, :10]).any(dim=1))      # exactly the listed pairs were written
+    return partials[P, :10]
+
+
+@pytest.mark.parametrize("scan_min", [64, 16])
+def test_k7_scan_form_on_the_longest_tiles(dev, scan_min):
+    """k_raster_bwd_scan (round 6): the longest tiles of a chain-bound frame with the batch's 64 ENTRIES in the lanes of a
+    wave -- transmittance and the sum behind as DPP prefix scans, each lane accumulating its own entry's sums, 16 waves per
+    tile -- beside the four-wave form for the rest.  Against one wave per tile on an object-centric scene, fused train-step
+    loss and plain upstream gradients: exactly the listed pairs' records written (NaN-poisoned buffers), equal up to
+    rounding of the record's own magnitude (records compared in list order: pair addresses differ between runs of the
+    front half), tile losses bit for bit; and the scan form did take tiles (the result differs from the four-wave-only run)."""
+    from touch_gs_amd import ops
+    from touch_gs_amd.scene import make_camera, synthetic_gaussians
+    N, W, H, deg = 60_000, 640, 400, 3
+    P, intr = synthetic_gaussians(N, W, H, deg, 5, clustered=True)
+    D = {k: v.to(dev).float().contiguous() for k, v in P.items()}
+    D["opac_logit"][::3] = 12.0                      # some opacities on the 0.999 clamp: both copies of the pixel loop run
+    cam = make_camera(intr, 1, 8, bg=(0.1, 0.2, 0.3))
+    g = torch.Generator().manual_seed(3)
+    gt = torch.rand(H, W, 3, generator=g).to(dev)
+    gd = (2 + 4 * torch.rand(H, W, generator=g)).to(dev)
+    gd[torch.rand(H, W, generator=g).to(dev) < 0.3] = 0.0
+    unc = (0.001 + 5 * torch.rand(H, W, generator=g)).to(dev)
+    loss = dict(gt_rgb=gt, l1_weight=0.8 / (3 * H * W), gt_depth=gd, depth_weight=0.2 / (H * W), uncertainty=unc,
+                uncertainty_weight=1.0, eps=1e-6)
+    v_rgb = torch.randn(H, W, 3, generator=g).to(dev)
+    v_d, v_a = torch.randn(H, W, generator=g).to(dev), torch.randn(H, W, generator=g).to(dev)
+    modes = {"loss": dict(v_rgb=v_rgb * 1e-6, loss=loss, want_tile_loss=True), "plain": dict(v_rgb=v_rgb, v_depth=v_d, v_alpha=v_a)}
+    before_q, before_s = ops.set_k7_quad(), ops.set_k7_scan()
+    out = {}
+    try:
+        for name, (f, mw, sm) in (("one", (0, 192, 0)), ("quad", (8, 16, 0)), ("scan", (8, 16, scan_min))):
+            ops.set_k7_quad(f, mw)
+            ops.set_k7_scan(sm, 512)
+            for mode, kw in modes.items():
+                # fresh lists + ONE forward per backward: the walk statistics the chain-bound rule reads accumulate
+                sp, radii, gb, ts, sg, st = ops.project_bin_sort(cam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], deg)
+                rgb, depth, fT, _ = ops.rasterize_fwd(cam, sp, sg, ts)
+                buf = torch.full((sg.shape[0], 12), float("nan"), device=dev)
+                partials, tl = ops.rasterize_bwd(cam, sp, gb, sg, ts, rgb, depth, fT, partials=buf, **kw)
+                out[name, mode] = (_records_in_list_order(cam, sp, gb, ts, sg, partials), None if tl is None else tl.clone())
+    finally:
+        ops.set_k7_quad(*before_q)
+        ops.set_k7_scan(*before_s)
+    for mode in modes:
+        a, ta = out["one", mode]
+        b, tb = out["scan", mode]
+        q, _ = out["quad", mode]
+        assert a.shape == b.shape == q.shape and not torch.isnan(b).any()
+        if ta is not None:
+            assert torch.equal(ta, tb)
+        assert not torch.equal(b, q)                                      # some tiles did take the scan form
+        mag = a.abs().amax(dim=1, keepdim=True).clamp(min=1e-30)
+        rel = ((a - b).abs() / mag).amax(dim=1)
+        q99 = float(torch.quantile(rel[::max(1, rel.numel() // 4_000_000)], 0.99))
+        print(f"k7 scan form vs one wave, {mode}: max {float(rel.max()):.2e}, q99 {q99:.2e}")
+        assert float(rel.max()) < 1e-3 and q99 < 2e-5, (float(rel.max()), q99)
+
+
 @pytest.mark.parametrize("N,W,H,deg,seed", [(1500, 128, 80, 3, 31), (400, 64, 48, 2, 32), (400, 64, 48, 0, 33)])
 def test_project_bwd(dev, N, W, H, deg, seed):
     from touch_gs_amd import ops

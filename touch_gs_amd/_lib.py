@@ -66,6 +66,7 @@ SIGNATURES = {
                                               _P, _P, C.c_int64, _P, _P, _P, C.c_int32, _P, _P, C.c_int32, _P]),
     "tgs_rasterize_fwd": (C.c_int, [C.POINTER(TgsCamera), _P, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, C.POINTER(TgsRasterOpts), _P]),
     "tgs_set_raster_variant": (C.c_int, [_I, _I]),
+    "tgs_set_k7_scan": (C.c_int, [_I, _I]),
     "tgs_set_k7_quad": (C.c_int, [_I, _I]),
     "tgs_set_k6_split": (C.c_int, [_I]),
     "tgs_slot_ok_len": (C.c_size_t, [_I, _I, C.c_int64]),

@@ -962,7 +962,7 @@ __global__ __launch_bounds__(64) void k_raster_bwd_f2b(
 // the four-wave form does 1.5x the work) and 1.4 - 1.6 on the uniform cfg3 (0.6 - 1.3).  The default factor 8 (ratio > 4)
 // takes the first two and leaves the others alone.  Both kernels evaluate the same predicate on the same words.
 // factor 0: never.
-struct QuadRule { int factor, min_walk; };
+struct QuadRule { int factor, min_walk, scan_min, scan_heads; };   // scan_min > 0: tiles of the schedule's first scan_heads slots that walk more than scan_min entries are k_raster_bwd_scan's
 __device__ __forceinline__ bool frame_is_chain_bound(const int32_t* __restrict__ tile_start, int T, QuadRule q) {
   if (q.factor <= 0) return false;
   int walk = 0;
@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(64) void k_raster_bwd(
   const int tmax = max(max(qlim[0], qlim[1]), max(qlim[2], qlim[3]));
   // in a chain-bound frame every tile with a walk worth splitting is k_raster_bwd_quad's (four waves); its losses were
   // written above
-  if (tmax > quad.min_walk && frame_is_chain_bound(tile_start, T_total, quad)) return;
+  if (tmax > quad.min_walk && frame_is_chain_bound(tile_start, T_total, quad)) return;   // (k_raster_bwd_quad's or k_raster_bwd_scan's)
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   // behind the last stop position nothing received a gradient
   for (int i = start + tmax + lane; i < end; i += 64) {
@@ -1698,6 +1698,7 @@ __global__ __launch_bounds__(256) void k_raster_bwd_quad(
   __syncthreads();
   const int tmax = max(max(s_qlim[0], s_qlim[1]), max(s_qlim[2], s_qlim[3]));
   if (tmax <= quad.min_walk) continue;   // k_raster_bwd's tile
+  if (quad.scan_min > 0 && slot < quad.scan_heads && tmax > quad.scan_min) continue;   // k_raster_bwd_scan's tile
 
   // per-pixel state, the arithmetic of k_raster_bwd's prologue for pixel slot k of the lane
   float T = 1.f, vCr = 0.f, vCg = 0.f, vCb = 0.f, vD = 0.f, SX = 0.f;
@@ -1884,6 +1885,250 @@ __global__ __launch_bounds__(256) void k_raster_bwd_quad(
   }   // slots
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// K7 for the LONGEST tiles of a chain-bound frame: entries in the lanes, a scan instead of a walk (round 6)
+// ---------------------------------------------------------------------------------------------
+// The four-wave launch lasts as long as its deepest tile: measured on the saved 720p checkpoints K7 = 110 us + 0.15 us x
+// the frame's deepest walk (tools/k7_tail_probe.py) -- a wave alone on its SIMD issues one instruction per ~5.75 cycles
+// and needs ~75 of them per (quadrant, entry), one entry after the other, because the entries of a pixel depend on each
+// other through T and the sum behind.  But that dependence is a SCAN: T in front of entry j = T behind the batch x
+// prod_{i >= j} 1 / (1 - alpha_i), the sum behind entry j = sum behind the batch + sum_{i > j} w_i c_i.v.  Here a
+// workgroup of 16 waves owns the tile, wave w its 4x4 block w; the 64 LANES of a wave hold the 64 entries of the batch
+// (lane 0 the deepest), and the wave goes through its 16 PIXELS one after the other: alpha of all 64 entries at once (the
+// forward's eval_s on the same bits: per-lane coefficients, uniform pixel constants), a 6-step DPP prefix product for T,
+// a 6-step prefix sum for the sum behind, then every lane adds ITS entry's ten sums into its own registers -- no
+// cross-lane reduction per entry at all.  Per batch the 16 waves' sums meet in LDS and lane j of wave 0 writes entry j's
+// partial record.  Per (pixel, batch of 64) ~60 instructions: ~1.5x the work of the four-wave form per contributing
+// evaluation (lanes = entries are filled 15 - 25 %), but a tile-entry costs ~100 cycles of chain instead of ~360.  So:
+// only the tiles that set the length of the launch (walk > scan_min among the schedule's first scan_heads slots), on a
+// second stream beside the four-wave launch.  Same decisions as the forward; sums in scan order: rounding only.
+#ifndef TGS_SCAN_SHFL
+#define TGS_SCAN_SHFL 0      // 1: the scans through __shfl_up (debug reference for the DPP form)
+#endif
+#if TGS_SCAN_SHFL
+__device__ __forceinline__ float scan_incl_add(float v) {
+  const int l = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o); if (l >= o) v += t; }
+  return v;
+}
+__device__ __forceinline__ float scan_incl_mul(float v) {
+  const int l = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o); if (l >= o) v *= t; }
+  return v;
+}
+__device__ __forceinline__ float lane_shr1_zero(float v) {
+  const float t = __shfl_up(v, 1);
+  return (threadIdx.x & 63) ? t : 0.f;
+}
+#else
+__device__ __forceinline__ float scan_incl_add(float v) {
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v));
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(v));
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v));
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(v));
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+  return v;
+}
+__device__ __forceinline__ float scan_incl_mul(float v) {
+  asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v));
+  asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(v));
+  asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v));
+  asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(v));
+  asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+  asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+  return v;
+}
+__device__ __forceinline__ float lane_shr1_zero(float v) {     // value of lane - 1, 0 in lane 0
+  float t;
+  asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(t) : "v"(v));
+  return t;
+}
+#endif
+__device__ __forceinline__ float rdlane(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+__global__ __launch_bounds__(1024) void k_raster_bwd_scan(
+    CamK cam, int T_total, const float* __restrict__ splats, const int32_t* __restrict__ group_base,
+    const int32_t* __restrict__ sorted_gid, const int32_t* __restrict__ tile_start,
+    const float* __restrict__ out_rgb, const float* __restrict__ out_depth,
+    const float* __restrict__ final_T, const int32_t* __restrict__ stop_pos, const float* __restrict__ v_rgb,
+    const float* __restrict__ v_depth, const float* __restrict__ v_alpha, LossK loss,
+    float* __restrict__ partials, const int32_t* __restrict__ tile_order, QuadRule quad) {
+  if (!frame_is_chain_bound(tile_start, T_total, quad)) return;
+  const int slot = blockIdx.x;
+  const int tile = tile_order ? tile_order[slot] : xcd_tile(slot, T_total);
+  if (tile >= T_total) return;
+  const int start = tile_start[tile], end = tile_start[tile + 1];
+  const int n = end - start;
+  if (n <= quad.scan_min) return;                     // (walk <= list length)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int ty = tile / cam.TW, tx = tile - ty * cam.TW;
+  const int bx = w & 3, by = w >> 2;                  // this wave's 4x4 block
+  // per-pixel state in lanes 0..15 (pixel p = lane: (4 bx + (p & 3), 4 by + (p >> 2)) of the tile)
+  float T = 1.f, vCr = 0.f, vCg = 0.f, vCb = 0.f, vD = 0.f, SX = 0.f;
+  int lim = 0;
+  {
+    const int p = lane & 15;
+    const int px = tx * TGS_BLOCK + 4 * bx + (p & 3), py = ty * TGS_BLOCK + 4 * by + (p >> 2);
+    if (lane < 16 && px < cam.W && py < cam.H) {
+      const size_t pi = (size_t)py * cam.W + px;
+      const float Tf = final_T[pi];
+      T = Tf;
+      lim = min(stop_pos[pi], n);
+      float vA = v_alpha ? v_alpha[pi] : 0.f;
+      if (v_rgb) { vCr = v_rgb[3 * pi]; vCg = v_rgb[3 * pi + 1]; vCb = v_rgb[3 * pi + 2]; }
+      if (v_depth) vD = v_depth[pi];
+      if (loss.on) {
+        if (loss.gt_rgb) {
+          const float d0 = out_rgb[3 * pi] - loss.gt_rgb[3 * pi];
+          const float d1 = out_rgb[3 * pi + 1] - loss.gt_rgb[3 * pi + 1];
+          const float d2 = out_rgb[3 * pi + 2] - loss.gt_rgb[3 * pi + 2];
+          vCr += loss.l1w * ((d0 > 0.f) - (d0 < 0.f));
+          vCg += loss.l1w * ((d1 > 0.f) - (d1 < 0.f));
+          vCb += loss.l1w * ((d2 > 0.f) - (d2 < 0.f));
+        }
+        if (loss.gt_depth) {
+          const float gd = loss.gt_depth[pi];
+          if (gd > 0.f) {
+            const float alpha = fmaxf(1.f - Tf, 1e-10f);
+            const float ia = 1.0f / alpha;
+            const float dhat = out_depth[pi] * ia;
+            const float r = dhat - gd;
+            float wgt = loss.dw;
+            if (loss.unc) wgt = wgt / (loss.uw * loss.unc[pi] + loss.eps);
+            const float gdh = 2.f * wgt * r;
+            vD += gdh * ia;
+            if (1.f - Tf > 1e-10f) vA += -gdh * dhat * ia;
+          }
+        }
+      }
+      const float bgdot = cam.bg[0] * vCr + cam.bg[1] * vCg + cam.bg[2] * vCb;
+      SX = -Tf * (vA - bgdot);
+    }
+  }
+  __shared__ int s_blim[16];
+  __shared__ float acc[16 * 64 * 10];
+  const int blim = wave_minmax_i<true>(lim);          // how far into the list this block's pixels reach
+  if (lane == 0) s_blim[w] = blim;
+  __syncthreads();
+  int tmax = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) tmax = max(tmax, s_blim[i]);
+  if (tmax <= quad.scan_min) return;                  // the four-wave launch's tile (same predicate there)
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = start + tmax + tid; i < end; i += 1024) {   // behind the last stop position nothing received a gradient
+    const int gid = sorted_gid[i];
+    const size_t P = pair_index(group_base, gid, ld4(splats + (size_t)gid * TGS_SPLAT_FLOATS + 8), tx, ty);
+    float* o = partials + P * TGS_PARTIAL_FLOATS;
+    st4(o, z4); st4(o + 4, z4); st4(o + 8, z4);
+  }
+  const int blk = 4 * by + bx;
+  const float ub = (float)(4 * bx) - 7.5f, vb0 = (float)(4 * by) - 7.5f;
+  for (int base = start + ((tmax - 1) & ~63); base >= start; base -= 64) {
+    const int rel = base - start;
+    const int cnt = min(64, tmax - rel);
+    // lane l <-> entry e = cnt - 1 - l of the batch: lane 0 is the DEEPEST entry, so back to front = increasing lane
+    const int e = cnt - 1 - lane;
+    const bool valid = lane < cnt;
+    const int pos = rel + e;
+    float c0 = 3.0e38f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f, c5 = 0.f, dep = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+    float gx = 0.f, gy = 0.f, opac = 1.f;
+    float4 a1 = z4;
+    size_t P = 0;
+    bool touch = false;
+    if (valid) {
+      const int gid = sorted_gid[base + e];
+      const float* r = splats + (size_t)gid * TGS_SPLAT_FLOATS;
+      float4 a0 = ld4(r);
+      a1 = ld4(r + 4);
+      const float4 a2 = ld4(r + 8);
+      centre_rel(a0, a2, tx, ty, cam.pix_center, gx, gy);
+      const unsigned mask = block_mask16(gx, gy, a1.x, a1.y, a1.z, -__log2f(a0.w));
+      opac = a0.w;
+      const TileRec t = make_tile_rec<false>(a0, a1, a2, gx, gy);
+      c0 = t.a.x; c1 = t.a.y; c2 = t.a.z; c3 = t.a.w; c4 = t.b.x; c5 = t.b.y; dep = t.b.z; cr = t.b.w; cg = t.c.x; cb = t.c.y;
+      touch = ((mask >> blk) & 1u) && pos < blim;
+      if (w == 0) P = pair_index(group_base, gid, a2, tx, ty);
+    }
+    const bool clampy = __ballot(valid && opac > CLAMP_FREE_OPACITY) != 0ull;
+    float a[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) a[i] = 0.f;
+#ifndef TGS_SCAN_DBG
+#define TGS_SCAN_DBG 0
+#endif
+    if ((TGS_SCAN_DBG & 1) || __ballot(touch) != 0ull) {
+      auto pixels = [&](auto mayclamp) {
+        constexpr bool MAYCLAMP = decltype(mayclamp)::value;
+#pragma unroll 1
+        for (int p = 0; p < 16; p++) {
+          const int limp = __builtin_amdgcn_readlane(lim, p);
+          if (!(TGS_SCAN_DBG & 2) && limp <= rel) continue;   // the pixel stopped in front of this batch
+          const float Tb = rdlane(T, p), SXb = rdlane(SX, p);
+          const float vr = rdlane(vCr, p), vg = rdlane(vCg, p), vbb = rdlane(vCb, p), vd = rdlane(vD, p);
+          const float u = ub + (float)(p & 3), v = vb0 + (float)(p >> 2);
+          const float uu = u * u, vv = v * v, uv = u * v;
+          float s = fmaf(c1, u, c0);                       // eval_s: the forward's arithmetic, operand for operand
+          s = fmaf(c2, v, s); s = fmaf(c3, uu, s); s = fmaf(c4, uv, s); s = fmaf(c5, vv, s);
+          const float ex = __builtin_amdgcn_exp2f(-s);
+          const float al0 = MAYCLAMP ? fminf(ALPHA_MAX, ex) : ex;
+          const bool go = valid & (s <= LOG2_255) & (pos < limp);
+          const float al = go ? al0 : 0.f;
+          const float ra = __builtin_amdgcn_rcpf(1.0f - al);        // = 1 exactly when al == 0
+          const float Pm = scan_incl_mul(ra);              // product over this entry and everything behind it in the batch
+          const float Tp = Tb * Pm;                        // transmittance in front of this entry
+          const float wgt = al * Tp;
+          float cv = cr * vr;
+          cv = fmaf(cg, vg, cv); cv = fmaf(cb, vbb, cv); cv = fmaf(dep, vd, cv);
+          const float z = wgt * cv;
+          const float Zi = scan_incl_add(z);
+          const float SXj = SXb + lane_shr1_zero(Zi);      // sum behind this entry
+          float q = fmaf(-(al * ra), SXj, z);
+          if constexpr (MAYCLAMP) q *= fmaxf(ex * (1.0f / ALPHA_MAX), 1.0f);
+          a[0] = fmaf(wgt, vr, a[0]); a[1] = fmaf(wgt, vg, a[1]); a[2] = fmaf(wgt, vbb, a[2]); a[3] = fmaf(wgt, vd, a[3]);
+          a[4] += q; a[5] = fmaf(q, u, a[5]); a[6] = fmaf(q, v, a[6]);
+          a[7] = fmaf(q, uu, a[7]); a[8] = fmaf(q, uv, a[8]); a[9] = fmaf(q, vv, a[9]);
+          // the pixel's state in front of the batch (lanes >= cnt hold ra = 1, z = 0: lane 63 has the batch's totals)
+          const bool mine = lane == p;
+          T = mine ? Tb * rdlane(Pm, 63) : T;
+          SX = mine ? SXb + rdlane(Zi, 63) : SX;
+        }
+      };
+      if (clampy) pixels(std::true_type{}); else pixels(std::false_type{});
+    }
+    float* my = acc + (w * 64 + lane) * 10;
+#pragma unroll
+    for (int i = 0; i < 10; i++) my[i] = a[i];
+    __syncthreads();
+    if (w == 0 && valid) {
+      float t[10];
+#pragma unroll
+      for (int i = 0; i < 10; i++) t[i] = 0.f;
+      for (int ww = 0; ww < 16; ww++) {                  // the 16 blocks' sums in block order
+        const float* o = acc + (ww * 64 + lane) * 10;
+#pragma unroll
+        for (int i = 0; i < 10; i++) t[i] += o[i];
+      }
+      const float A = a1.x, B = a1.y, Cc = a1.z;
+      const float Q0 = t[4], Qu = t[5], Qv = t[6], Quu = t[7], Quv = t[8], Qvv = t[9];
+      const float Mx = -(gx * Q0 - Qu), My = -(gy * Q0 - Qv);
+      const float Mxx = -(gx * gx * Q0 - 2.f * gx * Qu + Quu);
+      const float Mxy = -(gx * gy * Q0 - gx * Qv - gy * Qu + Quv);
+      const float Myy = -(gy * gy * Q0 - 2.f * gy * Qv + Qvv);
+      float* o = partials + P * TGS_PARTIAL_FLOATS;
+      st4(o, make_float4(A * Mx + B * My, B * Mx + Cc * My, t[3], Q0 / opac));
+      st4(o + 4, make_float4(0.5f * Mxx, Mxy, 0.5f * Myy, t[0]));
+      st4(o + 8, make_float4(t[1], t[2], 0.f, 0.f));
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 // Process-wide DEFAULTS of the per-call TgsRasterOpts fields: read from the environment once (first use), settable
@@ -1919,6 +2164,10 @@ static RasterDefault g_k7_quad_min{"TGS_K7_QUAD_MIN", 16, false};
 static RasterDefault g_k6_split{"TGS_K6_SPLIT", 2, false};
 // TGS_K7_BLOCKS: 1 = the backward in 4x4-block form (k_raster_bwd_blocks); default 0 (measured slower)
 static RasterDefault g_k7_blocks{"TGS_K7_BLOCKS", 0, true};
+// TGS_K7_SCAN_MIN: tiles of a chain-bound frame that walk more than this many entries (among the schedule's first
+// TGS_K7_SCAN_HEADS slots) go to k_raster_bwd_scan on a second stream; 0 = off
+static RasterDefault g_k7_scan_min{"TGS_K7_SCAN_MIN", 0, false};
+static RasterDefault g_k7_scan_heads{"TGS_K7_SCAN_HEADS", 512, false};
 static inline int opt_or(const TgsRasterOpts* o, int32_t TgsRasterOpts::*f, RasterDefault& d) {
   return (o && o->*f >= 0) ? (int)(o->*f) : d.get();
 }
@@ -1930,6 +2179,11 @@ extern "C" int tgs_set_raster_variant(int k6_blocks_on, int k7_front_to_back) {
 extern "C" int tgs_set_k6_split(int factor) {
   if (factor >= 0) g_k6_split.set(factor);
   return g_k6_split.get();
+}
+extern "C" int tgs_set_k7_scan(int min_walk, int heads) {
+  if (min_walk >= 0) g_k7_scan_min.set(min_walk);
+  if (heads >= 0) g_k7_scan_heads.set(heads);
+  return g_k7_scan_min.get() | (g_k7_scan_heads.get() << 16);
 }
 extern "C" int tgs_set_k7_quad(int factor, int min_walk) {
   if (factor >= 0) g_k7_quad.set(factor);
@@ -2030,9 +2284,18 @@ static int rasterize_bwd_impl(const TgsCamera* cam, const float* splats,
     QuadRule qf;
     qf.factor = band >= 0 ? 0 : opt_or(opts, &TgsRasterOpts::k7_quad, g_k7_quad);   // (a band launch keeps one wave per tile)
     qf.min_walk = opt_or(opts, &TgsRasterOpts::k7_quad_min_walk, g_k7_quad_min);
+    qf.scan_min = qf.factor > 0 ? g_k7_scan_min.get() : 0;
+    qf.scan_heads = min(grid, g_k7_scan_heads.get());
+    if (qf.scan_min > 0 && qf.scan_min < qf.min_walk) qf.scan_min = qf.min_walk;
     hipLaunchKernelGGL(k_raster_bwd, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T, splats,
                        group_base, sorted_gid, tile_start, out_rgb, out_depth, final_T, stop_pos,
                        v_rgb, v_depth, v_alpha, lk, partials, tile_loss, tile_order, qf);
+    if (qf.scan_min > 0 && qf.scan_heads > 0) {
+      TGS_CHECK_LAUNCH();
+      hipLaunchKernelGGL(k_raster_bwd_scan, dim3(qf.scan_heads), dim3(1024), 0, (hipStream_t)stream, k, T, splats,
+                         group_base, sorted_gid, tile_start, out_rgb, out_depth, final_T, stop_pos,
+                         v_rgb, v_depth, v_alpha, lk, partials, tile_order, qf);
+    }
     if (qf.factor > 0) {
       TGS_CHECK_LAUNCH();
       // 5 workgroups of 28 KB LDS fit a CU: 1280 resident workgroups walk the schedule

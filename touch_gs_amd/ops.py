@@ -429,6 +429,13 @@ def set_k7_quad(factor: Optional[int] = None, min_walk: Optional[int] = None):
     return r & 255, r >> 8
 
 
+def set_k7_scan(min_walk: Optional[int] = None, heads: Optional[int] = None):
+    """K7's scan form for the longest tiles of chain-bound frames (tgs_set_k7_scan): tiles walking more than ``min_walk``
+    entries among the schedule's first ``heads`` slots; 0 = off; None leaves a setting.  Returns (min_walk, heads)."""
+    r = _lib.load().tgs_set_k7_scan(-1 if min_walk is None else int(min_walk), -1 if heads is None else int(heads))
+    return r & 0xffff, r >> 16
+
+
 def _stop_pos_of(fT, stop_pos=None):
     """The stop positions that belong to a forward's final_T (K7 needs them; there is no fallback)."""
     sp = stop_pos if stop_pos is not None else getattr(fT, "stop_pos", None)
