@@ -272,11 +272,15 @@ int tgs_set_raster_variant(int k6_blocks_on, int k7_front_to_back);
  * of one four-term sum per (tile, Gaussian). */
 int tgs_set_k7_quad(int factor, int min_walk);
 
-/* The LONGEST tiles of a chain-bound frame (TGS_VERSION 310): the four-wave launch lasts as long as its deepest tile.  Tiles
- * that walk more than min_walk entries, among the first `heads` entries of the tile_order schedule (longest lists first), are
- * composited by tgs_rasterize_bwd's scan form instead -- the batch's 64 entries in the lanes of a wave, transmittance and the
- * sum behind as DPP prefix scans, 16 waves per tile.  min_walk 0 = off; negative arguments leave a setting.  Environment
- * TGS_K7_SCAN_MIN / TGS_K7_SCAN_HEADS.  Returns min_walk | heads << 16.  Same decisions; sums in scan order (rounding only). */
+/* The LONGEST tiles of a chain-bound frame (TGS_VERSION 310; an EXPERIMENT, off by default: measured, the chain of the deepest
+ * tile is 3x shorter and the step is not faster -- DESIGN.md 5.8, profiles/r6_ab_runs.txt).  Tiles that walk more than min_walk
+ * entries, among the first `heads` entries of the tile_order schedule (longest lists first), are composited by
+ * tgs_rasterize_bwd's scan form instead of the four-wave form: 16 waves per tile, one per 4x4 block; 16 entries that touch the
+ * block in the lanes of a DPP row, transmittance and the sum behind as prefix scans.  min_walk 0 = off; negative arguments leave
+ * a setting.  Environment TGS_K7_SCAN_MIN / TGS_K7_SCAN_HEADS; TGS_K7_SCAN_SIDE (default 1): the scan form's launch goes to an
+ * internal stream beside the other launches of the call (fork / join by events on the caller's stream; one stream per process:
+ * set 0 when several host threads call the backward concurrently).  Returns min_walk | heads << 16.  Same decisions; sums in
+ * scan order (rounding only). */
 int tgs_set_k7_scan(int min_walk, int heads);
 
 /* The forward's counterpart for tiles with LONG lists: a tile whose list is longer than max(256, factor * I / 4096) --

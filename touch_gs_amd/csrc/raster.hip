@@ -1887,69 +1887,64 @@ __global__ __launch_bounds__(256) void k_raster_bwd_quad(
 
 
 // ---------------------------------------------------------------------------------------------
-// K7 for the LONGEST tiles of a chain-bound frame: entries in the lanes, a scan instead of a walk (round 6)
+// K7 for the LONGEST tiles of a chain-bound frame: a scan over the entries instead of a walk (round 6)
 // ---------------------------------------------------------------------------------------------
 // The four-wave launch lasts as long as its deepest tile: measured on the saved 720p checkpoints K7 = 110 us + 0.15 us x
 // the frame's deepest walk (tools/k7_tail_probe.py) -- a wave alone on its SIMD issues one instruction per ~5.75 cycles
-// and needs ~75 of them per (quadrant, entry), one entry after the other, because the entries of a pixel depend on each
+// and needs ~60 of them per (quadrant, entry), one entry after the other, because the entries of a pixel depend on each
 // other through T and the sum behind.  But that dependence is a SCAN: T in front of entry j = T behind the batch x
-// prod_{i >= j} 1 / (1 - alpha_i), the sum behind entry j = sum behind the batch + sum_{i > j} w_i c_i.v.  Here a
-// workgroup of 16 waves owns the tile, wave w its 4x4 block w; the 64 LANES of a wave hold the 64 entries of the batch
-// (lane 0 the deepest), and the wave goes through its 16 PIXELS one after the other: alpha of all 64 entries at once (the
-// forward's eval_s on the same bits: per-lane coefficients, uniform pixel constants), a 6-step DPP prefix product for T,
-// a 6-step prefix sum for the sum behind, then every lane adds ITS entry's ten sums into its own registers -- no
-// cross-lane reduction per entry at all.  Per batch the 16 waves' sums meet in LDS and lane j of wave 0 writes entry j's
-// partial record.  Per (pixel, batch of 64) ~60 instructions: ~1.5x the work of the four-wave form per contributing
-// evaluation (lanes = entries are filled 15 - 25 %), but a tile-entry costs ~100 cycles of chain instead of ~360.  So:
-// only the tiles that set the length of the launch (walk > scan_min among the schedule's first scan_heads slots), on a
-// second stream beside the four-wave launch.  Same decisions as the forward; sums in scan order: rounding only.
-#ifndef TGS_SCAN_SHFL
-#define TGS_SCAN_SHFL 0      // 1: the scans through __shfl_up (debug reference for the DPP form)
-#endif
-#if TGS_SCAN_SHFL
-__device__ __forceinline__ float scan_incl_add(float v) {
-  const int l = threadIdx.x & 63;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o); if (l >= o) v += t; }
-  return v;
-}
-__device__ __forceinline__ float scan_incl_mul(float v) {
-  const int l = threadIdx.x & 63;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o); if (l >= o) v *= t; }
-  return v;
-}
-__device__ __forceinline__ float lane_shr1_zero(float v) {
-  const float t = __shfl_up(v, 1);
-  return (threadIdx.x & 63) ? t : 0.f;
-}
-#else
-__device__ __forceinline__ float scan_incl_add(float v) {
-  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v));
-  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(v));
-  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v));
-  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(v));
-  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
-  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
-  return v;
-}
-__device__ __forceinline__ float scan_incl_mul(float v) {
+// prod_{i >= j} 1 / (1 - alpha_i), the sum behind entry j = sum behind the batch + sum_{i > j} w_i c_i.v.
+// Here a workgroup of 16 waves owns the tile, wave w its 4x4 block w.  Per batch of 64 list entries a wave compacts the
+// entries that touch ITS block (the forward's exact 16-bit block mask: ~20 % of them) and goes through them 16 at a time:
+// the 16 lanes of a DPP row hold 16 entries (lane 0 the deepest), the four rows four pixels; four iterations cover the
+// block's 16 pixels.  Per iteration: alpha of 16 entries x 4 pixels (eval_s on the forward's bits), a 4-step DPP prefix
+// product for T and a 4-step prefix sum for the sum behind, and every lane adds its (entry, pixel) terms to ten registers
+// -- no cross-lane reduction per entry.  The per-pixel state lives in lane 0 of the pixel's row (T behind folded into the
+// first factor, the sum behind into the first term; `row_ror:1` brings the row's totals back to lane 0): no readlanes,
+// no broadcasts.  After the four iterations two lane-swap folds add the four rows, the block's sums go to its slab of an
+// LDS accumulator; after the batch's one barrier every wave sums four entries over the 16 blocks (one lane per block,
+// DPP row sum) and a rotating wave converts the moments and writes the 64 records.
+// First build of this idea (commit 781c77f: the 64 lanes = ALL 64 entries of the batch, one pixel at a time) spent 7.8 us
+// per batch -- CU-throughput bound, 16 waves x 16 pixels x 85 instructions on four SIMDs -- no better than the four-wave form.
+// Same decisions as the forward; sums in scan order: rounding only (test_k7_scan_form_on_the_longest_tiles).
+// MEASURED, NOT THE DEFAULT (TGS_K7_SCAN_MIN = 0; profiles/r6_ab_runs.txt): the frame's deepest tile (1233 entries)
+// takes 84 us here against ~250 us in the four-wave form -- the chain IS 3x shorter -- but a workgroup saturates its
+// CU's four SIMDs (16 waves x ~680 VALU per batch), so per tile-entry the form costs 1.65x the four-wave form's CU
+// time (all tiles through it: 342 us against 207), and run beside the four-wave launch on its own stream the frame's
+// K7 goes 221 -> ~200 us in the kernel trace while the step does not move (the one-wave launch stretches 14 -> 35 us,
+// the fork / join events cost what is left).
+constexpr int SCAN_ENT = 12;                       // floats per (block, entry) accumulator row (10 used; 48 B: b128-aligned)
+constexpr int SCAN_SLAB = 64 * SCAN_ENT + 4;       // floats per block slab (+4: the 16 blocks' rows of one entry fall into different banks)
+constexpr int SCAN_ACC = 16 * SCAN_SLAB;           // floats per buffer
+constexpr int SCAN_LDS_BYTES = (2 * SCAN_ACC + 2 * 64 * SCAN_ENT + 65 * 12) * 4 + 16 * 64;
+
+__device__ __forceinline__ float row_scan_mul(float v) {      // inclusive prefix product over the 16 lanes of every DPP row
   asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v));
   asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(v));
   asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v));
   asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(v));
-  asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
-  asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
   return v;
 }
-__device__ __forceinline__ float lane_shr1_zero(float v) {     // value of lane - 1, 0 in lane 0
-  float t;
-  asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(t) : "v"(v));
-  return t;
+__device__ __forceinline__ float row_scan_add(float v) {
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v));
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(v));
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(v));
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(v));
+  return v;
 }
-#endif
-__device__ __forceinline__ float rdlane(float v, int l) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+template <int CTRL>
+__device__ __forceinline__ float row_dpp_mov(float old, float v) {   // lanes without a source lane keep `old`
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// x, y -> one register: the sum over the two halves (rows 0 + 2, 1 + 3) of x in the lower half, of y in the upper half
+__device__ __forceinline__ float fold32(float x, float y) {
+  const tgs_u2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// x, y -> rows (x0 + x1, y0 + y1, x2 + x3, y2 + y3)
+__device__ __forceinline__ float fold16(float x, float y) {
+  const tgs_u2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 __global__ __launch_bounds__(1024) void k_raster_bwd_scan(
@@ -1969,18 +1964,30 @@ __global__ __launch_bounds__(1024) void k_raster_bwd_scan(
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int ty = tile / cam.TW, tx = tile - ty * cam.TW;
   const int bx = w & 3, by = w >> 2;                  // this wave's 4x4 block
-  // per-pixel state in lanes 0..15 (pixel p = lane: (4 bx + (p & 3), 4 by + (p >> 2)) of the tile)
-  float T = 1.f, vCr = 0.f, vCg = 0.f, vCb = 0.f, vD = 0.f, SX = 0.f;
-  int lim = 0;
-  {
-    const int p = lane & 15;
-    const int px = tx * TGS_BLOCK + 4 * bx + (p & 3), py = ty * TGS_BLOCK + 4 * by + (p >> 2);
-    if (lane < 16 && px < cam.W && py < cam.H) {
+  const int row = lane >> 4, li = lane & 15;
+  const bool head = li == 0;
+  extern __shared__ float4 scan_lds4[];
+  float* acc = reinterpret_cast<float*>(scan_lds4);                   // [2][16 blocks][64 entries][SCAN_ENT] (+ slab pads)
+  float* tot = acc + 2 * SCAN_ACC;                                     // [2][64 entries][SCAN_ENT]
+  float4* recs = reinterpret_cast<float4*>(tot + 2 * 64 * SCAN_ENT);  // [64 + null][3]
+  unsigned char* idx = reinterpret_cast<unsigned char*>(recs + 65 * 3) + w * 64;   // this wave's compacted entry list
+  __shared__ int s_blim[16];
+
+  // pixel (k, row) of the block = (4 bx + row, 4 by + k) of the tile; its state in lane 0 of the row, constants in all 16 lanes
+  float Tm[4], SXs[4], vr[4], vg[4], vb[4], vd[4];
+  int lim[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int px = tx * TGS_BLOCK + 4 * bx + row, py = ty * TGS_BLOCK + 4 * by + k;
+    float T = 1.f, SX = 0.f;
+    lim[k] = 0; vr[k] = vg[k] = vb[k] = vd[k] = 0.f;
+    if (px < cam.W && py < cam.H) {
       const size_t pi = (size_t)py * cam.W + px;
       const float Tf = final_T[pi];
       T = Tf;
-      lim = min(stop_pos[pi], n);
+      lim[k] = min(stop_pos[pi], n);
       float vA = v_alpha ? v_alpha[pi] : 0.f;
+      float vCr = 0.f, vCg = 0.f, vCb = 0.f, vD = 0.f;
       if (v_rgb) { vCr = v_rgb[3 * pi]; vCg = v_rgb[3 * pi + 1]; vCb = v_rgb[3 * pi + 2]; }
       if (v_depth) vD = v_depth[pi];
       if (loss.on) {
@@ -2009,12 +2016,21 @@ __global__ __launch_bounds__(1024) void k_raster_bwd_scan(
       }
       const float bgdot = cam.bg[0] * vCr + cam.bg[1] * vCg + cam.bg[2] * vCb;
       SX = -Tf * (vA - bgdot);
+      vr[k] = vCr; vg[k] = vCg; vb[k] = vCb; vd[k] = vD;
     }
+    Tm[k] = head ? T : 1.f;
+    SXs[k] = head ? SX : 0.f;
   }
-  __shared__ int s_blim[16];
-  __shared__ float acc[16 * 64 * 10];
-  const int blim = wave_minmax_i<true>(lim);          // how far into the list this block's pixels reach
-  if (lane == 0) s_blim[w] = blim;
+  int klim[4];                                        // how far into the list the four pixels of iteration k reach
+#pragma unroll
+  for (int k = 0; k < 4; k++) klim[k] = wave_minmax_i<true>(lim[k]);
+  const int blim = max(max(klim[0], klim[1]), max(klim[2], klim[3]));
+  if (lane == 0) {
+    s_blim[w] = blim;
+    recs[64 * 3] = make_float4(3.0e38f, 0.f, 0.f, 0.f);     // the null record: alpha = 0 (every wave stores the same bits)
+    recs[64 * 3 + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    recs[64 * 3 + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   __syncthreads();
   int tmax = 0;
 #pragma unroll
@@ -2028,105 +2044,136 @@ __global__ __launch_bounds__(1024) void k_raster_bwd_scan(
     st4(o, z4); st4(o + 4, z4); st4(o + 8, z4);
   }
   const int blk = 4 * by + bx;
-  const float ub = (float)(4 * bx) - 7.5f, vb0 = (float)(4 * by) - 7.5f;
-  for (int base = start + ((tmax - 1) & ~63); base >= start; base -= 64) {
-    const int rel = base - start;
+  const float u = (float)(4 * bx + row) - 7.5f, uu = u * u;
+  const float vb0 = (float)(4 * by) - 7.5f;
+  const int nb = (tmax + 63) >> 6;
+  // batch bi (0 = the deepest) covers list positions [rel, rel + cnt); lane l <-> entry cnt - 1 - l: lane 0 is the deepest
+  auto batch_rel = [&](int bi) { return (nb - 1 - bi) << 6; };
+  auto fetch_gid = [&](int bi) -> int {
+    if (bi >= nb) return -1;
+    const int rel = batch_rel(bi), cnt = min(64, tmax - rel);
+    return lane < cnt ? sorted_gid[start + rel + cnt - 1 - lane] : -1;
+  };
+  int gid_n = fetch_gid(0);
+  float4 n0 = z4, n1 = z4, n2 = z4;
+  if (gid_n >= 0) { const float* r = splats + (size_t)gid_n * TGS_SPLAT_FLOATS; n0 = ld4(r); n1 = ld4(r + 4); n2 = ld4(r + 8); }
+  int gid_nn = fetch_gid(1);
+  // the batch before this one, for the wave that writes its records
+  size_t pP = 0; float pA = 0.f, pB = 0.f, pC = 0.f, pgx = 0.f, pgy = 0.f, popac = 1.f; bool pvalid = false;
+  auto finish = [&](int bi) {                          // lane = entry of batch bi: moments -> the partial record
+    if (!pvalid) return;
+    const float* t = tot + ((bi & 1) * 64 + lane) * SCAN_ENT;
+    const float4 t0 = ld4(t), t1 = ld4(t + 4);
+    const float2 t2 = *reinterpret_cast<const float2*>(t + 8);
+    const float Q0 = t1.x, Qu = t1.y, Qv = t1.z, Quu = t1.w, Quv = t2.x, Qvv = t2.y;
+    const float Mx = -(pgx * Q0 - Qu), My = -(pgy * Q0 - Qv);
+    const float Mxx = -(pgx * pgx * Q0 - 2.f * pgx * Qu + Quu);
+    const float Mxy = -(pgx * pgy * Q0 - pgx * Qv - pgy * Qu + Quv);
+    const float Myy = -(pgy * pgy * Q0 - 2.f * pgy * Qv + Qvv);
+    float* o = partials + pP * TGS_PARTIAL_FLOATS;
+    st4(o, make_float4(pA * Mx + pB * My, pB * Mx + pC * My, t0.w, Q0 / popac));
+    st4(o + 4, make_float4(0.5f * Mxx, Mxy, 0.5f * Myy, t0.x));
+    st4(o + 8, make_float4(t0.y, t0.z, 0.f, 0.f));
+  };
+
+  for (int bi = 0; bi < nb; bi++) {
+    const int rel = batch_rel(bi);
     const int cnt = min(64, tmax - rel);
-    // lane l <-> entry e = cnt - 1 - l of the batch: lane 0 is the DEEPEST entry, so back to front = increasing lane
-    const int e = cnt - 1 - lane;
     const bool valid = lane < cnt;
-    const int pos = rel + e;
-    float c0 = 3.0e38f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f, c5 = 0.f, dep = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
-    float gx = 0.f, gy = 0.f, opac = 1.f;
-    float4 a1 = z4;
+    const int gid = gid_n;
+    const float4 a0 = n0, a1 = n1, a2 = n2;
+    // records of the next batch and the indices of the one after it: in flight while this batch is composited
+    gid_n = gid_nn;
+    if (gid_n >= 0) { const float* r = splats + (size_t)gid_n * TGS_SPLAT_FLOATS; n0 = ld4(r); n1 = ld4(r + 4); n2 = ld4(r + 8); }
+    gid_nn = fetch_gid(bi + 2);
+    float gx = 0.f, gy = 0.f;
     size_t P = 0;
     bool touch = false;
     if (valid) {
-      const int gid = sorted_gid[base + e];
-      const float* r = splats + (size_t)gid * TGS_SPLAT_FLOATS;
-      float4 a0 = ld4(r);
-      a1 = ld4(r + 4);
-      const float4 a2 = ld4(r + 8);
       centre_rel(a0, a2, tx, ty, cam.pix_center, gx, gy);
       const unsigned mask = block_mask16(gx, gy, a1.x, a1.y, a1.z, -__log2f(a0.w));
-      opac = a0.w;
       const TileRec t = make_tile_rec<false>(a0, a1, a2, gx, gy);
-      c0 = t.a.x; c1 = t.a.y; c2 = t.a.z; c3 = t.a.w; c4 = t.b.x; c5 = t.b.y; dep = t.b.z; cr = t.b.w; cg = t.c.x; cb = t.c.y;
-      touch = ((mask >> blk) & 1u) && pos < blim;
-      if (w == 0) P = pair_index(group_base, gid, a2, tx, ty);
+      recs[lane * 3] = t.a; recs[lane * 3 + 1] = t.b; recs[lane * 3 + 2] = t.c;      // (all 16 waves store the same bits)
+      touch = ((mask >> blk) & 1u) && (rel + cnt - 1 - lane) < blim;
+      if (w == (bi & 15)) P = pair_index(group_base, gid, a2, tx, ty);
     }
-    const bool clampy = __ballot(valid && opac > CLAMP_FREE_OPACITY) != 0ull;
-    float a[10];
+    const bool clampy = __ballot(valid && a0.w > CLAMP_FREE_OPACITY) != 0ull;
+    float* slab = acc + (bi & 1) * SCAN_ACC + w * SCAN_SLAB;
+    st4(slab + lane * SCAN_ENT, z4); st4(slab + lane * SCAN_ENT + 4, z4); st4(slab + lane * SCAN_ENT + 8, z4);
+    const unsigned long long bal = __ballot(touch);
+    const int cntT = __popcll(bal);
+    if (touch) idx[__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (unsigned char)lane;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    auto chunks = [&](auto mayclamp) {
+      constexpr bool MAYCLAMP = decltype(mayclamp)::value;
+      for (int c0 = 0; c0 < cntT; c0 += 16) {          // 16 touching entries at a time, deepest first
+        const bool has = c0 + li < cntT;
+        const int src = has ? (int)idx[c0 + li] : 64;
+        const float4 qa = recs[src * 3], qb = recs[src * 3 + 1], qc = recs[src * 3 + 2];
+        const int pos = rel + cnt - 1 - src;
+        float a[10];
 #pragma unroll
-    for (int i = 0; i < 10; i++) a[i] = 0.f;
-#ifndef TGS_SCAN_DBG
-#define TGS_SCAN_DBG 0
-#endif
-    if ((TGS_SCAN_DBG & 1) || __ballot(touch) != 0ull) {
-      auto pixels = [&](auto mayclamp) {
-        constexpr bool MAYCLAMP = decltype(mayclamp)::value;
-#pragma unroll 1
-        for (int p = 0; p < 16; p++) {
-          const int limp = __builtin_amdgcn_readlane(lim, p);
-          if (!(TGS_SCAN_DBG & 2) && limp <= rel) continue;   // the pixel stopped in front of this batch
-          const float Tb = rdlane(T, p), SXb = rdlane(SX, p);
-          const float vr = rdlane(vCr, p), vg = rdlane(vCg, p), vbb = rdlane(vCb, p), vd = rdlane(vD, p);
-          const float u = ub + (float)(p & 3), v = vb0 + (float)(p >> 2);
-          const float uu = u * u, vv = v * v, uv = u * v;
-          float s = fmaf(c1, u, c0);                       // eval_s: the forward's arithmetic, operand for operand
-          s = fmaf(c2, v, s); s = fmaf(c3, uu, s); s = fmaf(c4, uv, s); s = fmaf(c5, vv, s);
+        for (int i = 0; i < 10; i++) a[i] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (klim[k] <= rel) continue;                  // the four pixels stopped in front of this batch (state unchanged)
+          const float v = vb0 + (float)k, vv = v * v, uv = u * v;
+          float s = fmaf(qa.y, u, qa.x);                 // eval_s: the forward's arithmetic, operand for operand
+          s = fmaf(qa.z, v, s); s = fmaf(qa.w, uu, s); s = fmaf(qb.x, uv, s); s = fmaf(qb.y, vv, s);
           const float ex = __builtin_amdgcn_exp2f(-s);
           const float al0 = MAYCLAMP ? fminf(ALPHA_MAX, ex) : ex;
-          const bool go = valid & (s <= LOG2_255) & (pos < limp);
+          const bool go = (s <= LOG2_255) & (pos < lim[k]);
           const float al = go ? al0 : 0.f;
           const float ra = __builtin_amdgcn_rcpf(1.0f - al);        // = 1 exactly when al == 0
-          const float Pm = scan_incl_mul(ra);              // product over this entry and everything behind it in the batch
-          const float Tp = Tb * Pm;                        // transmittance in front of this entry
-          const float wgt = al * Tp;
-          float cv = cr * vr;
-          cv = fmaf(cg, vg, cv); cv = fmaf(cb, vbb, cv); cv = fmaf(dep, vd, cv);
+          const float Pm = row_scan_mul(ra * Tm[k]);     // T in front of this entry (lane 0 carries T behind the chunk)
+          const float wgt = al * Pm;
+          float cv = qb.w * vr[k];
+          cv = fmaf(qc.x, vg[k], cv); cv = fmaf(qc.y, vb[k], cv); cv = fmaf(qb.z, vd[k], cv);
           const float z = wgt * cv;
-          const float Zi = scan_incl_add(z);
-          const float SXj = SXb + lane_shr1_zero(Zi);      // sum behind this entry
+          const float Zi = row_scan_add(z + SXs[k]);     // (lane 0 carries the sum behind the chunk)
+          const float SXj = row_dpp_mov<0x111>(SXs[k], Zi);   // row_shr:1: the sum behind this entry; lane 0 keeps its own
           float q = fmaf(-(al * ra), SXj, z);
           if constexpr (MAYCLAMP) q *= fmaxf(ex * (1.0f / ALPHA_MAX), 1.0f);
-          a[0] = fmaf(wgt, vr, a[0]); a[1] = fmaf(wgt, vg, a[1]); a[2] = fmaf(wgt, vbb, a[2]); a[3] = fmaf(wgt, vd, a[3]);
+          a[0] = fmaf(wgt, vr[k], a[0]); a[1] = fmaf(wgt, vg[k], a[1]); a[2] = fmaf(wgt, vb[k], a[2]); a[3] = fmaf(wgt, vd[k], a[3]);
           a[4] += q; a[5] = fmaf(q, u, a[5]); a[6] = fmaf(q, v, a[6]);
           a[7] = fmaf(q, uu, a[7]); a[8] = fmaf(q, uv, a[8]); a[9] = fmaf(q, vv, a[9]);
-          // the pixel's state in front of the batch (lanes >= cnt hold ra = 1, z = 0: lane 63 has the batch's totals)
-          const bool mine = lane == p;
-          T = mine ? Tb * rdlane(Pm, 63) : T;
-          SX = mine ? SXb + rdlane(Zi, 63) : SX;
+          // the row's totals (lane 15) back to lane 0: the state in front of this chunk
+          const float Pt = row_dpp_mov<0x121>(1.f, Pm), Zt = row_dpp_mov<0x121>(0.f, Zi);    // row_ror:1
+          Tm[k] = head ? Pt : 1.f;
+          SXs[k] = head ? Zt : 0.f;
         }
-      };
-      if (clampy) pixels(std::true_type{}); else pixels(std::false_type{});
-    }
-    float* my = acc + (w * 64 + lane) * 10;
-#pragma unroll
-    for (int i = 0; i < 10; i++) my[i] = a[i];
-    __syncthreads();
-    if (w == 0 && valid) {
-      float t[10];
-#pragma unroll
-      for (int i = 0; i < 10; i++) t[i] = 0.f;
-      for (int ww = 0; ww < 16; ww++) {                  // the 16 blocks' sums in block order
-        const float* o = acc + (ww * 64 + lane) * 10;
-#pragma unroll
-        for (int i = 0; i < 10; i++) t[i] += o[i];
+        // the four rows (pixels) of every entry: rows of f* hold the totals of values (0, 2, 1, 3), (4, 6, 5, 7), (8, 8, 9, 9)
+        const float f0 = fold16(fold32(a[0], a[1]), fold32(a[2], a[3]));
+        const float f1 = fold16(fold32(a[4], a[5]), fold32(a[6], a[7]));
+        const float f2x = fold32(a[8], a[9]);
+        const float f2 = fold16(f2x, f2x);
+        if (has) {
+          float* o = slab + src * SCAN_ENT;
+          const int v0 = ((row & 1) << 1) | (row >> 1);
+          o[v0] = f0; o[4 + v0] = f1; o[8 + (row >> 1)] = f2;
+        }
       }
-      const float A = a1.x, B = a1.y, Cc = a1.z;
-      const float Q0 = t[4], Qu = t[5], Qv = t[6], Quu = t[7], Quv = t[8], Qvv = t[9];
-      const float Mx = -(gx * Q0 - Qu), My = -(gy * Q0 - Qv);
-      const float Mxx = -(gx * gx * Q0 - 2.f * gx * Qu + Quu);
-      const float Mxy = -(gx * gy * Q0 - gx * Qv - gy * Qu + Quv);
-      const float Myy = -(gy * gy * Q0 - 2.f * gy * Qv + Qvv);
-      float* o = partials + P * TGS_PARTIAL_FLOATS;
-      st4(o, make_float4(A * Mx + B * My, B * Mx + Cc * My, t[3], Q0 / opac));
-      st4(o + 4, make_float4(0.5f * Mxx, Mxy, 0.5f * Myy, t[0]));
-      st4(o + 8, make_float4(t[1], t[2], 0.f, 0.f));
-    }
+    };
+    if (clampy) chunks(std::true_type{}); else chunks(std::false_type{});
     __syncthreads();
+    {   // entry 4 w + row of the batch: sum over the 16 blocks, lane li = block li
+      const float* o = acc + (bi & 1) * SCAN_ACC + li * SCAN_SLAB + (4 * w + row) * SCAN_ENT;
+      const float4 x0 = ld4(o), x1 = ld4(o + 4);
+      const float2 x2 = *reinterpret_cast<const float2*>(o + 8);
+      float c[10] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y};
+      row_sum16x10(c);
+      if (head) {
+        float* t = tot + ((bi & 1) * 64 + 4 * w + row) * SCAN_ENT;
+        st4(t, make_float4(c[0], c[1], c[2], c[3])); st4(t + 4, make_float4(c[4], c[5], c[6], c[7]));
+        *reinterpret_cast<float2*>(t + 8) = make_float2(c[8], c[9]);
+      }
+    }
+    if (bi > 0 && w == ((bi - 1) & 15)) finish(bi - 1);
+    pP = P; pA = a1.x; pB = a1.y; pC = a1.z; pgx = gx; pgy = gy; popac = a0.w; pvalid = valid;
   }
+  __syncthreads();
+  if (w == ((nb - 1) & 15)) finish(nb - 1);
 }
 
 }  // namespace
@@ -2168,6 +2215,23 @@ static RasterDefault g_k7_blocks{"TGS_K7_BLOCKS", 0, true};
 // TGS_K7_SCAN_HEADS slots) go to k_raster_bwd_scan on a second stream; 0 = off
 static RasterDefault g_k7_scan_min{"TGS_K7_SCAN_MIN", 0, false};
 static RasterDefault g_k7_scan_heads{"TGS_K7_SCAN_HEADS", 512, false};
+// TGS_K7_SCAN_SIDE: 1 (default) = the scan form's launch on an internal high-priority stream beside the four-wave launch
+// (fork / join by events: also legal inside a stream capture); 0 = in line on the caller's stream.  One stream and one
+// event pair per process: concurrent backward calls from several host threads must set this to 0.
+static RasterDefault g_k7_scan_side{"TGS_K7_SCAN_SIDE", 1, true};
+struct ScanSide { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false; };
+static ScanSide& scan_side() {
+  static ScanSide x = [] {
+    ScanSide y;
+    int lo = 0, hi = 0;
+    y.ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
+           hipStreamCreateWithPriority(&y.s, hipStreamNonBlocking, hi) == hipSuccess &&
+           hipEventCreateWithFlags(&y.fork, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&y.join, hipEventDisableTiming) == hipSuccess;
+    return y;
+  }();
+  return x;
+}
 static inline int opt_or(const TgsRasterOpts* o, int32_t TgsRasterOpts::*f, RasterDefault& d) {
   return (o && o->*f >= 0) ? (int)(o->*f) : d.get();
 }
@@ -2287,15 +2351,31 @@ static int rasterize_bwd_impl(const TgsCamera* cam, const float* splats,
     qf.scan_min = qf.factor > 0 ? g_k7_scan_min.get() : 0;
     qf.scan_heads = min(grid, g_k7_scan_heads.get());
     if (qf.scan_min > 0 && qf.scan_min < qf.min_walk) qf.scan_min = qf.min_walk;
+    // The scan form's launch runs BESIDE the other two (all three only read the frame and write disjoint records; the
+    // scan form needs nothing of k_raster_bwd's): forked FIRST, so that its workgroups (108 KB of LDS, 16 waves: a CU
+    // of their own, more or less) are resident before the four-wave form's persistent grid fills every CU -- launched
+    // behind it they would only find room when that grid retires, i.e. run in series.  Joined before returning.
+    ScanSide* side = nullptr;
+    if (qf.scan_min > 0 && qf.scan_heads > 0) {
+      static const hipError_t scan_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_raster_bwd_scan),
+                                                              hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_LDS_BYTES);
+      TGS_CHECK_ARG(scan_attr == hipSuccess, "k_raster_bwd_scan: dynamic LDS size refused");
+      hipStream_t ss = (hipStream_t)stream;
+      if (g_k7_scan_side.get()) {
+        side = &scan_side();
+        TGS_CHECK_ARG(side->ok, "k_raster_bwd_scan: no side stream");
+        TGS_HIP(hipEventRecord(side->fork, (hipStream_t)stream));
+        TGS_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
+        ss = side->s;
+      }
+      hipLaunchKernelGGL(k_raster_bwd_scan, dim3(qf.scan_heads), dim3(1024), SCAN_LDS_BYTES, ss, k, T, splats,
+                         group_base, sorted_gid, tile_start, out_rgb, out_depth, final_T, stop_pos,
+                         v_rgb, v_depth, v_alpha, lk, partials, tile_order, qf);
+      if (side) TGS_HIP(hipEventRecord(side->join, side->s));
+    }
     hipLaunchKernelGGL(k_raster_bwd, dim3(grid), dim3(64), 0, (hipStream_t)stream, k, T, splats,
                        group_base, sorted_gid, tile_start, out_rgb, out_depth, final_T, stop_pos,
                        v_rgb, v_depth, v_alpha, lk, partials, tile_loss, tile_order, qf);
-    if (qf.scan_min > 0 && qf.scan_heads > 0) {
-      TGS_CHECK_LAUNCH();
-      hipLaunchKernelGGL(k_raster_bwd_scan, dim3(qf.scan_heads), dim3(1024), 0, (hipStream_t)stream, k, T, splats,
-                         group_base, sorted_gid, tile_start, out_rgb, out_depth, final_T, stop_pos,
-                         v_rgb, v_depth, v_alpha, lk, partials, tile_order, qf);
-    }
     if (qf.factor > 0) {
       TGS_CHECK_LAUNCH();
       // 5 workgroups of 28 KB LDS fit a CU: 1280 resident workgroups walk the schedule
@@ -2303,6 +2383,7 @@ static int rasterize_bwd_impl(const TgsCamera* cam, const float* splats,
                          group_base, sorted_gid, tile_start, out_rgb, out_depth, final_T, stop_pos,
                          v_rgb, v_depth, v_alpha, lk, partials, tile_order, qf, grid);
     }
+    if (side) TGS_HIP(hipStreamWaitEvent((hipStream_t)stream, side->join, 0));
   }
   TGS_CHECK_LAUNCH();
   return TGS_OK;
