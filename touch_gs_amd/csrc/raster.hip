@@ -975,6 +975,13 @@ __device__ __forceinline__ bool frame_is_chain_bound(const int32_t* __restrict__
   return (long long)walk * 8192 > work * q.factor;
 }
 
+__device__ __forceinline__ int frame_deepest_walk(const int32_t* __restrict__ tile_start, int T) {
+  int walk = 0;
+#pragma unroll
+  for (int i = 0; i < TGS_WALK_WORDS; i++) walk = max(walk, tile_start[TGS_WALK_AT(T, i)]);
+  return walk;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K7 backward, back to front (round 4; the default)
 // ---------------------------------------------------------------------------------------------
@@ -1647,6 +1654,12 @@ __global__ __launch_bounds__(64) void k_raster_bwd_blocks(
 // (frame_is_chain_bound) take this path.  Same decisions (the forward's compare on the same bits), same per-pixel arithmetic;
 // the quadrant totals are added in the order k = 0, 1, 2, 3 (deterministic; differs from the one-wave kernel's order
 // by rounding).  Losses (tile_loss) are k_raster_bwd's, which visits every tile first.
+#ifdef TGS_QUAD_TIMING   // developer build (tools/k7_quad_timing.py): where a tile's time goes, per schedule slot and wave
+__device__ unsigned long long g_quad_dbg[8192 * 16];
+#define QT_NOW() __builtin_amdgcn_s_memtime()
+#else
+#define QT_NOW() 0ull
+#endif
 __global__ __launch_bounds__(256) void k_raster_bwd_quad(
     CamK cam, int T_total, const float* __restrict__ splats, const int32_t* __restrict__ group_base,
     const int32_t* __restrict__ sorted_gid, const int32_t* __restrict__ tile_start,
@@ -1699,6 +1712,15 @@ __global__ __launch_bounds__(256) void k_raster_bwd_quad(
   const int tmax = max(max(s_qlim[0], s_qlim[1]), max(s_qlim[2], s_qlim[3]));
   if (tmax <= quad.min_walk) continue;   // k_raster_bwd's tile
   if (quad.scan_min > 0 && slot < quad.scan_heads && tmax > quad.scan_min) continue;   // k_raster_bwd_scan's tile
+#ifdef TGS_QUAD_PRIO
+  // the launch lasts as long as its deepest tiles, whose waves share their SIMDs with four other workgroups': let the
+  // arbiter prefer them (s_setprio is per wave and stays until the next tile)
+  {
+    const int deepest = frame_deepest_walk(tile_start, T_total);
+    const int pr = (4 * tmax > 3 * deepest) ? 3 : (2 * tmax > deepest) ? 2 : (4 * tmax > deepest) ? 1 : 0;
+    if (pr == 3) __builtin_amdgcn_s_setprio(3); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+  }
+#endif
 
   // per-pixel state, the arithmetic of k_raster_bwd's prologue for pixel slot k of the lane
   float T = 1.f, vCr = 0.f, vCg = 0.f, vCb = 0.f, vD = 0.f, SX = 0.f;
@@ -1780,7 +1802,9 @@ __global__ __launch_bounds__(256) void k_raster_bwd_quad(
     const int cnt = min(64, tmax - rel);
     size_t P = 0;
     float4 a0 = z4, a1 = z4;
+    const unsigned long long qt0 = QT_NOW();
     __syncthreads();                        // the previous batch's records and totals have been consumed
+    const unsigned long long qt1 = QT_NOW();
     if (k == 0) {
       if (lane < cnt) {
         const int gid = sorted_gid[base + lane];
@@ -1798,7 +1822,9 @@ __global__ __launch_bounds__(256) void k_raster_bwd_quad(
       if (lane == 0) s_clamp = hot != 0ull;
     }
     sums_k[lane * 4] = z4; sums_k[lane * 4 + 1] = z4; sums_k[lane * 4 + 2] = z4; sums_k[lane * 4 + 3] = z4;
+    const unsigned long long qt2 = QT_NOW();
     __syncthreads();
+    const unsigned long long qt3 = QT_NOW();
 
     // this quadrant's entries: mask bit k, below the quadrant's own furthest stop position
     const unsigned my_mask = lane < cnt ? __float_as_uint(recs[lane * 3 + 2].w) : 0u;
@@ -1857,7 +1883,18 @@ __global__ __launch_bounds__(256) void k_raster_bwd_quad(
     };
     if (s_clamp) walk(std::true_type{});
     else walk(std::false_type{});
+    const unsigned long long qt4 = QT_NOW();
     __syncthreads();
+    const unsigned long long qt5 = QT_NOW();
+#ifdef TGS_QUAD_TIMING
+    if (lane == 0 && slot < 8192) {
+      unsigned long long* d = g_quad_dbg + slot * 16 + k * 4;
+      d[0] += qt1 - qt0;      // waiting at the top barrier (for wave 0: the other waves; for the others: wave 0's combine)
+      d[1] += qt3 - qt1;      // staging (wave 0) / waiting for it
+      d[2] += qt4 - qt3;      // own walk
+      d[3] += qt5 - qt4;      // waiting for the slowest quadrant
+    }
+#endif
     if (k == 0 && lane < cnt) {
       float4 s0 = sums[lane * 4], s1 = sums[lane * 4 + 1], s2 = sums[lane * 4 + 2], s3 = sums[lane * 4 + 3];
 #pragma unroll
@@ -2249,6 +2286,13 @@ extern "C" int tgs_set_k7_scan(int min_walk, int heads) {
   if (heads >= 0) g_k7_scan_heads.set(heads);
   return g_k7_scan_min.get() | (g_k7_scan_heads.get() << 16);
 }
+#ifdef TGS_QUAD_TIMING
+extern "C" int tgs_debug_quad_timing(unsigned long long* host_dst, int clear) {
+  if (host_dst && hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_quad_dbg), sizeof(unsigned long long) * 8192 * 16) != hipSuccess) return -1;
+  if (clear) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_quad_dbg)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned long long) * 8192 * 16) != hipSuccess) return -2; }
+  return 0;
+}
+#endif
 extern "C" int tgs_set_k7_quad(int factor, int min_walk) {
   if (factor >= 0) g_k7_quad.set(factor);
   if (min_walk >= 0) g_k7_quad_min.set(min_walk);
