@@ -1802,9 +1802,9 @@ __global__ __launch_bounds__(256) void k_raster_bwd_quad(
     const int cnt = min(64, tmax - rel);
     size_t P = 0;
     float4 a0 = z4, a1 = z4;
-    const unsigned long long qt0 = QT_NOW();
+    [[maybe_unused]] const unsigned long long qt0 = QT_NOW();
     __syncthreads();                        // the previous batch's records and totals have been consumed
-    const unsigned long long qt1 = QT_NOW();
+    [[maybe_unused]] const unsigned long long qt1 = QT_NOW();
     if (k == 0) {
       if (lane < cnt) {
         const int gid = sorted_gid[base + lane];
@@ -1822,9 +1822,9 @@ __global__ __launch_bounds__(256) void k_raster_bwd_quad(
       if (lane == 0) s_clamp = hot != 0ull;
     }
     sums_k[lane * 4] = z4; sums_k[lane * 4 + 1] = z4; sums_k[lane * 4 + 2] = z4; sums_k[lane * 4 + 3] = z4;
-    const unsigned long long qt2 = QT_NOW();
+    [[maybe_unused]] const unsigned long long qt2 = QT_NOW();
     __syncthreads();
-    const unsigned long long qt3 = QT_NOW();
+    [[maybe_unused]] const unsigned long long qt3 = QT_NOW();
 
     // this quadrant's entries: mask bit k, below the quadrant's own furthest stop position
     const unsigned my_mask = lane < cnt ? __float_as_uint(recs[lane * 3 + 2].w) : 0u;
@@ -1883,9 +1883,9 @@ __global__ __launch_bounds__(256) void k_raster_bwd_quad(
     };
     if (s_clamp) walk(std::true_type{});
     else walk(std::false_type{});
-    const unsigned long long qt4 = QT_NOW();
+    [[maybe_unused]] const unsigned long long qt4 = QT_NOW();
     __syncthreads();
-    const unsigned long long qt5 = QT_NOW();
+    [[maybe_unused]] const unsigned long long qt5 = QT_NOW();
 #ifdef TGS_QUAD_TIMING
     if (lane == 0 && slot < 8192) {
       unsigned long long* d = g_quad_dbg + slot * 16 + k * 4;
