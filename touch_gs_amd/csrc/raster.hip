@@ -975,13 +975,6 @@ __device__ __forceinline__ bool frame_is_chain_bound(const int32_t* __restrict__
   return (long long)walk * 8192 > work * q.factor;
 }
 
-__device__ __forceinline__ int frame_deepest_walk(const int32_t* __restrict__ tile_start, int T) {
-  int walk = 0;
-#pragma unroll
-  for (int i = 0; i < TGS_WALK_WORDS; i++) walk = max(walk, tile_start[TGS_WALK_AT(T, i)]);
-  return walk;
-}
-
 // ---------------------------------------------------------------------------------------------
 // K7 backward, back to front (round 4; the default)
 // ---------------------------------------------------------------------------------------------
@@ -1670,8 +1663,8 @@ __global__ __launch_bounds__(256) void k_raster_bwd_quad(
   if (!frame_is_chain_bound(tile_start, T_total, quad)) return;   // the usual case: nothing to do (every wave alike)
   const int tid = threadIdx.x, lane = tid & 63, k = tid >> 6;   // k = this wave's quadrant
   __shared__ int s_qlim[4];
-  __shared__ int s_clamp;
-  __shared__ float4 recs[64 * 3];
+  __shared__ int s_clamp[2], s_stager[2], s_arrive;
+  __shared__ float4 recs2[2 * 64 * 3];  // two batches of staged records: the next one is staged while this one is walked
   __shared__ float4 sums[4 * 64 * 4];   // [quadrant][Gaussian j][16 slots]
   constexpr int RED_RS = 68;
   constexpr int RED_ROWS = 8;
@@ -1712,15 +1705,6 @@ __global__ __launch_bounds__(256) void k_raster_bwd_quad(
   const int tmax = max(max(s_qlim[0], s_qlim[1]), max(s_qlim[2], s_qlim[3]));
   if (tmax <= quad.min_walk) continue;   // k_raster_bwd's tile
   if (quad.scan_min > 0 && slot < quad.scan_heads && tmax > quad.scan_min) continue;   // k_raster_bwd_scan's tile
-#ifdef TGS_QUAD_PRIO
-  // the launch lasts as long as its deepest tiles, whose waves share their SIMDs with four other workgroups': let the
-  // arbiter prefer them (s_setprio is per wave and stays until the next tile)
-  {
-    const int deepest = frame_deepest_walk(tile_start, T_total);
-    const int pr = (4 * tmax > 3 * deepest) ? 3 : (2 * tmax > deepest) ? 2 : (4 * tmax > deepest) ? 1 : 0;
-    if (pr == 3) __builtin_amdgcn_s_setprio(3); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-  }
-#endif
 
   // per-pixel state, the arithmetic of k_raster_bwd's prologue for pixel slot k of the lane
   float T = 1.f, vCr = 0.f, vCg = 0.f, vCb = 0.f, vD = 0.f, SX = 0.f;
@@ -1797,34 +1781,46 @@ __global__ __launch_bounds__(256) void k_raster_bwd_quad(
       wt[i] = w;
     }
   }
-  for (int base = start + ((tmax - 1) & ~63); base >= start; base -= 64) {
+  // Staging (64 records: two dependent loads, the tile-centred quadratic, the quadrant mask: ~10 % of a tile's life when
+  // wave 0 did it between two barriers with the other three waves idle) is done by whichever wave finishes its walk of
+  // the CURRENT batch first -- a batch lasts as long as its slowest quadrant, so somebody has the time (tools/
+  // k7_quad_timing.py: 21 % of all wave time, 46 % of the deepest tile's, was spent waiting for it) -- into the other
+  // half of recs2; the stager keeps the batch's pair indices and conics and converts / writes its records after the walk.
+  struct Staged { size_t P; float4 a0, a1; };
+  auto stage = [&](int base, int half) -> Staged {
+    const int cnt = min(64, tmax - (base - start));
+    Staged g; g.P = 0; g.a0 = z4; g.a1 = z4;
+    if (lane < cnt) {
+      const int gid = sorted_gid[base + lane];
+      const float* r = splats + (size_t)gid * TGS_SPLAT_FLOATS;
+      g.a0 = ld4(r); g.a1 = ld4(r + 4);
+      const float4 a2 = ld4(r + 8);
+      float gx, gy;
+      centre_rel(g.a0, a2, tx, ty, cam.pix_center, gx, gy);
+      g.a0.x = gx; g.a0.y = gy;                       // kept for the conversion of the moments below
+      const TileRec t = make_tile_rec(g.a0, g.a1, a2, gx, gy);
+      float4* rc = recs2 + half * (64 * 3);
+      rc[lane * 3] = t.a; rc[lane * 3 + 1] = t.b; rc[lane * 3 + 2] = t.c;
+      g.P = pair_index(group_base, gid, a2, tx, ty);
+    }
+    const unsigned long long hot = __ballot(lane < cnt && g.a0.w > CLAMP_FREE_OPACITY);
+    if (lane == 0) { s_clamp[half] = hot != 0ull; s_stager[half] = k; }
+    return g;
+  };
+  const int base0 = start + ((tmax - 1) & ~63);
+  Staged cur, nxt;
+  cur.P = 0; cur.a0 = z4; cur.a1 = z4; nxt = cur;
+  if (k == 0) cur = stage(base0, 0);
+  if (tid == 0) s_arrive = 0;
+  [[maybe_unused]] unsigned long long qt0 = QT_NOW();
+  __syncthreads();
+  int half = 0;
+  for (int base = base0; base >= start; base -= 64, half ^= 1) {
     const int rel = base - start;
     const int cnt = min(64, tmax - rel);
-    size_t P = 0;
-    float4 a0 = z4, a1 = z4;
-    [[maybe_unused]] const unsigned long long qt0 = QT_NOW();
-    __syncthreads();                        // the previous batch's records and totals have been consumed
+    const float4* recs = recs2 + half * (64 * 3);
     [[maybe_unused]] const unsigned long long qt1 = QT_NOW();
-    if (k == 0) {
-      if (lane < cnt) {
-        const int gid = sorted_gid[base + lane];
-        const float* r = splats + (size_t)gid * TGS_SPLAT_FLOATS;
-        a0 = ld4(r); a1 = ld4(r + 4);
-        const float4 a2 = ld4(r + 8);
-        float gx, gy;
-        centre_rel(a0, a2, tx, ty, cam.pix_center, gx, gy);
-        a0.x = gx; a0.y = gy;                       // kept for the conversion of the moments below
-        const TileRec t = make_tile_rec(a0, a1, a2, gx, gy);
-        recs[lane * 3] = t.a; recs[lane * 3 + 1] = t.b; recs[lane * 3 + 2] = t.c;
-        P = pair_index(group_base, gid, a2, tx, ty);
-      }
-      const unsigned long long hot = __ballot(lane < cnt && a0.w > CLAMP_FREE_OPACITY);
-      if (lane == 0) s_clamp = hot != 0ull;
-    }
-    sums_k[lane * 4] = z4; sums_k[lane * 4 + 1] = z4; sums_k[lane * 4 + 2] = z4; sums_k[lane * 4 + 3] = z4;
-    [[maybe_unused]] const unsigned long long qt2 = QT_NOW();
-    __syncthreads();
-    [[maybe_unused]] const unsigned long long qt3 = QT_NOW();
+    sums_k[lane * 4] = z4; sums_k[lane * 4 + 1] = z4; sums_k[lane * 4 + 2] = z4; sums_k[lane * 4 + 3] = z4;   // (only this wave writes them)
 
     // this quadrant's entries: mask bit k, below the quadrant's own furthest stop position
     const unsigned my_mask = lane < cnt ? __float_as_uint(recs[lane * 3 + 2].w) : 0u;
@@ -1881,21 +1877,21 @@ __global__ __launch_bounds__(256) void k_raster_bwd_quad(
       }
     }
     };
-    if (s_clamp) walk(std::true_type{});
+    if (s_clamp[half]) walk(std::true_type{});
     else walk(std::false_type{});
-    [[maybe_unused]] const unsigned long long qt4 = QT_NOW();
-    __syncthreads();
-    [[maybe_unused]] const unsigned long long qt5 = QT_NOW();
-#ifdef TGS_QUAD_TIMING
-    if (lane == 0 && slot < 8192) {
-      unsigned long long* d = g_quad_dbg + slot * 16 + k * 4;
-      d[0] += qt1 - qt0;      // waiting at the top barrier (for wave 0: the other waves; for the others: wave 0's combine)
-      d[1] += qt3 - qt1;      // staging (wave 0) / waiting for it
-      d[2] += qt4 - qt3;      // own walk
-      d[3] += qt5 - qt4;      // waiting for the slowest quadrant
+    [[maybe_unused]] const unsigned long long qt2 = QT_NOW();
+    if (base - 64 >= start) {                 // first to finish: stage the next batch
+      int t = 0;
+      if (lane == 0) t = atomicAdd(&s_arrive, 1);
+      if (__builtin_amdgcn_readfirstlane(t) == 0) nxt = stage(base - 64, half ^ 1);
     }
-#endif
-    if (k == 0 && lane < cnt) {
+    [[maybe_unused]] const unsigned long long qt3 = QT_NOW();
+    __syncthreads();                          // every quadrant's totals of this batch are in LDS, the next batch is staged
+    [[maybe_unused]] const unsigned long long qt4 = QT_NOW();
+    const bool mine = s_stager[half] == k;
+    if (mine) {
+      if (lane == 0) s_arrive = 0;
+      if (lane < cnt) {
       float4 s0 = sums[lane * 4], s1 = sums[lane * 4 + 1], s2 = sums[lane * 4 + 2], s3 = sums[lane * 4 + 3];
 #pragma unroll
       for (int w = 1; w < 4; w++) {        // quadrant totals in the order 0, 1, 2, 3
@@ -1906,6 +1902,7 @@ __global__ __launch_bounds__(256) void k_raster_bwd_quad(
         s2.x += t2.x; s2.y += t2.y; s2.z += t2.z; s2.w += t2.w;
         s3.x += t3.x; s3.y += t3.y; s3.z += t3.z; s3.w += t3.w;
       }
+      const float4 a0 = cur.a0, a1 = cur.a1;
       const float gx = a0.x, gy = a0.y;           // centre relative to the tile centre (set while staging)
       const float A = a1.x, B = a1.y, Cc = a1.z;
       const float Q0 = s1.x, Qu = s1.y + s1.z, Qv = s1.w + s2.x, Quu = s2.y + s2.z, Qvv = s2.w + s3.x, Quv = s3.y;
@@ -1913,11 +1910,25 @@ __global__ __launch_bounds__(256) void k_raster_bwd_quad(
       const float Mxx = -(gx * gx * Q0 - 2.f * gx * Qu + Quu);
       const float Mxy = -(gx * gy * Q0 - gx * Qv - gy * Qu + Quv);
       const float Myy = -(gy * gy * Q0 - 2.f * gy * Qv + Qvv);
-      float* o = partials + P * TGS_PARTIAL_FLOATS;
+      float* o = partials + cur.P * TGS_PARTIAL_FLOATS;
       st4(o, make_float4(A * Mx + B * My, B * Mx + Cc * My, s0.w, Q0 / a0.w));
       st4(o + 4, make_float4(0.5f * Mxx, Mxy, 0.5f * Myy, s0.x));
       st4(o + 8, make_float4(s0.y, s0.z, 0.f, 0.f));
+      }
     }
+    cur = nxt;                                // (meaningful in the wave that staged the next batch: the only one that will use it)
+    [[maybe_unused]] const unsigned long long qt5 = QT_NOW();
+    __syncthreads();                          // the totals have been consumed (the next walk overwrites them), s_arrive is 0
+#ifdef TGS_QUAD_TIMING
+    if (lane == 0 && slot < 8192) {
+      unsigned long long* d = g_quad_dbg + slot * 16 + k * 4;
+      d[0] += (qt1 - qt0) + (QT_NOW() - qt5);   // barriers around the conversion (one wave converts, three wait)
+      d[1] += qt3 - qt2;                        // staging the next batch (the first wave to finish)
+      d[2] += qt2 - qt1;                        // own walk
+      d[3] += qt4 - qt3;                        // waiting for the slowest quadrant
+    }
+    qt0 = QT_NOW();
+#endif
   }
   }   // slots
 }
