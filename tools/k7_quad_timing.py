@@ -40,7 +40,7 @@ used = np.nonzero(tot[:, 0] > 0)[0]
 tick_us = None
 print(f"K7 {k7:.1f} us; slots with a four-wave tile: {len(used)}; longest tile total {tot[:, 0].max():.0f} ticks")
 top = used[np.argsort(-tot[used, 0])][:12]
-print("slot  tile  walk   ticks/wave0   top-barrier  staging  own-walk  wait-slowest   (shares of wave 0 | of the slowest-walking wave)")
+print("slot  tile  walk   ticks/wave0   conv-barriers  staging-next  own-walk  wait-slowest   (shares of wave 0 | of the slowest-walking wave)")
 for s_ in top:
     t = int(order[s_]) if s_ < len(order) else -1
     w0 = d[s_, 0] / tot[s_, 0]
@@ -48,6 +48,6 @@ for s_ in top:
     wk = d[s_, kk] / tot[s_, kk]
     print(f"{s_:5d} {t:5d} {int(walk[t]) if 0 <= t < T else -1:5d} {tot[s_, 0]:10.0f}   " + " ".join(f"{x:6.2f}" for x in w0) + "   | k=%d " % kk + " ".join(f"{x:6.2f}" for x in wk))
 S = d[used].sum(axis=(0, 1))
-print("all four-wave tiles, all waves: top-barrier %.2f staging %.2f own-walk %.2f wait-slowest %.2f" % tuple(S / S.sum()))
+print("all four-wave tiles, all waves: conversion barriers %.2f staging the next batch %.2f own-walk %.2f wait-slowest %.2f" % tuple(S / S.sum()))
 S0 = d[used][:, 0].sum(axis=0); print("wave 0 only: " + " ".join(f"{x:.2f}" for x in S0 / S0.sum()))
 print(json.dumps(dict(k7_us=k7, ticks_longest=float(tot[:, 0].max()), walk_max=int(walk.max()))))

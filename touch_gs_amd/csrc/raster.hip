@@ -1653,7 +1653,10 @@ __device__ unsigned long long g_quad_dbg[8192 * 16];
 #else
 #define QT_NOW() 0ull
 #endif
-__global__ __launch_bounds__(256) void k_raster_bwd_quad(
+#ifndef TGS_QUAD_WAVES
+#define TGS_QUAD_WAVES 4      // waves per SIMD asked of the register allocator: 109 VGPRs; 5 (96 VGPRs, 42 spilled) measures 2 % slower on the step
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TGS_QUAD_WAVES, 8))) void k_raster_bwd_quad(
     CamK cam, int T_total, const float* __restrict__ splats, const int32_t* __restrict__ group_base,
     const int32_t* __restrict__ sorted_gid, const int32_t* __restrict__ tile_start,
     const float* __restrict__ out_rgb, const float* __restrict__ out_depth,
