@@ -515,9 +515,9 @@ __device__ __forceinline__ void raster_fwd_quadrant(
 // Which tiles the forward splits into quadrant blocks: lists longer than max(256, factor x I / 4096) -- factor (default 2)
 // times what a wave slot would hold if the frame's I intersections were spread evenly -- among the first `heads` entries
 // of the schedule (longest lists first: extra blocks are only launched for those).  cfg3 never qualifies.
-struct SplitRule { int factor, n_slots, heads; };
+struct SplitRule { int factor, n_slots, heads, floor; };
 __device__ __forceinline__ bool tile_is_split(int n, int I, SplitRule r) {
-  return r.factor > 0 && n > max(256, (int)(((long long)I * r.factor) >> 12));
+  return r.factor > 0 && n > max(r.floor, (int)(((long long)I * r.factor) >> 12));
 }
 
 template <bool WANT_IDX>
@@ -2340,6 +2340,8 @@ extern "C" int tgs_rasterize_fwd(const TgsCamera* cam, const float* splats,
     sr.n_slots = grid;
     static const int env_heads = [] { const char* e = getenv("TGS_K6_HEADS"); return e ? atoi(e) : 512; }();
     sr.heads = sr.factor > 0 ? min(grid, env_heads) : 0;
+    static const int env_floor = [] { const char* e = getenv("TGS_K6_FLOOR"); return e ? atoi(e) : 256; }();
+    sr.floor = env_floor;
     const int blocks = grid + 3 * sr.heads;
     if (final_idx)
       hipLaunchKernelGGL(k_raster_fwd_blocks<true>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, k, T, splats,
