@@ -55,7 +55,10 @@ def _write_report(lines):
 #   huge_720p: the reference's image size with a dozen SCREEN-FILLING Gaussians (a table / background Gaussian of a
 #   converged object-centric model covers 1000 - 3600 tiles): K8's workgroup-shared segmented sum of long runs, the
 #   direct counting path and k_fill_bins on groups of tens of thousands of pairs (round 6).
-EXTRA_CONFIGS = {"huge_720p": (30_000, 1280, 720, 3, 77, 1)}
+#   clamp_640: every third Gaussian with opacity > 0.999 and e^2 larger axes: tens of thousands of (pixel, Gaussian) pairs ON
+#   the alpha = 0.999 clamp (App. B.6 / B.7), at a size where the strict bar of the full-size test can be asserted in both
+#   forms of K7 (the small-size test of test_gpu_parity.py is statistical).
+EXTRA_CONFIGS = {"huge_720p": (30_000, 1280, 720, 3, 77, 1), "clamp_640": (20_000, 640, 400, 3, 91, 1)}
 HUGE_EVERY = 2500     # rows 0, 2500, 5000, ... of huge_720p are blown up
 
 
@@ -68,7 +71,12 @@ def _mutate_huge(P):
     P["means"][idx, 2] = P["means"][idx, 2].clamp(min=3.0)
 
 
-EXTRA_MUTATE = {"huge_720p": _mutate_huge}
+def _mutate_clamp(P):
+    P["opac_logit"][::3] = 12.0
+    P["log_scales"][::3] += 2.0 + torch.tensor([0.0, 0.2, -0.2]).to(P["log_scales"])    # (not isotropic: max_over(), exception (b))
+
+
+EXTRA_MUTATE = {"huge_720p": _mutate_huge, "clamp_640": _mutate_clamp}
 
 
 def order_ambiguous_tiles(sg_hip, ts_hip, g_ref, ts_ref, N):
@@ -513,3 +521,51 @@ def test_gradients_with_screen_filling_gaussians(dev):
             report.append(f"{key}: the huge Gaussians' error / mass: max {e.max():.1e}")
             assert e.max() < GTOL, (key, e)
     print("\n".join(report))
+
+
+@pytest.mark.parametrize("quad", [False, True])
+def test_gradients_on_the_alpha_clamp_in_both_forms_of_k7(dev, quad):
+    """The full-size test's bar -- max <= 1e-4 of the un-cancelled magnitude on EVERY decision-clear Gaussian, ten
+    screen-space and five parameter gradients -- on a scene whose pixels sit on the alpha = 0.999 clamp by the ten
+    thousand (the BASELINE scenes have almost none), through K7's one-wave form and through its four-wave form (rule
+    forced onto every tile walking more than 8 entries).  The small-size backward test (tests/test_gpu_parity.py::
+    test_rasterize_bwd) asserts a share of bad entries and a median; this one has no statistical escape."""
+    from tests.util import K7_KEYS, PARAM_KEYS, k7_outputs, param_mass
+    from touch_gs_amd import ops
+    before = ops.set_k7_quad()
+    try:
+        ops.set_k7_quad(*((1, 8) if quad else (0, before[1])))
+        b = build_case("clamp_640", dev)
+    finally:
+        ops.set_k7_quad(*before)
+    N, W, H = b["N"], b["W"], b["H"]
+    pc = b["pc"]
+    # pairs on the clamp, counted with the oracle's own projection: o exp(-sigma) > 0.999 at a pixel centre
+    n_cl = 0
+    for g in np.nonzero((pc["opac"] > 0.999) & (pc["tiles_hit"] > 0))[0]:      # (the region is a fraction of the footprint)
+        x0, y0 = int(min(max(pc["xy"][g, 0] - 4, 0), W)), int(min(max(pc["xy"][g, 1] - 4, 0), H))
+        ys, xs = np.mgrid[y0:min(y0 + 8, H), x0:min(x0 + 8, W)]
+        dx, dy = pc["xy"][g, 0] - (xs + 0.5), pc["xy"][g, 1] - (ys + 0.5)
+        sig = 0.5 * (pc["conic"][g, 0] * dx * dx + pc["conic"][g, 2] * dy * dy) + pc["conic"][g, 1] * dx * dy
+        n_cl += int((pc["opac"][g] * np.exp(-sig) > 0.999).sum())
+    assert n_cl >= 3000, n_cl
+    pm, reach, clear = classify_gaussians(b)
+    frac = clear.sum() / max(reach.sum(), 1)
+    report = [f"clamp_640 (four-wave form: {quad}): >= {n_cl} pixel-Gaussian pairs on the clamp; "
+              f"clear Gaussians {frac:.4f} of the reaching ones"]
+    assert frac > 0.25, report
+    ref7 = {k: np.asarray(b["bb"][k], np.float64).reshape(N, -1) for k in K7_KEYS}
+    assert_gradients("clamp_640", k7_outputs(b["v_splats"]), ref7, b["m7"], reach, clear, K7_KEYS, report)
+    pmass = param_mass(b["R"], b["Pn"], b["deg"], b["cb"], W, H, pc["radius"], b["m7"])
+    assert_gradients("clamp_640", dict(zip(PARAM_KEYS, b["grads"])), b["pb"], pmass, reach, clear, PARAM_KEYS, report)
+    print("\n".join(report))
+    _write_report(report)
+    # the two forms did take different paths: same gradients up to rounding, not the same bits
+    _CLAMP_FORMS[quad] = b["v_splats"]
+    if len(_CLAMP_FORMS) == 2:
+        a, c = _CLAMP_FORMS[False], _CLAMP_FORMS[True]
+        assert not np.array_equal(a, c) and np.abs(a - c).max() <= 1e-3 * np.abs(a).max()
+
+
+_CLAMP_FORMS = {}
+

@@ -254,6 +254,14 @@ __device__ __forceinline__ void geom_eval(const CamK& cam, const float* m, const
 // group's pair range and counts its (tile, Gaussian) intersections (K3a), so the records are not
 // re-read and the pair offset is stored with the record instead of patched into it afterwards.
 // PRE: the colours come from colors_in although DEG >= 0 (colour prefetch, k_project_fwd_colors)
+// d sigmoid / d logit without the cancellation of o (1 - o): at opacity 0.99999 (logit 12, a converged opaque surface)
+// 1 - o has only 7 bits left in fp32.  sigmoid'(x) = t / (1 + t)^2 with t = exp(-|x|) (even in x, no overflow).
+__device__ __forceinline__ float sigmoid_deriv(float x) {
+  const float t = expf(-fabsf(x));
+  const float s = 1.0f / (1.0f + t);
+  return t * s * s;
+}
+
 // project_fwd_core: everything after the parameters and the colour are in registers (m, ls, q, opac_logit value,
 // rgb; ignored for g >= N) -- shared by the stand-alone K1 below and by the fused K8 + Adam kernel, which runs
 // the NEXT view's K1 on the parameters it has just updated (front prefetch).
@@ -749,8 +757,7 @@ __global__ __launch_bounds__(256) void k_project_bwd(
   const float m[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
   float vm[3] = {0.f, 0.f, 0.f};
 
-  const float o = 1.0f / (1.0f + expf(-opac_logit[g]));
-  v_opac_logit[g] = v[3] * o * (1.0f - o);
+  v_opac_logit[g] = v[3] * sigmoid_deriv(opac_logit[g]);
 
   // ---- SH colour backward (B.5) ----
   if constexpr (DEG >= 0) {
@@ -902,8 +909,7 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
   if (g < N) {
     m[0] = means[3 * g]; m[1] = means[3 * g + 1]; m[2] = means[3 * g + 2];
     ol = opac_logit[g];
-    const float o = 1.0f / (1.0f + expf(-ol));
-    vol = v[3] * o * (1.0f - o);
+    vol = v[3] * sigmoid_deriv(ol);
     // ---- SH colour backward (B.5), coefficients from / gradients to the LDS row ----
     float dx = m[0] - cam.campos[0], dy = m[1] - cam.campos[1], dz = m[2] - cam.campos[2];
     const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
