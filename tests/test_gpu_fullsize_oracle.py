@@ -58,7 +58,11 @@ def _write_report(lines):
 #   clamp_640: every third Gaussian with opacity > 0.999 and e^2 larger axes: tens of thousands of (pixel, Gaussian) pairs ON
 #   the alpha = 0.999 clamp (App. B.6 / B.7), at a size where the strict bar of the full-size test can be asserted in both
 #   forms of K7 (the small-size test of test_gpu_parity.py is statistical).
-EXTRA_CONFIGS = {"huge_720p": (30_000, 1280, 720, 3, 77, 1), "clamp_640": (20_000, 640, 400, 3, 91, 1)}
+#   hard_640: strata the random BASELINE scenes do not hold -- needles (16 : 1), sub-pixel Gaussians (the 0.3 px blur is
+#   most of their footprint), Gaussians 3 - 30 cm from the camera, never-visible faint ones, SH bands large enough to drive
+#   colours through the zero clamp, and a stratum 20x farther away at 20x the size (same screen footprint, large depths).
+EXTRA_CONFIGS = {"huge_720p": (30_000, 1280, 720, 3, 77, 1), "clamp_640": (20_000, 640, 400, 3, 91, 1),
+                 "hard_640": (24_000, 640, 400, 3, 93, 0)}
 HUGE_EVERY = 2500     # rows 0, 2500, 5000, ... of huge_720p are blown up
 
 
@@ -76,7 +80,27 @@ def _mutate_clamp(P):
     P["log_scales"][::3] += 2.0 + torch.tensor([0.0, 0.2, -0.2]).to(P["log_scales"])    # (not isotropic: max_over(), exception (b))
 
 
-EXTRA_MUTATE = {"huge_720p": _mutate_huge, "clamp_640": _mutate_clamp}
+def _mutate_hard(P):
+    N = P["means"].shape[0]
+    i = torch.arange(N)
+    g = torch.Generator().manual_seed(5)
+    needle, tiny, near, faint, loud, far = (i % 8 == k for k in range(6))
+    # 16 : 1.  (Not more: the conic is the inverse of a 2x2 covariance whose condition number is the squared aspect ratio;
+    # any fp32 evaluation, the reference's included, carries eps x aspect^2 into it -- measured at 90 : 1: conics off by
+    # 4.5e-4, pixels by 2e-4 -- so the 1e-4 bar ends near 40 : 1.)
+    P["log_scales"][needle] = P["log_scales"][needle].mean(1, keepdim=True) + torch.tensor([1.6, -1.2, -1.2]).to(P["log_scales"])
+    P["log_scales"][tiny] -= 3.0
+    z_new = 0.03 + 0.3 * torch.rand(int(near.sum()), generator=g)           # view 0: camera z = world z
+    k = (z_new / P["means"][near, 2]).to(P["means"])
+    P["means"][near] = P["means"][near] * k[:, None]                          # same pixel, closer
+    P["log_scales"][near] += torch.log(k)[:, None]                            # same footprint
+    P["opac_logit"][faint] = -7.0                                             # alpha < 1 / 255 everywhere
+    P["sh"][loud, 1:, :] *= 20.0
+    P["means"][far] *= 20.0
+    P["log_scales"][far] += float(np.log(20.0))
+
+
+EXTRA_MUTATE = {"huge_720p": _mutate_huge, "clamp_640": _mutate_clamp, "hard_640": _mutate_hard}
 
 
 def order_ambiguous_tiles(sg_hip, ts_hip, g_ref, ts_ref, N):
@@ -568,4 +592,41 @@ def test_gradients_on_the_alpha_clamp_in_both_forms_of_k7(dev, quad):
 
 
 _CLAMP_FORMS = {}
+
+
+def test_gradients_on_hard_strata(dev):
+    """The full-size test's bar on the strata of hard_640 (see EXTRA_CONFIGS): forward at 1e-4 on every decision-clear
+    pixel, ten screen-space and five parameter gradients at 1e-4 of the un-cancelled magnitude on every decision-clear
+    Gaussian, stratum by stratum in the report."""
+    from tests.util import K7_KEYS, PARAM_KEYS, err_over_mass, k7_outputs, param_mass
+    b = build_case("hard_640", dev)
+    N, W, H = b["N"], b["W"], b["H"]
+    clear_px = (b["margin"] > 1e-3) & b["order_ok"]
+    assert clear_px.mean() > 0.85, clear_px.mean()
+    er = relerr(b["rgb"], b["bf"]["rgb"], floor=1e-2)[clear_px]
+    ed = relerr(b["depth"], b["bf"]["depth_acc"], floor=1e-2)[clear_px]
+    eT = np.abs(b["fT"] - b["bf"]["final_T"])[clear_px]
+    assert er.max() <= TOL and ed.max() <= TOL and eT.max() <= TOL, (er.max(), ed.max(), eT.max())
+    pm, reach, clear = classify_gaussians(b)
+    names = ("needle", "sub-pixel", "near", "faint", "loud SH", "far", "plain", "plain")
+    report = [f"hard_640: decision-clear pixels {clear_px.mean():.4f}; rgb / depth / T max {er.max():.1e} {ed.max():.1e} {eT.max():.1e}; "
+              + ", ".join(f"{names[k]}: {int((reach & (np.arange(N) % 8 == k)).sum())} reaching / {int((clear & (np.arange(N) % 8 == k)).sum())} clear"
+                          for k in range(6))]
+    assert int((reach & (np.arange(N) % 8 == 3)).sum()) == 0          # the faint stratum reaches no pixel
+    for k in (0, 1, 2, 4, 5):
+        assert int((clear & (np.arange(N) % 8 == k)).sum()) >= 150, report
+    ref7 = {k: np.asarray(b["bb"][k], np.float64).reshape(N, -1) for k in K7_KEYS}
+    got7 = k7_outputs(b["v_splats"])
+    # (tol_q = the bar itself: with 17 k Gaussians q99.99 is the second largest value)
+    assert_gradients("hard_640", got7, ref7, b["m7"], reach, clear, K7_KEYS, report, tol_q=GTOL)
+    pmass = param_mass(b["R"], b["Pn"], b["deg"], b["cb"], W, H, b["pc"]["radius"], b["m7"])
+    got = dict(zip(PARAM_KEYS, b["grads"]))
+    assert_gradients("hard_640", got, b["pb"], pmass, reach, clear, PARAM_KEYS, report, tol_q=GTOL)
+    for k in (0, 1, 2, 4, 5):
+        sel = clear & (np.arange(N) % 8 == k)
+        worst = max(float(err_over_mass(g_[key], r_[key], m_[key])[sel].max())
+                    for keys, g_, r_, m_ in ((K7_KEYS, got7, ref7, b["m7"]), (PARAM_KEYS, got, b["pb"], pmass)) for key in keys)
+        report.append(f"{names[k]}: worst error / mass over the fifteen gradients {worst:.1e}")
+    print("\n".join(report))
+    _write_report(report)
 
