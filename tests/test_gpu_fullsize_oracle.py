@@ -62,7 +62,10 @@ def _write_report(lines):
 #   most of their footprint), Gaussians 3 - 30 cm from the camera, never-visible faint ones, SH bands large enough to drive
 #   colours through the zero clamp, and a stratum 20x farther away at 20x the size (same screen footprint, large depths).
 EXTRA_CONFIGS = {"huge_720p": (30_000, 1280, 720, 3, 77, 1), "clamp_640": (20_000, 640, 400, 3, 91, 1),
-                 "hard_640": (24_000, 640, 400, 3, 93, 0)}
+                 "hard_640": (24_000, 640, 400, 3, 93, 0),
+                 # every other scene of the suite has fx = fy and the principal point in the image centre; a RealSense
+                 # (the reference's camera, utils/read_realsense_depth.py) has neither
+                 "skewed_640": (20_000, 640, 400, 3, 95, 1)}
 HUGE_EVERY = 2500     # rows 0, 2500, 5000, ... of huge_720p are blown up
 
 
@@ -101,6 +104,9 @@ def _mutate_hard(P):
 
 
 EXTRA_MUTATE = {"huge_720p": _mutate_huge, "clamp_640": _mutate_clamp, "hard_640": _mutate_hard}
+# fx 15 % longer than fy, principal point 37 px right of and 21.5 px above the centre (the image no longer sits in the
+# middle of the frustum the 1.3 x tan(fov / 2) clamp of B.2 is built around)
+EXTRA_INTRINSICS = {"skewed_640": lambda i: dict(fx=1.15 * i["fx"], fy=i["fy"], cx=i["cx"] + 37.0, cy=i["cy"] - 21.5)}
 
 
 def order_ambiguous_tiles(sg_hip, ts_hip, g_ref, ts_ref, N):
@@ -156,6 +162,8 @@ def build_case(name, dev):
     P, intr = synthetic_gaussians(N, W, H, deg, seed)
     if name in EXTRA_MUTATE:
         EXTRA_MUTATE[name](P)
+    if name in EXTRA_INTRINSICS:
+        intr.update(EXTRA_INTRINSICS[name](intr))
     cam = make_camera(intr, view, 8, bg=(0.1, 0.2, 0.3))
     D = {k: v.to(dev).contiguous() for k, v in P.items()}
     # ---- HIP ----
@@ -643,4 +651,31 @@ def test_gradients_on_hard_strata(dev):
         report.append(f"{names[k]}: worst error / mass over the fifteen gradients {worst:.1e}")
     print("\n".join(report))
     _write_report(report)
+
+
+def test_forward_and_gradients_with_an_off_centre_camera(dev):
+    """fx != fy and a principal point away from the image centre (every other scene of the suite is symmetric): forward at
+    1e-4 on the decision-clear pixels, all fifteen gradients at 1e-4 of the un-cancelled magnitude on the decision-clear
+    Gaussians, and the fused train step through the same oracle chain."""
+    from tests.util import K7_KEYS, PARAM_KEYS, k7_outputs, param_mass
+    b = build_case("skewed_640", dev)
+    N, W, H = b["N"], b["W"], b["H"]
+    assert abs(b["cam"].fx / b["cam"].fy - 1.15) < 1e-6 and abs(b["cam"].cx - (W / 2 + 37.0)) < 1e-6
+    clear_px = (b["margin"] > 1e-3) & b["order_ok"]
+    assert clear_px.mean() > 0.9, clear_px.mean()
+    er = relerr(b["rgb"], b["bf"]["rgb"], floor=1e-2)[clear_px]
+    ed = relerr(b["depth"], b["bf"]["depth_acc"], floor=1e-2)[clear_px]
+    eT = np.abs(b["fT"] - b["bf"]["final_T"])[clear_px]
+    assert er.max() <= TOL and ed.max() <= TOL and eT.max() <= TOL, (er.max(), ed.max(), eT.max())
+    assert np.array_equal(b["last_hip"][clear_px], b["last_ref"][clear_px])
+    pm, reach, clear = classify_gaussians(b)
+    report = [f"skewed_640: decision-clear pixels {clear_px.mean():.4f}; rgb / depth / T max {er.max():.1e} {ed.max():.1e} {eT.max():.1e}; "
+              f"clear Gaussians {clear.sum() / max(reach.sum(), 1):.4f} of the reaching ones"]
+    ref7 = {k: np.asarray(b["bb"][k], np.float64).reshape(N, -1) for k in K7_KEYS}
+    assert_gradients("skewed_640", k7_outputs(b["v_splats"]), ref7, b["m7"], reach, clear, K7_KEYS, report, tol_q=GTOL)
+    pmass = param_mass(b["R"], b["Pn"], b["deg"], b["cb"], W, H, b["pc"]["radius"], b["m7"])
+    assert_gradients("skewed_640", dict(zip(PARAM_KEYS, b["grads"])), b["pb"], pmass, reach, clear, PARAM_KEYS, report, tol_q=GTOL)
+    print("\n".join(report))
+    _write_report(report)
+    _train_step_case(b, dev, {"block": FLAG_SETS["block"]})
 
