@@ -56,16 +56,16 @@ def _write_report(lines):
 #   converged object-centric model covers 1000 - 3600 tiles): K8's workgroup-shared segmented sum of long runs, the
 #   direct counting path and k_fill_bins on groups of tens of thousands of pairs (round 6).
 #   clamp_640: every third Gaussian with opacity > 0.999 and e^2 larger axes: tens of thousands of (pixel, Gaussian) pairs ON
-#   the alpha = 0.999 clamp (App. B.6 / B.7), at a size where the strict bar of the full-size test can be asserted in both
+#   the alpha = 0.999 clamp (App. B.6 / B.7), SH degree 2, at a size where the strict bar of the full-size test can be asserted in both
 #   forms of K7 (the small-size test of test_gpu_parity.py is statistical).
 #   hard_640: strata the random BASELINE scenes do not hold -- needles (16 : 1), sub-pixel Gaussians (the 0.3 px blur is
 #   most of their footprint), Gaussians 3 - 30 cm from the camera, never-visible faint ones, SH bands large enough to drive
 #   colours through the zero clamp, and a stratum 20x farther away at 20x the size (same screen footprint, large depths).
-EXTRA_CONFIGS = {"huge_720p": (30_000, 1280, 720, 3, 77, 1), "clamp_640": (20_000, 640, 400, 3, 91, 1),
+EXTRA_CONFIGS = {"huge_720p": (30_000, 1280, 720, 3, 77, 1), "clamp_640": (20_000, 640, 400, 2, 91, 1),
                  "hard_640": (24_000, 640, 400, 3, 93, 0),
                  # every other scene of the suite has fx = fy and the principal point in the image centre; a RealSense
-                 # (the reference's camera, utils/read_realsense_depth.py) has neither
-                 "skewed_640": (20_000, 640, 400, 3, 95, 1)}
+                 # (the reference's camera, utils/read_realsense_depth.py) has neither.  637 x 395: ragged right / bottom tiles
+                 "skewed_640": (20_000, 637, 395, 3, 95, 1)}
 HUGE_EVERY = 2500     # rows 0, 2500, 5000, ... of huge_720p are blown up
 
 
