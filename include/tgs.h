@@ -283,6 +283,15 @@ int tgs_set_k7_quad(int factor, int min_walk);
  * scan order (rounding only). */
 int tgs_set_k7_scan(int min_walk, int heads);
 
+/* Binning: a Gaussian whose tile rect holds more than `tiles` tiles is a LONG RUN (TGS_VERSION 310): its pairs stay outside its
+ * binning group's aggregated counting box (counted with direct atomics) and its partial-gradient records are summed by the
+ * whole workgroup in K8 instead of by its own thread.  Default 32 (environment TGS_LONG_RUN); the trainer lowers it to 8 for
+ * object-centric models, where a few thousand table / background Gaussians hold most of the pairs (model.spatial_sort; the
+ * row order `optim.balanced_order` deals exactly these Gaussians evenly over the groups).  A launch-shape parameter: lists,
+ * images and gradients are the same up to the rounding of K8's sums, whose shape depends on (tiles covered, this value).
+ * tiles < 1 leaves the setting; returns the value in effect (1 .. 256).  Process-wide, like the other tgs_set_* tuning calls. */
+int tgs_set_long_run(int tiles);
+
 /* The forward's counterpart for tiles with LONG lists: a tile whose list is longer than max(256, factor * I / 4096) --
  * factor (default 2 -- 4 until TGS_VERSION 310 --, environment TGS_K6_SPLIT) times the per-slot load of an even spread -- among the first 512 entries
  * of the tile_order schedule is composited by FOUR blocks of the same launch, one 8x8 quadrant each (pixels are

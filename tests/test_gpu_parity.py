@@ -1041,3 +1041,44 @@ def test_tile_order_schedule(dev, W, H):
         assert torch.equal(a, b)
     # the pair index space has holes (one region per XCD): compare the slots that exist, through K8a
     assert torch.equal(ops.reduce_partials(acam, splats, gb, bwd_a), ops.reduce_partials(acam, splats, gb, bwd_b))
+
+
+def test_long_run_threshold_changes_nothing_but_the_shape_of_the_sums(dev):
+    """tgs_set_long_run (which Gaussians count as long runs: outside the group's counting box, their partial records
+    summed by the whole workgroup in K8) is a launch-shape parameter: on an object-centric scene with screen-filling
+    Gaussians the tile lists are the same bit for bit at 4, 8, 32 and 256 tiles, the images too, and the parameter
+    gradients agree to the rounding of K8's sums."""
+    from touch_gs_amd import ops
+    from touch_gs_amd.scene import make_camera, synthetic_gaussians
+    N, W, H, deg = 40_000, 640, 400, 3
+    P, intr = synthetic_gaussians(N, W, H, deg, 9, clustered=True)
+    P["log_scales"][::400] += 3.5                       # a hundred Gaussians covering hundreds of tiles
+    D = {k: v.to(dev).float().contiguous() for k, v in P.items()}
+    cam = make_camera(intr, 1, 8, bg=(0.1, 0.2, 0.3))
+    g = torch.Generator().manual_seed(4)
+    v_rgb = torch.randn(H, W, 3, generator=g).to(dev)
+    v_d, v_a = torch.randn(H, W, generator=g).to(dev), torch.randn(H, W, generator=g).to(dev)
+    before = ops.set_long_run()
+    out = {}
+    try:
+        for lr in (32, 4, 8, 256):
+            assert ops.set_long_run(lr) == lr
+            sp, radii, gb, ts, sg, st = ops.project_bin_sort(cam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], deg)
+            T = cam.num_tiles
+            n = int(ts[T])
+            rgb, depth, fT, _ = ops.rasterize_fwd(cam, sp, sg, ts)
+            partials, _ = ops.rasterize_bwd(cam, sp, gb, sg, ts, rgb, depth, fT, v_rgb, v_d, v_a)
+            grads = ops.project_bwd(cam, D["means"], D["log_scales"], D["quats"], D["opac_logit"], D["sh"], deg, sp, gb, partials)
+            out[lr] = (ts[:T + 1].clone(), sg[:n].clone(), rgb.clone(), depth.clone(), [t.clone() for t in grads[:5]])
+    finally:
+        ops.set_long_run(before)
+    hits = (out[32][0][1:] - out[32][0][:-1])
+    assert int(hits.max()) > 64
+    for lr in (4, 8, 256):
+        a, b = out[32], out[lr]
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), lr            # the lists
+        assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]), lr            # the images
+        for x, y in zip(a[4], b[4]):
+            assert torch.allclose(x, y, rtol=2e-4, atol=1e-6 * float(x.abs().max())), (lr, float((x - y).abs().max()), float(x.abs().max()))
+    assert any(not torch.equal(x, y) for x, y in zip(out[32][4], out[4][4]))       # (the sums did take another shape)
+

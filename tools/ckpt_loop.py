@@ -117,6 +117,7 @@ def main():
         torch.cuda.synchronize()
     m.spatial_sort()
     out["layout"] = a.layout
+    out["long_run"] = ops.set_long_run()      # chosen by the re-sort (model.spatial_sort)
     if a.breakdown:
         out["breakdown"] = breakdown(m, views[:3])
     m.enable_speculative_budget()

@@ -35,6 +35,23 @@ __global__ __launch_bounds__(256) void k_calib_fma(int n_iter, float a, float b,
 }
 }  // namespace
 
+// Process-wide default of CamK.long_run (tgs_common.h make_camk): environment TGS_LONG_RUN once, tgs_set_long_run afterwards.
+#include <atomic>
+#include "tgs_binning.h"
+extern "C" int tgs_set_long_run(int tiles) {
+  static std::atomic<int> v{-1};
+  int x = v.load(std::memory_order_relaxed);
+  if (x < 0) {
+    const char* e = getenv("TGS_LONG_RUN");
+    int init = e ? atoi(e) : TGS_LONG_RUN;
+    init = init < 1 ? 1 : (init > 256 ? 256 : init);
+    int expect = -1;
+    x = v.compare_exchange_strong(expect, init, std::memory_order_relaxed) ? init : expect;
+  }
+  if (tiles >= 1) { x = tiles > 256 ? 256 : tiles; v.store(x, std::memory_order_relaxed); }
+  return x;
+}
+
 extern "C" int tgs_calib_fma_stream(int n_iter, float* sink, int64_t* n_wave_instr, void* stream) {
   TGS_CHECK_ARG(n_iter > 0 && sink, "bad argument");
   const int blocks = 256 * 4;     // 4 workgroups of 4 waves per CU: 4 waves per SIMD

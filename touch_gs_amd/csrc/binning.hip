@@ -32,7 +32,7 @@ __device__ __forceinline__ int group_load_scan(const CamK& cam, int N, int group
     hits = w * h;
     dbits = __float_as_uint(rec[2]);
   }
-  return group_scan_store(S, hits, x0, y0, w, dbits, my_off);
+  return group_scan_store(S, hits, x0, y0, w, dbits, my_off, cam.long_run);
 }
 
 // K3a: count intersections per tile; allocate the group's pair range; remember every pair's
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(TGS_GROUP) void k_tile_count(
   const int total = group_load_scan(cam, N, tgs_group_id(), splats, S, my_off);
   const int g = tgs_group_id() * TGS_GROUP + threadIdx.x;
   if (g < N) splats[(size_t)g * TGS_SPLAT_FLOATS + 11] = __int_as_float(my_off);
-  group_count_tiles(S, cam.TW, cam.TW * cam.TH, total, group_base, tile_count, rank, status, capacity, sticky);
+  group_count_tiles(S, cam.TW, cam.TW * cam.TH, total, group_base, tile_count, rank, status, capacity, sticky, cam.long_run);
 }
 
 // K4: exclusive scan of the [8][T] per-XCD tile counters in tile-major order -> tile_start[T+1] and

@@ -327,12 +327,12 @@ __device__ __forceinline__ void project_fwd_core(
     GroupScan& S = *Sp;
     int x0, y0, w, h, my_off;
     unpack_rect(rect, x0, y0, w, h);
-    const int total = group_scan_store(S, w * h, x0, y0, w, __float_as_uint(tz), my_off);
+    const int total = group_scan_store(S, w * h, x0, y0, w, __float_as_uint(tz), my_off, cam.long_run);
     if (g < N) {
       float* o = splats + (size_t)g * TGS_SPLAT_FLOATS;
       st4(o + 8, make_float4(c1, c2, __uint_as_float(rect), __int_as_float(my_off)));
     }
-    group_count_tiles(S, cam.TW, cam.TW * cam.TH, total, group_base, tile_count, rank, status, capacity, sticky);
+    group_count_tiles(S, cam.TW, cam.TW * cam.TH, total, group_base, tile_count, rank, status, capacity, sticky, cam.long_run);
   }
 }
 
@@ -530,7 +530,7 @@ __device__ __forceinline__ float row_sum16(float v) {
 __device__ __forceinline__ void group_sum_partials(const float* __restrict__ splats,
                                                    const int32_t* __restrict__ group_base,
                                                    const float* __restrict__ partials, int g, int N, float* v,
-                                                   RunScan& S) {
+                                                   RunScan& S, int long_run) {
 #pragma unroll
   for (int i = 0; i < 10; i++) v[i] = 0.f;
   const int tid = threadIdx.x;
@@ -542,7 +542,7 @@ __device__ __forceinline__ void group_sum_partials(const float* __restrict__ spl
     hits = w * h;
     if (hits) base = group_base[g / TGS_GROUP] + __float_as_int(r2.w);
   }
-  const bool big = hits > TGS_LONG_RUN;
+  const bool big = hits > long_run;
   if (!__syncthreads_or(big)) {        // nothing long in this group
     sum_run_serial(partials + (size_t)base * TGS_PARTIAL_FLOATS, hits, v);
     return;
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials(
   __shared__ RunScan S;
   const int g = blockIdx.x * 256 + threadIdx.x;
   float v[10];
-  group_sum_partials(splats, group_base, partials, g, N, v, S);
+  group_sum_partials(splats, group_base, partials, g, N, v, S, cam.long_run);
   if (g >= N) return;
   float* o = v_splats + (size_t)g * TGS_SPLAT_FLOATS;
   st4(o, make_float4(v[0], v[1], v[2], v[3]));
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(256) void k_project_bwd(
   }
   // per-Gaussian upstream gradient: {v_x, v_y, v_depth, v_opac, v_a, v_b, v_c, v_r, v_g, v_b}
   float v[10];
-  if (partials) group_sum_partials(splats, group_base, partials, g, N, v, S);   // (workgroup-uniform: every thread calls)
+  if (partials) group_sum_partials(splats, group_base, partials, g, N, v, S, cam.long_run);   // (workgroup-uniform: every thread calls)
   if (g >= N) return;
   if (!partials) {
     const float* p = v_splats + (size_t)g * TGS_SPLAT_FLOATS;
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(256) void k_project_bwd_lds(
   // group's partial records, long runs shared by the whole workgroup.  Its scratch aliases the (not yet loaded) SH image.
   static_assert(256 * (3 * KS + 4) * sizeof(float) >= sizeof(RunScan), "the run scan reuses the SH image");
   float v[10];
-  group_sum_partials(splats, group_base, partials, g, N, v, *reinterpret_cast<RunScan*>(lds4));
+  group_sum_partials(splats, group_base, partials, g, N, v, *reinterpret_cast<RunScan*>(lds4), cam.long_run);
   {
     const int nf = nrows * F4;
     for (int f0 = tid; f0 < nf; f0 += 256 * 4) {

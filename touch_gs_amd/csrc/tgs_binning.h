@@ -69,7 +69,9 @@ static inline int tgs_counter_len(int T) { return TGS_MAXG_OFF(T) + TGS_XCC * TG
 // ordered buffer spans the whole image and takes the direct path.
 #define TGS_AGG_TILES 1024
 #define TGS_AGG_U 4            // pairs per thread kept in registers by the aggregated path (256 * 4 per group)
-#define TGS_LONG_RUN 32        // runs of more tiles than this: outside the group's box (here), summed by the workgroup (K8)
+#ifndef TGS_LONG_RUN
+#define TGS_LONG_RUN 32        // DEFAULT of CamK.long_run (tgs_set_long_run): runs of more tiles than this stay outside the group's box (here) and are summed by the workgroup (K8)
+#endif
 #ifndef TGS_DIRECT_U
 #define TGS_DIRECT_U 4         // pairs per thread and round of the direct counting path and of k_fill_bins
 #endif
@@ -97,7 +99,7 @@ struct GroupScan {
 // Builds the in-group exclusive scan from each thread's (rect, depth).  Returns the group total.
 // Must be called by all 256 threads; the caller synchronises before reading S.
 __device__ __forceinline__ int group_scan_store(GroupScan& S, int hits, int x0, int y0, int w,
-                                                unsigned dbits, int& my_off) {
+                                                unsigned dbits, int& my_off, int long_run) {
   const int tid = threadIdx.x;
   int incl = hits;
 #pragma unroll
@@ -108,7 +110,7 @@ __device__ __forceinline__ int group_scan_store(GroupScan& S, int hits, int x0, 
   if ((tid & (TGS_WAVE - 1)) == TGS_WAVE - 1) S.wave_tot[tid / TGS_WAVE] = incl;
   {   // tile bounding box of the wave's rects (DPP reductions; same-address LDS atomics would serialise)
     // (Gaussians with long runs of tiles stay outside the box: their pairs are counted directly, group_count_tiles)
-    const bool any = hits > 0 && hits <= TGS_LONG_RUN;
+    const bool any = hits > 0 && hits <= long_run;
     const int bx0 = wave_minmax_i<false>(any ? x0 : (1 << 30)), by0 = wave_minmax_i<false>(any ? y0 : (1 << 30));
     const int bx1 = wave_minmax_i<true>(any ? x0 + w : 0), by1 = wave_minmax_i<true>(any ? y0 + hits / max(w, 1) : 0);
     if ((tid & (TGS_WAVE - 1)) == 0) {
@@ -231,7 +233,7 @@ __device__ __forceinline__ void group_count_tiles(GroupScan& S, int TW, int T, i
                                                   int32_t* __restrict__ tile_count,
                                                   int32_t* __restrict__ rank,
                                                   int32_t* __restrict__ status, long long capacity,
-                                                  int32_t* __restrict__ sticky) {
+                                                  int32_t* __restrict__ sticky, int long_run) {
   const int tid = threadIdx.x;
   const int x = xcc_id();
   // pair range of the group: one returning atomic on the XCD's allocator.  Issued first and consumed
@@ -268,7 +270,7 @@ __device__ __forceinline__ void group_count_tiles(GroupScan& S, int TW, int T, i
       bool valid[TGS_AGG_U], lng[TGS_AGG_U];
       group_pairs_xy<TGS_AGG_U>(S, tid, TGS_GROUP, total, j, tx, ty, valid);
 #pragma unroll
-      for (int u = 0; u < TGS_AGG_U; u++) lng[u] = S.off[j[u] + 1] - S.off[j[u]] > TGS_LONG_RUN;
+      for (int u = 0; u < TGS_AGG_U; u++) lng[u] = S.off[j[u] + 1] - S.off[j[u]] > long_run;
 #pragma unroll
       for (int u = 0; u < TGS_AGG_U; u++) {
         lb[u] = -1; lr[u] = 0;

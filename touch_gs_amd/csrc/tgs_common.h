@@ -98,10 +98,13 @@ struct CamK {
   float near_plane, pix_center, glob_scale;
   float bg[3];
   int W, H, TW, TH;
+  int long_run;    // binning: runs of more tiles than this are "long" (tgs_set_long_run; not a camera property -- it rides here because every kernel of the front half and K8 takes the block)
 };
 
+extern "C" int tgs_set_long_run(int tiles);
 static inline CamK make_camk(const TgsCamera* c) {
   CamK k;
+  k.long_run = tgs_set_long_run(-1);
   const float* V = c->viewmat;
   for (int r = 0; r < 3; r++) {
     for (int j = 0; j < 3; j++) k.R[3 * r + j] = V[4 * r + j];

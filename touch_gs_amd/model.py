@@ -73,6 +73,7 @@ class ModelConfig:
     # spatial_sort deals the Gaussians that covered more than 32 tiles in the last frame evenly over the binning groups
     # (optim.balanced_order): a layout choice like the Morton order itself, results unchanged
     balance_long_runs: bool = True
+    long_run: int = 0          # tiles beyond which a Gaussian is a long run (tgs_set_long_run); 0 = chosen at every re-sort (32, or 8 for object-centric frames)
 
     def downscale_factor(self, step: int) -> int:
         """2 ** max(num_downscales - step // resolution_schedule, 0)  (Splatfacto._get_downscale_factor)."""
@@ -355,7 +356,20 @@ class DepthGaussianSplattingModel:
                 hits = (hits + int(n_cams) - 1) // int(n_cams)
             else:
                 hits = (hits + len(cams) - 1) // len(cams)    # mean tiles per view (rounded up)
-        perm = balanced_order(self.params.means, hits)
+        long_run = ops.set_long_run()
+        if hits is not None:
+            # which Gaussians count as long runs (tgs_set_long_run: the kernels' counting box, K8's shared sums AND the rows
+            # dealt over the groups here -- one number): 32 tiles, but 8 where the long runs ARE the frame -- an object on a
+            # table: 7 % of the Gaussians hold 60 % of the pairs, and a group's pairs set the length of K1's counting,
+            # k_fill_bins and K8 (largest group 8 951 -> 5 098 pairs, step -2.9 % / -2.2 % on the saved 720p checkpoints;
+            # cfg3 -0.5 ... -1.3 % if it were applied there: profiles/r6_ab_runs.txt).  ModelConfig.long_run fixes it.
+            long_run = self.config.long_run
+            if long_run <= 0:
+                share = float(hits[hits > 32].sum()) / max(float(hits.sum()), 1.0)
+                long_run = 8 if share > 0.3 else 32
+            if long_run != ops.set_long_run():
+                ops.set_long_run(long_run)
+        perm = balanced_order(self.params.means, hits, long_run=long_run)
         self.params.permute_(perm, self.optimizer.exp_avg, self.optimizer.exp_avg_sq)
         density = getattr(self, "density", None)
         if density is not None:

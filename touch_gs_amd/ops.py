@@ -415,6 +415,12 @@ def set_raster_variant(k6_blocks: Optional[bool] = None, k7_front_to_back: Optio
     return _lib.load().tgs_set_raster_variant(f(k6_blocks), f(k7_front_to_back))
 
 
+def set_long_run(tiles: Optional[int] = None) -> int:
+    """Binning: Gaussians covering more than ``tiles`` tiles are long runs (tgs_set_long_run; default 32, None = query):
+    counted outside the group's aggregated box, their partial records summed by the whole workgroup in K8."""
+    return _lib.load().tgs_set_long_run(-1 if tiles is None else int(tiles))
+
+
 def set_k6_split(factor: Optional[int] = None) -> int:
     """The forward splits tiles whose list exceeds max(256, factor x the balanced per-slot load) into four quadrant blocks
     of the same launch (tgs_set_k6_split; default 2, 0 = never, None = query).  Bit-identical outputs."""
