@@ -298,6 +298,12 @@ int tgs_set_long_run(int tiles);
  * independent: nothing to exchange; same images, final_T and stop positions bit for bit).  Block-form forward with a
  * tile_order only.  factor 0 = never; negative leaves it.  Returns the factor in effect. */
 int tgs_set_k6_split(int factor);
+/* The shape of that rule (TGS_VERSION 310): `floor` = the shortest list it splits (default 256, environment TGS_K6_FLOOR, never
+ * below 64) and `heads` = how many leading entries of the schedule get the three extra blocks (default 512, TGS_K6_HEADS).  An
+ * object-centric 720p frame composites faster with factor 1, floor 128, 2048 heads (its mid-size lists are single waves on an
+ * under-occupied GPU: -1.7 % of the step), uniform frames do not (-1 %): the trainer's re-sort switches between the two
+ * (model.spatial_sort).  Negative arguments leave a setting; returns floor | heads << 16.  Bit-identical outputs. */
+int tgs_set_k6_split_shape(int floor, int heads);
 
 /* K7  compositing backward with the tactile depth/uncertainty loss fused in  (stands behind
  *     gsplat `rasterize_gaussians` bwd; spec App. B.7).

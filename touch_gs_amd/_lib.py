@@ -70,6 +70,7 @@ SIGNATURES = {
     "tgs_set_k7_quad": (C.c_int, [_I, _I]),
     "tgs_set_k6_split": (C.c_int, [_I]),
     "tgs_set_long_run": (C.c_int, [_I]),
+    "tgs_set_k6_split_shape": (C.c_int, [_I, _I]),
     "tgs_slot_ok_len": (C.c_size_t, [_I, _I, C.c_int64]),
     "tgs_rasterize_bwd": (C.c_int, [C.POINTER(TgsCamera)] + [_P] * 4 + [C.c_int64] + [_P] * 8 + [C.POINTER(TgsLossSpec), _P, _P, _P, C.POINTER(TgsRasterOpts), _P]),
     "tgs_rasterize_bwd_band": (C.c_int, [C.POINTER(TgsCamera)] + [_P] * 4 + [C.c_int64] + [_P] * 8 + [C.POINTER(TgsLossSpec), _P, _P, _I, _P, C.POINTER(TgsRasterOpts), _P]),

@@ -2291,6 +2291,15 @@ extern "C" int tgs_set_raster_variant(int k6_blocks_on, int k7_front_to_back) {
   if (k7_front_to_back >= 0) g_k7_f2b.set(k7_front_to_back);
   return (g_k6_blocks.get() ? 1 : 0) | (g_k7_f2b.get() ? 2 : 0);
 }
+// the split's shape: the shortest list it applies to (never below 64: one staged batch) and how many entries of the schedule
+// get extra blocks (tgs_set_k6_split_shape; the trainer widens both for object-centric models, model.spatial_sort)
+static RasterDefault g_k6_floor{"TGS_K6_FLOOR", 256, false};
+static RasterDefault g_k6_heads{"TGS_K6_HEADS", 512, false};
+extern "C" int tgs_set_k6_split_shape(int floor, int heads) {
+  if (floor >= 0) g_k6_floor.set(floor);
+  if (heads >= 0) g_k6_heads.set(heads > 65535 ? 65535 : heads);
+  return g_k6_floor.get() | (g_k6_heads.get() << 16);
+}
 extern "C" int tgs_set_k6_split(int factor) {
   if (factor >= 0) g_k6_split.set(factor);
   return g_k6_split.get();
@@ -2338,10 +2347,8 @@ extern "C" int tgs_rasterize_fwd(const TgsCamera* cam, const float* splats,
     SplitRule sr;
     sr.factor = tile_order ? opt_or(opts, &TgsRasterOpts::k6_split, g_k6_split) : 0;
     sr.n_slots = grid;
-    static const int env_heads = [] { const char* e = getenv("TGS_K6_HEADS"); return e ? atoi(e) : 512; }();
-    sr.heads = sr.factor > 0 ? min(grid, env_heads) : 0;
-    static const int env_floor = [] { const char* e = getenv("TGS_K6_FLOOR"); return e ? atoi(e) : 256; }();
-    sr.floor = env_floor;
+    sr.heads = sr.factor > 0 ? min(grid, g_k6_heads.get()) : 0;
+    sr.floor = max(64, g_k6_floor.get());
     const int blocks = grid + 3 * sr.heads;
     if (final_idx)
       hipLaunchKernelGGL(k_raster_fwd_blocks<true>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, k, T, splats,

@@ -369,6 +369,15 @@ class DepthGaussianSplattingModel:
                 long_run = 8 if share > 0.3 else 32
             if long_run != ops.set_long_run():
                 ops.set_long_run(long_run)
+            if self.config.long_run <= 0:
+                # the same regime wants K6 to split more of its lists (tgs_set_k6_split_shape: -1.7 % of the step on the 720p
+                # checkpoints, +1 % on uniform frames); the process's own settings are kept for everything else
+                if getattr(self, "_k6_rule", None) is None:
+                    self._k6_rule = (ops.set_k6_split(), ops.set_k6_split_shape())
+                if share > 0.3:
+                    ops.set_k6_split(1); ops.set_k6_split_shape(128, 2048)
+                else:
+                    ops.set_k6_split(self._k6_rule[0]); ops.set_k6_split_shape(*self._k6_rule[1])
         perm = balanced_order(self.params.means, hits, long_run=long_run)
         self.params.permute_(perm, self.optimizer.exp_avg, self.optimizer.exp_avg_sq)
         density = getattr(self, "density", None)

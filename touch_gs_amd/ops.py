@@ -415,6 +415,13 @@ def set_raster_variant(k6_blocks: Optional[bool] = None, k7_front_to_back: Optio
     return _lib.load().tgs_set_raster_variant(f(k6_blocks), f(k7_front_to_back))
 
 
+def set_k6_split_shape(floor: Optional[int] = None, heads: Optional[int] = None):
+    """The shape of K6's split rule (tgs_set_k6_split_shape): the shortest list it splits and how many leading entries of
+    the schedule get extra blocks.  None leaves a setting.  Returns (floor, heads)."""
+    r = _lib.load().tgs_set_k6_split_shape(-1 if floor is None else int(floor), -1 if heads is None else int(heads))
+    return r & 0xffff, r >> 16
+
+
 def set_long_run(tiles: Optional[int] = None) -> int:
     """Binning: Gaussians covering more than ``tiles`` tiles are long runs (tgs_set_long_run; default 32, None = query):
     counted outside the group's aggregated box, their partial records summed by the whole workgroup in K8."""
